@@ -1,0 +1,7 @@
+"""flingbot_amd -- MI355X-native FlingBot cloth hot path (solver + rasteriser + value-map CNN).
+
+The compute lives in hand-written HIP kernels behind the C-ABI of include/flingsim.h; this package is the thin host
+side: `sim` (batched ctypes binding), `pyflex_native/pyflex` (pybind11 module with the reference's pyflex surface),
+`nets` (learning/nets.py module surface on PyTorch-ROCm).
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,552 @@
+// fs_capi.hip -- C-ABI of libflingsim (include/flingsim.h) and the context runtime.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/flingsim.h"
+#include "fs_context.h"
+
+static thread_local std::string g_err;
+void fs_set_error(const std::string &msg) { g_err = msg; }
+bool fs_hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    fs_set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(call)                                   \
+    do {                                                \
+        if (!fs_hip_ok((call), #call)) return FS_ERR_HIP; \
+    } while (0)
+
+extern "C" const char *fs_last_error(void) { return g_err.c_str(); }
+extern "C" int fs_version(void) { return 100; }
+
+FsTopologyDev::~FsTopologyDev() {
+    if (slab) (void)hipFree(slab);
+}
+
+fs_ctx::~fs_ctx() {
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &e : envs)
+        if (e.slab) (void)hipFree(e.slab);
+    envs.clear();
+    topo_cache.clear();
+    if (d_envs) (void)hipFree(d_envs);
+    if (d_shapes) (void)hipFree(d_shapes);
+    if (d_ids) (void)hipFree(d_ids);
+    if (h_ids) (void)hipHostFree(h_ids);
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (render_scratch) (void)hipFree(render_scratch);
+    if (d_coverage) (void)hipFree(d_coverage);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+void *fs_stage(fs_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_stage_bytes) return ctx->h_stage;
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->h_stage_bytes = 0;
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+    if (!fs_hip_ok(hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault), "hipHostMalloc(stage)")) return nullptr;
+    ctx->h_stage_bytes = want;
+    return ctx->h_stage;
+}
+
+extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camera_height) {
+    if (n_envs < 1 || n_envs > (1 << 20)) { fs_set_error("n_envs out of range"); return nullptr; }
+    int count = 0;
+    if (!fs_hip_ok(hipGetDeviceCount(&count), "hipGetDeviceCount") || count <= 0) {
+        if (count <= 0) fs_set_error("no HIP device visible: libflingsim has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= count) { fs_set_error("device index out of range"); return nullptr; }
+    if (!fs_hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+    fs_ctx *ctx = new fs_ctx();
+    ctx->device = device;
+    ctx->n_envs = n_envs;
+    ctx->cam_width = camera_width > 0 ? camera_width : 720;
+    ctx->cam_height = camera_height > 0 ? camera_height : 720;
+    ctx->envs.resize(n_envs);
+    for (auto &e : ctx->envs) {
+        memset(&e.dev, 0, sizeof(e.dev));
+        memset(&e.shapes, 0, sizeof(e.shapes));
+        e.cam.width = ctx->cam_width;
+        e.cam.height = ctx->cam_height;
+    }
+    bool ok = fs_hip_ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_envs, sizeof(FsEnvDev) * n_envs), "hipMalloc(envs)") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_shapes, sizeof(FsShapesDev) * n_envs), "hipMalloc(shapes)") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_ids, sizeof(int) * n_envs), "hipMalloc(ids)") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_coverage, sizeof(float) * n_envs), "hipMalloc(cov)") &&
+              fs_hip_ok(hipHostMalloc((void **)&ctx->h_ids, sizeof(int) * n_envs, hipHostMallocDefault), "hipHostMalloc") &&
+              fs_hip_ok(hipMemset(ctx->d_envs, 0, sizeof(FsEnvDev) * n_envs), "hipMemset") &&
+              fs_hip_ok(hipMemset(ctx->d_shapes, 0, sizeof(FsShapesDev) * n_envs), "hipMemset");
+    if (!ok) {
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
+extern "C" int fs_n_envs(const fs_ctx *ctx) { return ctx ? ctx->n_envs : FS_ERR_ARG; }
+extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
+    if (!ctx || solver < 0 || solver > 2) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    ctx->solver = solver;
+    return FS_OK;
+}
+extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
+extern "C" void *fs_stream(fs_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+static FsEnv *get_env(fs_ctx *ctx, int env, bool need_scene = true) {
+    if (!ctx) { fs_set_error("null context"); return nullptr; }
+    if (env < 0 || env >= ctx->n_envs) { fs_set_error("env index out of range"); return nullptr; }
+    FsEnv *e = &ctx->envs[env];
+    if (need_scene && !e->has_scene) { fs_set_error("env has no scene: call fs_set_scene first"); return nullptr; }
+    return e;
+}
+
+static uint64_t fnv(uint64_t h, const void *data, size_t bytes) {
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+static size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+// carve helper
+struct Carver {
+    char *base;
+    size_t off = 0;
+    template <typename T> T *take(size_t count) {
+        T *p = base ? (T *)(base + off) : nullptr;
+        off += align_up(sizeof(T) * count);
+        return p;
+    }
+};
+
+static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostScene &s) {
+    uint64_t key = 1469598103934665603ull;
+    key = fnv(key, s.pos.data(), s.pos.size() * 4);
+    key = fnv(key, s.springs.data(), s.springs.size() * 4);
+    key = fnv(key, s.spring_len.data(), s.spring_len.size() * 4);
+    key = fnv(key, s.spring_k.data(), s.spring_k.size() * 4);
+    key = fnv(key, s.tris.data(), s.tris.size() * 4);
+    for (auto it = ctx->topo_cache.begin(); it != ctx->topo_cache.end();) {
+        auto sp = it->lock();
+        if (!sp) { it = ctx->topo_cache.erase(it); continue; }
+        if (sp->key == key && sp->n == s.n && sp->m == s.m && sp->t == s.t) return sp;
+        ++it;
+    }
+    auto topo = std::make_shared<FsTopologyDev>();
+    topo->key = key; topo->n = s.n; topo->m = s.m; topo->t = s.t; topo->max_deg = s.max_deg;
+    const size_t n = s.n, m2 = size_t(2) * s.m, ell = size_t(s.max_deg) * s.n;
+    auto carve = [&](char *base) {
+        Carver c{base};
+        topo->rest = c.take<FsVec4>(n);
+        topo->adj_off = c.take<int>(n + 1);
+        topo->adj_j = c.take<int>(m2 + 1);
+        topo->adj_len = c.take<float>(m2 + 1);
+        topo->adj_k = c.take<float>(m2 + 1);
+        topo->ell_j = c.take<int>(ell + 1);
+        topo->ell_len = c.take<float>(ell + 1);
+        topo->ell_k = c.take<float>(ell + 1);
+        topo->tris = c.take<int>(size_t(3) * s.t + 1);
+        return c.off;
+    };
+    topo->bytes = carve(nullptr);
+    if (!fs_hip_ok(hipMalloc(&topo->slab, topo->bytes), "hipMalloc(topology)")) return nullptr;
+    carve((char *)topo->slab);
+    bool ok = true;
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        if (bytes) ok = ok && fs_hip_ok(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(topology)");
+    };
+    up(topo->rest, s.pos.data(), n * 16);
+    up(topo->adj_off, s.adj_off.data(), (n + 1) * 4);
+    up(topo->adj_j, s.adj_j.data(), m2 * 4);
+    up(topo->adj_len, s.adj_len.data(), m2 * 4);
+    up(topo->adj_k, s.adj_k.data(), m2 * 4);
+    up(topo->ell_j, s.ell_j.data(), ell * 4);
+    up(topo->ell_len, s.ell_len.data(), ell * 4);
+    up(topo->ell_k, s.ell_k.data(), ell * 4);
+    up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
+    if (!ok) return nullptr;
+    ctx->topo_cache.push_back(topo);
+    return topo;
+}
+
+static int push_env_desc(fs_ctx *ctx, int env) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_envs + env, &ctx->envs[env].dev, sizeof(FsEnvDev), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+static int push_shapes(fs_ctx *ctx, int env) {
+    HIP_TRY(hipMemcpyAsync(ctx->d_shapes + env, &ctx->envs[env].shapes, sizeof(FsShapesDev), hipMemcpyHostToDevice,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int n_params, const float *verts,
+                            int n_vert_floats, const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints,
+                            const int *shear, int n_shear_ints, const int *faces, int n_face_ints) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    FsHostScene scene;
+    std::string err = fs_build_scene(scene, scene_params, n_params, verts, n_vert_floats, stretch, n_stretch_ints, bend,
+                                     n_bend_ints, shear, n_shear_ints, faces, n_face_ints);
+    if (!err.empty()) { fs_set_error(err); return FS_ERR_ARG; }
+    // Init tears down the previous solver, buffers and shapes (main.cpp:623-706)
+    if (e->slab) { (void)hipFree(e->slab); e->slab = nullptr; }
+    e->has_scene = false;
+    e->topo.reset();
+    auto topo = make_topology(ctx, scene);
+    if (!topo) return FS_ERR_HIP;
+
+    const size_t n = scene.n;
+    FsEnvDev d;
+    memset(&d, 0, sizeof(d));
+    auto carve = [&](char *base) {
+        Carver c{base};
+        d.pos = c.take<FsVec4>(n);
+        d.vel = c.take<FsVec4>(n);
+        d.phase = c.take<int>(n);
+        d.x0 = c.take<FsVec4>(n);
+        d.v0 = c.take<FsVec4>(n);
+        d.xa = c.take<FsVec4>(n);
+        d.xb = c.take<FsVec4>(n);
+        d.ncount = c.take<int>(n);
+        d.nlist = c.take<int>(n * FS_MAX_NEIGHBORS);
+        d.cell_count = c.take<int>(FS_GRID_BUCKETS + 1);
+        d.cell_fill = c.take<int>(FS_GRID_BUCKETS + 1);
+        d.cell_items = c.take<int>(n);
+        return c.off;
+    };
+    size_t bytes = carve(nullptr);
+    void *slab = nullptr;
+    HIP_TRY(hipMalloc(&slab, bytes));
+    carve((char *)slab);
+    HIP_TRY(hipMemset(slab, 0, bytes));
+    d.n = scene.n; d.m = scene.m; d.max_deg = scene.max_deg; d.has_scene = 1;
+    d.rest = topo->rest; d.adj_off = topo->adj_off; d.adj_j = topo->adj_j; d.adj_len = topo->adj_len; d.adj_k = topo->adj_k;
+    d.ell_j = topo->ell_j; d.ell_len = topo->ell_len; d.ell_k = topo->ell_k;
+    d.p = scene.params;
+
+    // uploads (main.cpp:1025-1085): positions, velocities (zero), phases
+    std::vector<float> vel4(n * 4, 0.0f);
+    HIP_TRY(hipMemcpy(d.pos, scene.pos.data(), n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.vel, vel4.data(), n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.phase, scene.phase.data(), n * 4, hipMemcpyHostToDevice));
+
+    e->slab = slab; e->slab_bytes = bytes; e->dev = d; e->topo = topo;
+    e->host = std::move(scene);
+    memset(&e->shapes, 0, sizeof(e->shapes));  // shapes wiped by Init (main.cpp:701-706)
+    // CenterCamera (softgym_cloth.h:177-183)
+    for (int k = 0; k < 3; ++k) { e->cam.pos[k] = e->host.cam_pos[k]; e->cam.angle[k] = e->host.cam_angle[k]; }
+    e->cam.width = e->host.cam_width > 0 ? e->host.cam_width : ctx->cam_width;
+    e->cam.height = e->host.cam_height > 0 ? e->host.cam_height : ctx->cam_height;
+    e->has_scene = true;
+    int rc = push_env_desc(ctx, env);
+    if (rc != FS_OK) return rc;
+    return push_shapes(ctx, env);
+}
+
+extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
+    if (!ctx) { fs_set_error("null context"); return FS_ERR_ARG; }
+    if (n_steps < 0) { fs_set_error("n_steps < 0"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int> ids;
+    if (env == -1) {
+        for (int i = 0; i < ctx->n_envs; ++i)
+            if (ctx->envs[i].has_scene) ids.push_back(i);
+    } else {
+        if (!get_env(ctx, env)) return FS_ERR_ARG;
+        ids.push_back(env);
+    }
+    if (ids.empty() || n_steps == 0) return FS_OK;
+    int solver = ctx->solver;
+    if (solver == FS_SOLVER_AUTO) {
+        solver = FS_SOLVER_FUSED;
+        for (int id : ids)
+            if (!fs_fused_supported(ctx, ctx->envs[id])) solver = FS_SOLVER_STREAM;
+    } else if (solver == FS_SOLVER_FUSED) {
+        for (int id : ids)
+            if (!fs_fused_supported(ctx, ctx->envs[id])) {
+                fs_set_error("FS_SOLVER_FUSED: episode does not fit the LDS-resident kernel");
+                return FS_ERR_STATE;
+            }
+    }
+    return solver == FS_SOLVER_FUSED ? fs_step_fused(ctx, ids, n_steps) : fs_step_stream(ctx, ids, n_steps);
+}
+
+extern "C" int fs_sync(fs_ctx *ctx) {
+    if (!ctx) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+
+extern "C" int fs_n_particles(const fs_ctx *ctx, int env) {
+    FsEnv *e = get_env((fs_ctx *)ctx, env);
+    return e ? e->host.n : FS_ERR_ARG;
+}
+extern "C" int fs_n_springs(const fs_ctx *ctx, int env) {
+    FsEnv *e = get_env((fs_ctx *)ctx, env);
+    return e ? e->host.m : FS_ERR_ARG;
+}
+extern "C" int fs_n_triangles(const fs_ctx *ctx, int env) {
+    FsEnv *e = get_env((fs_ctx *)ctx, env);
+    return e ? e->host.t : FS_ERR_ARG;
+}
+extern "C" int fs_n_shapes(const fs_ctx *ctx, int env) {
+    FsEnv *e = get_env((fs_ctx *)ctx, env, false);
+    return e ? e->shapes.count : FS_ERR_ARG;
+}
+
+// ---- device <-> host accessors through the pinned staging buffer
+static int d2h(fs_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    void *st = fs_stage(ctx, bytes);
+    if (!st) return FS_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(dst, st, bytes);
+    return FS_OK;
+}
+static int h2d(fs_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    void *st = fs_stage(ctx, bytes);
+    if (!st) return FS_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // staging buffer may still be in flight
+    memcpy(st, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return FS_OK;
+}
+#define CHECK_LEN(have, need)                                                      \
+    do {                                                                           \
+        if ((have) < (need)) { fs_set_error("buffer too small"); return FS_ERR_ARG; } \
+    } while (0)
+
+extern "C" int fs_get_positions(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 4 * e->host.n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return d2h(ctx, out, e->dev.pos, size_t(16) * e->host.n);
+}
+extern "C" int fs_set_positions(fs_ctx *ctx, int env, const float *in, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !in) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 4 * e->host.n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return h2d(ctx, e->dev.pos, in, size_t(16) * e->host.n);
+}
+extern "C" int fs_get_velocities(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    const int n = e->host.n;
+    CHECK_LEN(n_floats, 3 * n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<float> tmp(size_t(4) * n);
+    int rc = d2h(ctx, tmp.data(), e->dev.vel, size_t(16) * n);
+    if (rc != FS_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = tmp[4 * size_t(i) + k];
+    return FS_OK;
+}
+extern "C" int fs_set_velocities(fs_ctx *ctx, int env, const float *in, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !in) return FS_ERR_ARG;
+    const int n = e->host.n;
+    CHECK_LEN(n_floats, 3 * n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<float> tmp(size_t(4) * n, 0.0f);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) tmp[4 * size_t(i) + k] = in[3 * i + k];
+    return h2d(ctx, e->dev.vel, tmp.data(), size_t(16) * n);
+}
+extern "C" int fs_get_phases(fs_ctx *ctx, int env, int *out, int n_ints) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_ints, e->host.n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return d2h(ctx, out, e->dev.phase, size_t(4) * e->host.n);
+}
+extern "C" int fs_set_phases(fs_ctx *ctx, int env, const int *in, int n_ints) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !in) return FS_ERR_ARG;
+    CHECK_LEN(n_ints, e->host.n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return h2d(ctx, e->dev.phase, in, size_t(4) * e->host.n);
+}
+extern "C" int fs_get_rest_positions(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 4 * e->host.n);
+    memcpy(out, e->host.pos.data(), size_t(16) * e->host.n);
+    return FS_OK;
+}
+extern "C" int fs_get_normals(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 4 * e->host.n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return fs_normals_env(ctx, env, out);
+}
+extern "C" int fs_get_edges(fs_ctx *ctx, int env, int *out, int n_ints) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_ints, 2 * e->host.m);
+    memcpy(out, e->host.springs.data(), size_t(8) * e->host.m);
+    return FS_OK;
+}
+extern "C" int fs_get_faces(fs_ctx *ctx, int env, int *out, int n_ints) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_ints, 3 * e->host.t);
+    memcpy(out, e->host.tris.data(), size_t(12) * e->host.t);
+    return FS_OK;
+}
+extern "C" int fs_get_spring_lengths(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, e->host.m);
+    memcpy(out, e->host.spring_len.data(), size_t(4) * e->host.m);
+    return FS_OK;
+}
+extern "C" int fs_get_spring_stiffness(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, e->host.m);
+    memcpy(out, e->host.spring_k.data(), size_t(4) * e->host.m);
+    return FS_OK;
+}
+extern "C" int fs_get_params(fs_ctx *ctx, int env, float *o, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !o) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 32);
+    const FsParams &p = e->dev.p;
+    memset(o, 0, sizeof(float) * 32);
+    o[0] = (float)p.numIterations; o[1] = (float)p.numSubsteps; o[2] = p.dt;
+    o[3] = p.gravity[0]; o[4] = p.gravity[1]; o[5] = p.gravity[2];
+    o[6] = p.radius; o[7] = p.solidRestDistance; o[8] = p.collisionDistance; o[9] = p.shapeCollisionMargin;
+    o[10] = p.particleCollisionMargin; o[11] = p.dynamicFriction; o[12] = p.staticFriction; o[13] = p.particleFriction;
+    o[14] = p.damping; o[15] = p.sleepThreshold; o[16] = p.relaxationFactor; o[17] = p.maxAcceleration;
+    o[18] = p.maxSpeed; o[19] = p.restitution; o[20] = p.adhesion; o[21] = p.dissipation;
+    o[22] = (float)p.numPlanes; o[23] = p.planes[0][0]; o[24] = p.planes[0][1]; o[25] = p.planes[0][2];
+    o[26] = p.planes[0][3]; o[27] = (float)p.maxNeighbors; o[28] = (float)p.maxContacts; o[29] = (float)p.relaxationMode;
+    return FS_OK;
+}
+extern "C" int fs_get_scene_bounds(fs_ctx *ctx, int env, float *lower3, float *upper3) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !lower3 || !upper3) return FS_ERR_ARG;
+    memcpy(lower3, e->host.scene_lower, 12);
+    memcpy(upper3, e->host.scene_upper, 12);
+    return FS_OK;
+}
+
+// ---- shapes
+extern "C" int fs_add_sphere(fs_ctx *ctx, int env, float radius, const float *pos3, const float *quat4) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e || !pos3 || !quat4) return FS_ERR_ARG;
+    if (e->shapes.count >= FS_MAX_SHAPES) { fs_set_error("too many shapes"); return FS_ERR_STATE; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int q = e->shapes.count++;
+    e->shapes.pos[q] = FsVec4{pos3[0], pos3[1], pos3[2], radius};
+    e->shapes.prev[q] = FsVec4{pos3[0], pos3[1], pos3[2], radius};  // prev := current (helpers.h:493-494)
+    for (int k = 0; k < 4; ++k) { e->shape_rot[q][k] = quat4[k]; e->shape_prev_rot[q][k] = quat4[k]; }
+    return push_shapes(ctx, env);
+}
+extern "C" int fs_clear_shapes(fs_ctx *ctx, int env) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    e->shapes.count = 0;
+    return push_shapes(ctx, env);
+}
+extern "C" int fs_get_shape_states(fs_ctx *ctx, int env, float *out, int n_floats) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 14 * e->shapes.count);
+    for (int q = 0; q < e->shapes.count; ++q) {
+        float *o = out + 14 * q;
+        o[0] = e->shapes.pos[q].x; o[1] = e->shapes.pos[q].y; o[2] = e->shapes.pos[q].z;
+        o[3] = e->shapes.prev[q].x; o[4] = e->shapes.prev[q].y; o[5] = e->shapes.prev[q].z;
+        for (int k = 0; k < 4; ++k) { o[6 + k] = e->shape_rot[q][k]; o[10 + k] = e->shape_prev_rot[q][k]; }
+    }
+    return FS_OK;
+}
+extern "C" int fs_set_shape_states(fs_ctx *ctx, int env, const float *in, int n_floats) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e) return FS_ERR_ARG;
+    if (e->shapes.count == 0) return FS_OK;  // loops over the internal count (pyflex.cpp:839)
+    if (!in) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 14 * e->shapes.count);
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (int q = 0; q < e->shapes.count; ++q) {
+        const float *o = in + 14 * q;
+        e->shapes.pos[q].x = o[0]; e->shapes.pos[q].y = o[1]; e->shapes.pos[q].z = o[2];
+        e->shapes.prev[q].x = o[3]; e->shapes.prev[q].y = o[4]; e->shapes.prev[q].z = o[5];
+        for (int k = 0; k < 4; ++k) { e->shape_rot[q][k] = o[6 + k]; e->shape_prev_rot[q][k] = o[10 + k]; }
+    }
+    return push_shapes(ctx, env);
+}
+
+// ---- camera (asymmetric layouts are the reference's: pyflex.cpp:891-922)
+extern "C" int fs_get_camera_params(fs_ctx *ctx, int env, float *o) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e || !o) return FS_ERR_ARG;
+    o[0] = (float)e->cam.width; o[1] = (float)e->cam.height;
+    for (int k = 0; k < 3; ++k) { o[2 + k] = e->cam.pos[k]; o[5 + k] = e->cam.angle[k]; }
+    return FS_OK;
+}
+extern "C" int fs_set_camera_params(fs_ctx *ctx, int env, const float *in) {
+    FsEnv *e = get_env(ctx, env, false);
+    if (!e || !in) return FS_ERR_ARG;
+    for (int k = 0; k < 3; ++k) { e->cam.pos[k] = in[k]; e->cam.angle[k] = in[3 + k]; }
+    e->cam.width = (int)in[6];
+    e->cam.height = (int)in[7];
+    return FS_OK;
+}
+
+extern "C" int fs_render(fs_ctx *ctx, int env, unsigned char *rgba, int n_bytes, float *depth, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !rgba || !depth) return FS_ERR_ARG;
+    const int px = e->cam.width * e->cam.height;
+    CHECK_LEN(n_bytes, 4 * px);
+    CHECK_LEN(n_floats, px);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return fs_render_env(ctx, env, rgba, depth);
+}
+
+extern "C" int fs_coverage(fs_ctx *ctx, float *out, int n_floats) {
+    if (!ctx || !out) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, ctx->n_envs);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return fs_coverage_all(ctx, out);
+}
+
+extern "C" int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !counts || !lists) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = e->host.n;
+    int rc = d2h(ctx, counts, e->dev.ncount, size_t(4) * n);
+    if (rc != FS_OK) return rc;
+    std::vector<int> slotmajor(size_t(n) * FS_MAX_NEIGHBORS);
+    rc = d2h(ctx, slotmajor.data(), e->dev.nlist, slotmajor.size() * 4);
+    if (rc != FS_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        for (int s = 0; s < FS_MAX_NEIGHBORS; ++s)
+            lists[size_t(i) * FS_MAX_NEIGHBORS + s] = s < counts[i] ? slotmajor[size_t(s) * n + i] : -1;
+    return FS_OK;
+}
+
+extern "C" void *fs_device_positions(fs_ctx *ctx, int env) {
+    FsEnv *e = get_env(ctx, env);
+    return e ? (void *)e->dev.pos : nullptr;
+}

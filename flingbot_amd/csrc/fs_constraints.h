@@ -1,0 +1,182 @@
+// fs_constraints.h -- per-particle constraint projections shared by the streaming and the fused LDS solver kernels.
+//
+// Jacobi with local relaxation (reference NvFlex.h:86-90,152-153): every constraint touching particle i adds its
+// position delta to an accumulator and bumps a counter; the particle then moves by relaxationFactor * delta / count.
+// Accumulation order per particle is fixed (springs by ascending spring id, particle contacts by ascending
+// neighbour id, planes, spheres) and the build uses -ffp-contract=off, so results do not depend on the launch
+// geometry and are reproducible bit for bit.
+//
+// Semantics: distance constraints NvFlex.h:656-667, solidRestDistance :101, particleFriction :107, inelastic
+// particle contacts :108, collisionDistance :145, dynamic/static friction :105-106, planes :149, shapes :941-987.
+// The friction model (positional Coulomb friction on the tangential displacement since the substep start) follows
+// Macklin et al. 2014, section 6.1 -- the closed-source reference cannot be consulted.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fs_types.h"
+
+struct FsAcc {
+    float d0, d1, d2;
+    int cnt;
+};
+
+__device__ __forceinline__ float fs_friction_scale(float tl, float pen, float mu_s, float mu_k) {
+    if (tl < mu_s * pen) return 1.0f;
+    float lim = mu_k * pen;
+    return (tl > lim) ? lim / tl : 1.0f;
+}
+
+// distance constraint between particle i (xi, wi) and j (xj.w = invMass), rest length L, stiffness k (<0: tether)
+__device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float xi2, float wi, const FsVec4 xj, float L,
+                                          float k) {
+    float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
+    float l2 = ex * ex + ey * ey + ez * ez;
+    float len = sqrtf(l2);
+    if (!(len > 0.0f)) return;
+    float C = len - L;
+    if (k < 0.0f) {
+        if (!(C > 0.0f)) return;
+        k = -k;
+    }
+    float ratio = wi / (wi + xj.w);
+    float sc = (k * ratio) * (C / len);
+    a.d0 = a.d0 - ex * sc;
+    a.d1 = a.d1 - ey * sc;
+    a.d2 = a.d2 - ez * sc;
+    a.cnt++;
+}
+
+// particle-particle contact; (ri*) = xi - x0_i, rj = xj - x0_j (displacement since substep start)
+__device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float xi1, float xi2, float wi, float ri0,
+                                                    float ri1, float ri2, const FsVec4 xj, float rj0, float rj1,
+                                                    float rj2, float restd, float restd2, float mu) {
+    float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
+    float l2 = ex * ex + ey * ey + ez * ez;
+    if (!(l2 < restd2)) return;
+    float dist = sqrtf(l2);
+    float nx, ny, nz;
+    if (dist > 0.0f) {
+        float inv = 1.0f / dist;
+        nx = ex * inv; ny = ey * inv; nz = ez * inv;
+    } else {
+        nx = 0.0f; ny = 1.0f; nz = 0.0f;
+    }
+    float pen = restd - dist;
+    float ratio = wi / (wi + xj.w);
+    float cn = pen * ratio;
+    float c0 = nx * cn, c1 = ny * cn, c2 = nz * cn;
+    if (mu > 0.0f) {
+        float rx = ri0 - rj0, ry = ri1 - rj1, rz = ri2 - rj2;
+        float rn = rx * nx + ry * ny + rz * nz;
+        float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
+        float tl2 = tx * tx + ty * ty + tz * tz;
+        if (tl2 > 0.0f) {
+            float tl = sqrtf(tl2);
+            float fs = fs_friction_scale(tl, pen, mu, mu) * ratio;
+            c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+        }
+    }
+    a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
+    a.cnt++;
+}
+
+__device__ __forceinline__ void fs_plane_contact(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
+                                                 float ri2, float p0, float p1, float p2, float p3, float cd, float mu_s,
+                                                 float mu_k) {
+    float sdist = p0 * xi0 + p1 * xi1 + p2 * xi2 + p3;
+    if (!(sdist < cd)) return;
+    float pen = cd - sdist;
+    float c0 = p0 * pen, c1 = p1 * pen, c2 = p2 * pen;
+    float rn = ri0 * p0 + ri1 * p1 + ri2 * p2;
+    float tx = ri0 - p0 * rn, ty = ri1 - p1 * rn, tz = ri2 - p2 * rn;
+    float tl2 = tx * tx + ty * ty + tz * tz;
+    if (tl2 > 0.0f) {
+        float tl = sqrtf(tl2);
+        float fs = fs_friction_scale(tl, pen, mu_s, mu_k);
+        c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+    }
+    a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
+    a.cnt++;
+}
+
+// kinematic sphere at centre (c*) with radius r, which moved by (s*) during this substep
+__device__ __forceinline__ void fs_sphere_contact(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
+                                                  float ri2, float c0_, float c1_, float c2_, float r, float s0,
+                                                  float s1, float s2, float cd, float mu_s, float mu_k) {
+    float ex = xi0 - c0_, ey = xi1 - c1_, ez = xi2 - c2_;
+    float l2 = ex * ex + ey * ey + ez * ez;
+    float lim = r + cd;
+    if (!(l2 < lim * lim)) return;
+    float dist = sqrtf(l2);
+    float nx, ny, nz;
+    if (dist > 0.0f) {
+        float inv = 1.0f / dist;
+        nx = ex * inv; ny = ey * inv; nz = ez * inv;
+    } else {
+        nx = 0.0f; ny = 1.0f; nz = 0.0f;
+    }
+    float pen = lim - dist;
+    float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
+    float rx = ri0 - s0, ry = ri1 - s1, rz = ri2 - s2;
+    float rn = rx * nx + ry * ny + rz * nz;
+    float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
+    float tl2 = tx * tx + ty * ty + tz * tz;
+    if (tl2 > 0.0f) {
+        float tl = sqrtf(tl2);
+        float fs = fs_friction_scale(tl, pen, mu_s, mu_k);
+        c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+    }
+    a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
+    a.cnt++;
+}
+
+// sphere centre at the end of substep `sub` (0-based) and its displacement during the substep: linear sweep from the
+// previous to the current transform over the frame.
+__device__ __forceinline__ void fs_shape_sweep(const FsShapesDev &sh, int q, int sub, float S, float &c0, float &c1,
+                                               float &c2, float &s0, float &s1, float &s2) {
+    float a1 = (float)(sub + 1) / S, a0 = (float)sub / S;
+    float dx = sh.pos[q].x - sh.prev[q].x, dy = sh.pos[q].y - sh.prev[q].y, dz = sh.pos[q].z - sh.prev[q].z;
+    c0 = sh.prev[q].x + dx * a1; c1 = sh.prev[q].y + dy * a1; c2 = sh.prev[q].z + dz * a1;
+    float b0 = sh.prev[q].x + dx * a0, b1 = sh.prev[q].y + dy * a0, b2 = sh.prev[q].z + dz * a0;
+    s0 = c0 - b0; s1 = c1 - b1; s2 = c2 - b2;
+}
+
+// planes + spheres for one particle (order: planes ascending, spheres ascending)
+__device__ __forceinline__ void fs_shape_contacts(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
+                                                  float ri2, const FsParams &p, const FsShapesDev &sh, int sub) {
+    for (int q = 0; q < p.numPlanes; ++q)
+        fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
+                         p.collisionDistance, p.staticFriction, p.dynamicFriction);
+    const float S = (float)p.numSubsteps;
+    for (int q = 0; q < sh.count; ++q) {
+        float c0, c1, c2, s0, s1, s2;
+        fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
+        fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, p.collisionDistance,
+                          p.staticFriction, p.dynamicFriction);
+    }
+}
+
+// applyDeltas with local relaxation
+__device__ __forceinline__ void fs_apply(const FsAcc &a, float relax, float &x0, float &x1, float &x2) {
+    if (a.cnt > 0) {
+        float sc = relax / (float)a.cnt;
+        x0 = x0 + a.d0 * sc; x1 = x1 + a.d1 * sc; x2 = x2 + a.d2 * sc;
+    }
+}
+
+// neighbour-search pair filter on phases and rest pose (NvFlex.h:165-166,564-565)
+__device__ __forceinline__ bool fs_pair_allowed(int phi, int phj, const FsVec4 ri, const FsVec4 rj, float r2) {
+    if ((phi & FS_PHASE_GROUP_MASK) == (phj & FS_PHASE_GROUP_MASK)) {
+        if (!((phi & FS_PHASE_SELF_COLLIDE) && (phj & FS_PHASE_SELF_COLLIDE))) return false;
+        if ((phi | phj) & FS_PHASE_SELF_COLLIDE_FILTER) {
+            float ex = ri.x - rj.x, ey = ri.y - rj.y, ez = ri.z - rj.z;
+            float e2 = ex * ex + ey * ey + ez * ez;
+            if (e2 < r2) return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ int fs_bucket(int cx, int cy, int cz) {
+    return (cx & (FS_GRID_BX - 1)) | ((cy & (FS_GRID_BY - 1)) << 5) | ((cz & (FS_GRID_BZ - 1)) << 9);
+}

@@ -1,0 +1,82 @@
+// fs_context.h -- host runtime of libflingsim: a context owning n_envs cloth episodes on one HIP device.
+//
+// Replaces the reference's process-global demo runtime (PyFlex/bindings/main.cpp: g_solver / g_buffers / Init /
+// UpdateFrame) with a per-context object; the device arrays are the source of truth, host mirrors are materialised
+// only at the accessor boundary (pyflex.cpp:326-922 semantics).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fs_scene.h"
+#include "fs_types.h"
+
+struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
+    void *slab = nullptr;
+    size_t bytes = 0;
+    uint64_t key = 0;
+    int n = 0, m = 0, max_deg = 0;
+    FsVec4 *rest = nullptr;
+    int *adj_off = nullptr, *adj_j = nullptr;
+    float *adj_len = nullptr, *adj_k = nullptr;
+    int *ell_j = nullptr;
+    float *ell_len = nullptr, *ell_k = nullptr;
+    int *tris = nullptr;  // 3t
+    int t = 0;
+    ~FsTopologyDev();
+};
+
+struct FsCamera {
+    float pos[3] = {0, 2, 0};
+    float angle[3] = {0, 0, 0};
+    int width = 720, height = 720;
+};
+
+struct FsEnv {
+    bool has_scene = false;
+    FsHostScene host;  // topology + initial state (positions here are the INITIAL ones)
+    std::shared_ptr<FsTopologyDev> topo;
+    void *slab = nullptr;  // dynamic state + scratch
+    size_t slab_bytes = 0;
+    FsEnvDev dev;          // host copy of the descriptor
+    FsShapesDev shapes;    // host copy
+    float shape_rot[FS_MAX_SHAPES][4], shape_prev_rot[FS_MAX_SHAPES][4];
+    FsCamera cam;
+};
+
+struct fs_ctx {
+    int device = 0;
+    int n_envs = 0;
+    int solver = 0;
+    hipStream_t stream = nullptr;
+    std::vector<FsEnv> envs;
+    FsEnvDev *d_envs = nullptr;       // [n_envs]
+    FsShapesDev *d_shapes = nullptr;  // [n_envs]
+    int *d_ids = nullptr;             // [n_envs] launch list
+    int *h_ids = nullptr;             // pinned
+    void *h_stage = nullptr;          // pinned staging for accessors
+    size_t h_stage_bytes = 0;
+    std::vector<std::weak_ptr<FsTopologyDev>> topo_cache;
+    int cam_width = 720, cam_height = 720;
+    // renderer scratch (fs_render.hip)
+    void *render_scratch = nullptr;
+    size_t render_scratch_bytes = 0;
+    float *d_coverage = nullptr;
+
+    ~fs_ctx();
+};
+
+void fs_set_error(const std::string &msg);
+bool fs_hip_ok(hipError_t e, const char *what);
+void *fs_stage(fs_ctx *ctx, size_t bytes);
+
+// solver back-ends
+int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps);
+int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps);
+bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env);
+// renderer / coverage
+int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth);
+int fs_normals_env(fs_ctx *ctx, int env, float *out4n);
+int fs_coverage_all(fs_ctx *ctx, float *out);

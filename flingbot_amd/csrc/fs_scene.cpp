@@ -1,0 +1,240 @@
+// fs_scene.cpp -- see fs_scene.h.  Compiled with -ffp-contract=off: every fp32 value below must come out exactly as the
+// reference's x86 build computes it (no FMA fusion), because spring rest lengths are part of the bit-exact topology.
+#include "fs_scene.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+struct SceneAssembler {
+    FsHostScene &s;
+    explicit SceneAssembler(FsHostScene &scene) : s(scene) {}
+
+    int add_particle(float x, float y, float z, float inv_mass, int phase) {
+        int id = int(s.pos.size() / 4);
+        s.pos.insert(s.pos.end(), {x, y, z, inv_mass});
+        s.vel.insert(s.vel.end(), {0.0f, 0.0f, 0.0f});
+        s.phase.push_back(phase);
+        return id;
+    }
+
+    void add_triangle(int a, int b, int c, float nx, float ny, float nz) {
+        s.tris.insert(s.tris.end(), {a, b, c});
+        s.tri_normals.insert(s.tri_normals.end(), {nx, ny, nz});
+    }
+
+    // reference helpers.h:144-150; rest length = (1 + give) * Length(p_i - p_j), give = 0
+    void add_spring(int i, int j, float stiffness) {
+        const float *pi = &s.pos[4 * size_t(i)], *pj = &s.pos[4 * size_t(j)];
+        float ex = pi[0] - pj[0], ey = pi[1] - pj[1], ez = pi[2] - pj[2];
+        float sq = ex * ex + ey * ey + ez * ez;
+        float length = (sq != 0.0f) ? sqrtf(sq) : 0.0f;
+        s.springs.push_back(i);
+        s.springs.push_back(j);
+        s.spring_len.push_back((1.0f + 0.0f) * length);
+        s.spring_k.push_back(stiffness);
+    }
+
+    // reference helpers.h:838-924 with dz == 1: particles row-major (index = y*dx + x), two triangles per quad,
+    // then a row-major pass of [stretch x-1, bend x-2, shear (x+1,y-1), shear (x-1,y-1)] and a column-major pass of
+    // [stretch y-1, bend y-2].
+    void grid_cloth(const float lower[3], int dx, int dy, float spacing, int phase, float k_stretch, float k_bend,
+                    float k_shear, float inv_mass) {
+        const int base = int(s.pos.size() / 4);
+        auto at = [&](int x, int y) { return base + y * dx + x; };
+        for (int y = 0; y < dy; ++y) {
+            for (int x = 0; x < dx; ++x) {
+                add_particle(lower[0] + spacing * float(x), lower[1] + spacing * float(0), lower[2] + spacing * float(y),
+                             inv_mass, phase);
+                if (x > 0 && y > 0) {
+                    add_triangle(at(x - 1, y - 1), at(x, y - 1), at(x, y), 0.0f, 1.0f, 0.0f);
+                    add_triangle(at(x - 1, y - 1), at(x, y), at(x - 1, y), 0.0f, 1.0f, 0.0f);
+                }
+            }
+        }
+        for (int y = 0; y < dy; ++y) {
+            for (int x = 0; x < dx; ++x) {
+                if (x > 0) add_spring(at(x, y), at(x - 1, y), k_stretch);
+                if (x > 1) add_spring(at(x, y), at(x - 2, y), k_bend);
+                if (y > 0 && x < dx - 1) add_spring(at(x, y), at(x + 1, y - 1), k_shear);
+                if (y > 0 && x > 0) add_spring(at(x, y), at(x - 1, y - 1), k_shear);
+            }
+        }
+        for (int x = 0; x < dx; ++x) {
+            for (int y = 0; y < dy; ++y) {
+                if (y > 0) add_spring(at(x, y), at(x, y - 1), k_stretch);
+                if (y > 1) add_spring(at(x, y), at(x, y - 2), k_bend);
+            }
+        }
+    }
+
+    // reference softgym_cloth.h:69-132
+    void mesh_cloth(const float lower[3], const float *verts, int nv, const int *faces, int nf, const int *stretch,
+                    int n_stretch, const int *bend, int n_bend, const int *shear, int n_shear, float inv_mass, int phase,
+                    float k_stretch, float k_bend, float k_shear) {
+        const int base = int(s.pos.size() / 4);
+        for (int i = 0; i < nv; ++i)
+            add_particle(verts[3 * i] + lower[0], verts[3 * i + 1] + lower[1], verts[3 * i + 2] + lower[2],
+                         inv_mass + 0.0f, phase);
+        for (int f = 0; f < nf; ++f) {
+            int a = base + faces[3 * f], b = base + faces[3 * f + 1], c = base + faces[3 * f + 2];
+            const float *p1 = &s.pos[4 * size_t(a)], *p2 = &s.pos[4 * size_t(b)], *p3 = &s.pos[4 * size_t(c)];
+            float ux = p2[0] - p1[0], uy = p2[1] - p1[1], uz = p2[2] - p1[2];
+            float vx = p3[0] - p1[0], vy = p3[1] - p1[1], vz = p3[2] - p1[2];
+            float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+            float sq = nx * nx + ny * ny + nz * nz;
+            float len = (sq != 0.0f) ? sqrtf(sq) : 0.0f;
+            add_triangle(a, b, c, nx / len, ny / len, nz / len);
+        }
+        for (int e = 0; e < n_stretch; ++e) add_spring(base + stretch[2 * e], base + stretch[2 * e + 1], k_stretch);
+        for (int e = 0; e < n_bend; ++e) add_spring(base + bend[2 * e], base + bend[2 * e + 1], k_bend);
+        for (int e = 0; e < n_shear; ++e) add_spring(base + shear[2 * e], base + shear[2 * e + 1], k_shear);
+    }
+};
+
+void default_params(FsParams &p) {  // reference main.cpp:717-828
+    memset(&p, 0, sizeof(p));
+    p.dt = 1.0f / 100.0f;
+    p.gravity[1] = -9.8f;
+    p.radius = 0.15f;
+    p.numIterations = 3;
+    p.numSubsteps = 20;
+    p.maxSpeed = FLT_MAX;
+    p.maxAcceleration = 100.0f;
+    p.relaxationMode = 1;  // eNvFlexRelaxationLocal
+    p.relaxationFactor = 1.0f;
+    p.numPlanes = 1;
+    p.maxNeighbors = FS_MAX_NEIGHBORS;
+    p.maxContacts = 6;
+}
+
+void build_adjacency(FsHostScene &s) {
+    const int n = s.n, m = s.m;
+    s.adj_off.assign(size_t(n) + 1, 0);
+    for (int e = 0; e < 2 * m; ++e) s.adj_off[size_t(s.springs[e]) + 1]++;
+    int deg_max = 0;
+    for (int i = 0; i < n; ++i) {
+        if (s.adj_off[i + 1] > deg_max) deg_max = s.adj_off[i + 1];
+        s.adj_off[i + 1] += s.adj_off[i];
+    }
+    s.max_deg = deg_max;
+    s.adj_j.assign(size_t(2) * m, 0);
+    s.adj_len.assign(size_t(2) * m, 0.0f);
+    s.adj_k.assign(size_t(2) * m, 0.0f);
+    std::vector<int> cursor(s.adj_off.begin(), s.adj_off.end() - 1);
+    for (int e = 0; e < m; ++e) {  // ascending spring id per particle
+        for (int side = 0; side < 2; ++side) {
+            int i = s.springs[2 * e + side], j = s.springs[2 * e + 1 - side];
+            int slot = cursor[i]++;
+            s.adj_j[slot] = j;
+            s.adj_len[slot] = s.spring_len[e];
+            s.adj_k[slot] = s.spring_k[e];
+        }
+    }
+    s.ell_j.assign(size_t(deg_max) * n, -1);
+    s.ell_len.assign(size_t(deg_max) * n, 0.0f);
+    s.ell_k.assign(size_t(deg_max) * n, 0.0f);
+    for (int i = 0; i < n; ++i)
+        for (int a = s.adj_off[i]; a < s.adj_off[i + 1]; ++a) {
+            size_t slot = size_t(a - s.adj_off[i]) * n + i;
+            s.ell_j[slot] = s.adj_j[a];
+            s.ell_len[slot] = s.adj_len[a];
+            s.ell_k[slot] = s.adj_k[a];
+        }
+}
+
+}  // namespace
+
+std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const float *verts, int n_vert_floats,
+                           const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints, const int *shear,
+                           int n_shear_ints, const int *faces, int n_face_ints) {
+    if (!sp || n_params < 19) return "scene_params needs 19 floats (flex_utils.py:332-342)";
+    s = FsHostScene();
+    FsParams &p = s.params;
+    default_params(p);
+
+    const float cloth_spacing = 0.00625f;  // softgym_cloth.h:47
+    const int dimx = int(sp[3]), dimz = int(sp[4]);
+    const float k_stretch = sp[5], k_bend = sp[6], k_shear = sp[7];
+    s.render_mode = int(sp[8]);
+    for (int k = 0; k < 3; ++k) { s.cam_pos[k] = sp[9 + k]; s.cam_angle[k] = sp[12 + k]; }
+    s.cam_width = int(sp[15]);
+    s.cam_height = int(sp[16]);
+    const int flip_mesh = int(sp[18]);
+    // NvFlexMakePhase(0, SelfCollide | SelfCollideFilter): group 0, all shape channels (NvFlex.h:187-192)
+    const int phase = (0 & FS_PHASE_GROUP_MASK) |
+                      ((FS_PHASE_SELF_COLLIDE | FS_PHASE_SELF_COLLIDE_FILTER) & 0x00f00000) | FS_PHASE_CHANNEL_MASK;
+    const float lower[3] = {sp[0], -sp[1], sp[2]};  // y negated: softgym_cloth.h:76,136
+
+    SceneAssembler asmb(s);
+    const int nv = n_vert_floats / 3;
+    if (nv > 0) {
+        if (!verts) return "vertices pointer is null";
+        const int nf = n_face_ints / 3;
+        auto in_range = [&](const int *a, int cnt) {
+            for (int i = 0; i < cnt; ++i)
+                if (a[i] < 0 || a[i] >= nv) return false;
+            return true;
+        };
+        if (!in_range(faces, nf * 3) || !in_range(stretch, n_stretch_ints / 2 * 2) ||
+            !in_range(bend, n_bend_ints / 2 * 2) || !in_range(shear, n_shear_ints / 2 * 2))
+            return "mesh index out of range";
+        const float mass = sp[17] / float(nv);
+        asmb.mesh_cloth(lower, verts, nv, faces, nf, stretch, n_stretch_ints / 2, bend, n_bend_ints / 2, shear,
+                        n_shear_ints / 2, 1.0f / mass, phase, k_stretch, k_bend, k_shear);
+    } else {
+        if (dimx < 1 || dimz < 1 || (long long)dimx * dimz > (1 << 24)) return "bad cloth grid size";
+        const float mass = sp[17] / float(dimx * dimz);
+        asmb.grid_cloth(lower, dimx, dimz, cloth_spacing, phase, k_stretch, k_bend, k_shear, 1.0f / mass);
+    }
+    if (flip_mesh) {  // softgym_cloth.h:137-152 (folding task; triangle winding only)
+        const int first = (dimx - 1) * 1 / 8;
+        for (int j = 0; j < dimz - 1; ++j)
+            for (int i = first; i < first + 5; ++i) {
+                size_t q = size_t(j * (dimx - 1) + i) * 6;
+                if (q + 5 >= s.tris.size()) continue;
+                if (i != first + 4) std::swap(s.tris[q], s.tris[q + 1]);
+                if (i != first) std::swap(s.tris[q + 3], s.tris[q + 4]);
+            }
+    }
+
+    // softgym_cloth.h:154-170
+    p.numSubsteps = 4;
+    p.numIterations = 30;
+    p.dynamicFriction = 0.75f;
+    p.particleFriction = 1.0f;
+    p.damping = 1.0f;
+    p.sleepThreshold = 0.02f;
+    p.relaxationFactor = 1.0f;
+    p.shapeCollisionMargin = 0.04f;
+    p.radius = cloth_spacing * 1.8f;
+    p.collisionDistance = 0.005f;
+    for (int k = 0; k < 3; ++k) { s.scene_lower[k] = -1.0f; s.scene_upper[k] = 1.0f; }
+
+    // main.cpp:844-864 derived parameters
+    if (p.solidRestDistance == 0.0f) p.solidRestDistance = p.radius;
+    if (p.collisionDistance == 0.0f) p.collisionDistance = p.solidRestDistance * 0.5f;
+    if (p.particleFriction == 0.0f) p.particleFriction = p.dynamicFriction * 0.1f;
+    if (p.shapeCollisionMargin == 0.0f) p.shapeCollisionMargin = p.collisionDistance * 0.5f;
+
+    s.n = int(s.pos.size() / 4);
+    s.m = int(s.spring_len.size());
+    s.t = int(s.tris.size() / 3);
+    if (s.n == 0) return "scene has no particles";
+
+    // main.cpp:866-879 scene bounds (no shapes exist at Init time: main.cpp:701-706)
+    for (int i = 0; i < s.n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float v = s.pos[4 * size_t(i) + k];
+            if (v < s.scene_lower[k]) s.scene_lower[k] = v;
+            if (v > s.scene_upper[k]) s.scene_upper[k] = v;
+        }
+    for (int k = 0; k < 3; ++k) { s.scene_lower[k] -= p.collisionDistance; s.scene_upper[k] += p.collisionDistance; }
+    // main.cpp:882-884 ground plane (g_waveFloorTilt = 0)
+    p.planes[0][0] = 0.0f; p.planes[0][1] = 1.0f; p.planes[0][2] = 0.0f; p.planes[0][3] = 0.0f;
+
+    build_adjacency(s);
+    return "";
+}

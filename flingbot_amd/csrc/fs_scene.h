@@ -1,0 +1,40 @@
+// fs_scene.h -- host-side cloth scene builder (topology + parameters) of libflingsim.
+//
+// Rebuilds, with bit-identical index order and fp32 values, what the reference assembles in
+//   SoftgymCloth::Initialize  PyFlex/bindings/softgym_scenes/softgym_cloth.h:33-175
+//   CreateSpringGrid          PyFlex/bindings/helpers.h:838-924
+//   CreateSpring              PyFlex/bindings/helpers.h:144-150
+//   Init (defaults, derived params, bounds, normals, rest pose)  PyFlex/bindings/main.cpp:613-1122
+#pragma once
+#include <string>
+#include <vector>
+
+#include "fs_types.h"
+
+struct FsHostScene {
+    int n = 0, m = 0, t = 0;
+    std::vector<float> pos;      // 4n
+    std::vector<float> vel;      // 3n
+    std::vector<int> phase;      // n
+    std::vector<int> springs;    // 2m
+    std::vector<float> spring_len, spring_k;  // m
+    std::vector<int> tris;       // 3t
+    std::vector<float> tri_normals;  // 3t (initial)
+    FsParams params;
+    float scene_lower[3], scene_upper[3];
+    // camera from scene_params (softgym_cloth.h:177-183 CenterCamera)
+    float cam_pos[3], cam_angle[3];
+    int cam_width, cam_height;
+    int render_mode;
+    // adjacency derived from `springs`
+    int max_deg = 0;
+    std::vector<int> adj_off, adj_j;
+    std::vector<float> adj_len, adj_k;
+    std::vector<int> ell_j;
+    std::vector<float> ell_len, ell_k;
+};
+
+// Returns "" on success, otherwise an error message.
+std::string fs_build_scene(FsHostScene &out, const float *scene_params, int n_params, const float *verts,
+                           int n_vert_floats, const int *stretch, int n_stretch, const int *bend, int n_bend,
+                           const int *shear, int n_shear, const int *faces, int n_faces);

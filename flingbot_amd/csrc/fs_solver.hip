@@ -1,0 +1,75 @@
+// fs_solver.hip -- launch logic of the two solver back-ends.
+#include <hip/hip_runtime.h>
+
+#include "../../include/flingsim.h"
+#include "fs_context.h"
+#include "fs_fused_kernel.h"
+#include "fs_stream_kernels.h"
+
+#define HIP_TRY(call)                                     \
+    do {                                                  \
+        if (!fs_hip_ok((call), #call)) return FS_ERR_HIP; \
+    } while (0)
+
+static int upload_ids(fs_ctx *ctx, const std::vector<int> &ids) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // h_ids may still be read by an earlier copy
+    for (size_t k = 0; k < ids.size(); ++k) ctx->h_ids[k] = ids[k];
+    HIP_TRY(hipMemcpyAsync(ctx->d_ids, ctx->h_ids, sizeof(int) * ids.size(), hipMemcpyHostToDevice, ctx->stream));
+    return FS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming back-end: per substep  predict -> grid scan -> grid scatter -> find neighbours -> I x iterate -> finalize
+int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
+    int rc = upload_ids(ctx, ids);
+    if (rc != FS_OK) return rc;
+    int max_n = 0, substeps = 0, iters = 0;
+    for (int id : ids) {
+        const FsEnv &e = ctx->envs[id];
+        if (e.host.n > max_n) max_n = e.host.n;
+        if (substeps == 0) { substeps = e.dev.p.numSubsteps; iters = e.dev.p.numIterations; }
+        if (e.dev.p.numSubsteps != substeps || e.dev.p.numIterations != iters) {
+            fs_set_error("episodes stepped together must share numSubsteps / numIterations");
+            return FS_ERR_STATE;
+        }
+    }
+    const dim3 grid((max_n + FS_TILE - 1) / FS_TILE, (unsigned)ids.size());
+    const dim3 block(FS_TILE);
+    hipStream_t st = ctx->stream;
+    for (int f = 0; f < n_steps; ++f) {
+        for (int sub = 0; sub < substeps; ++sub) {
+            hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, ctx->d_ids);
+            hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, ctx->d_envs, ctx->d_ids);
+            hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, ctx->d_ids);
+            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, ctx->d_ids);
+            for (int it = 0; it < iters; ++it)
+                hipLaunchKernelGGL(fs_k_iterate, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, ctx->d_ids, sub, it & 1);
+            hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, ctx->d_ids, iters & 1);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused back-end: one workgroup per episode, LDS-resident particle state, the whole frame(s) in one launch.
+bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env) {
+    (void)ctx;
+    return env.has_scene && env.host.n <= FS_FUSED_MAX_PARTICLES && env.host.max_deg <= FS_FUSED_MAX_DEG &&
+           env.dev.p.numPlanes <= 1;
+}
+
+int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
+    int rc = upload_ids(ctx, ids);
+    if (rc != FS_OK) return rc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    FS_FUSED_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fs_k_fused_step, dim3((unsigned)ids.size()), dim3(FS_FUSED_THREADS), FS_FUSED_LDS_BYTES, ctx->stream,
+                       ctx->d_envs, ctx->d_shapes, ctx->d_ids, n_steps);
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+}

@@ -1,0 +1,76 @@
+// fs_types.h -- shared host/device plain-data types of libflingsim (MI355X cloth hot path).
+#pragma once
+#include <stdint.h>
+
+#define FS_MAX_SHAPES 16
+#define FS_MAX_NEIGHBORS 96   // g_maxNeighborsPerParticle, reference main.cpp:826
+#define FS_MAX_PLANES 8       // NvFlexParams::planes, reference NvFlex.h:149
+
+// NvFlex.h:159-192 phase bits
+#define FS_PHASE_GROUP_MASK 0x000fffff
+#define FS_PHASE_SELF_COLLIDE (1 << 20)
+#define FS_PHASE_SELF_COLLIDE_FILTER (1 << 21)
+#define FS_PHASE_CHANNEL_MASK 0x7f000000
+
+// wrapped uniform grid used for particle-neighbour search: 32 x 16 x 32 buckets; any 3x3x3 block of cells maps to 27
+// distinct buckets, so a neighbour is never visited twice.
+#define FS_GRID_BX 32
+#define FS_GRID_BY 16
+#define FS_GRID_BZ 32
+#define FS_GRID_BUCKETS (FS_GRID_BX * FS_GRID_BY * FS_GRID_BZ)
+
+// Effective NvFlexParams subset that reaches the cloth step (reference NvFlex.h:95-154; values main.cpp:717-884,
+// softgym_cloth.h:154-170).
+struct FsParams {
+    int numIterations, numSubsteps;
+    float dt;
+    float gravity[3];
+    float radius, solidRestDistance, collisionDistance, shapeCollisionMargin, particleCollisionMargin;
+    float dynamicFriction, staticFriction, particleFriction;
+    float damping, sleepThreshold, relaxationFactor, maxAcceleration, maxSpeed;
+    float restitution, adhesion, dissipation;
+    int numPlanes;
+    float planes[FS_MAX_PLANES][4];
+    int maxNeighbors, maxContacts, relaxationMode;
+};
+
+struct FsVec4 { float x, y, z, w; };
+
+// Kinematic collision shapes of one episode (spheres; reference helpers.h:484 AddSphere).
+struct FsShapesDev {
+    int count;
+    int pad[3];
+    FsVec4 pos[FS_MAX_SHAPES];   // xyz = current centre, w = radius
+    FsVec4 prev[FS_MAX_SHAPES];  // xyz = previous centre (NvFlex.h:981-982)
+};
+
+// Device-side descriptor of one episode.  Particle fields are separate arrays (SoA); each field is 16 B per particle
+// so one lane moves one dwordx4.
+struct FsEnvDev {
+    int n, m, max_deg, has_scene;
+    // dynamic state
+    FsVec4 *pos;    // xyz + invMass (NvFlex.h:545)
+    FsVec4 *vel;    // xyz, w unused
+    int *phase;
+    // per-substep scratch
+    FsVec4 *x0;     // substep-start position
+    FsVec4 *v0;     // substep-start velocity
+    FsVec4 *xa;     // Jacobi ping
+    FsVec4 *xb;     // Jacobi pong
+    int *ncount;    // particle-contact candidates per particle
+    int *nlist;     // [FS_MAX_NEIGHBORS][n] slot-major
+    int *cell_count;  // [FS_GRID_BUCKETS + 1] -> exclusive starts after the scan
+    int *cell_fill;   // [FS_GRID_BUCKETS]
+    int *cell_items;  // [n] particle ids grouped by bucket
+    // topology (shared between episodes with the same cloth)
+    const FsVec4 *rest;     // rest pose (main.cpp:971-973)
+    const int *adj_off;     // CSR: particle -> incident springs, ascending spring id
+    const int *adj_j;       // other endpoint
+    const float *adj_len;   // rest length
+    const float *adj_k;     // stiffness
+    // ELL copy of the same adjacency, slot-major [max_deg][n]; j < 0 marks an empty slot
+    const int *ell_j;
+    const float *ell_len;
+    const float *ell_k;
+    FsParams p;
+};

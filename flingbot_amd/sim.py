@@ -1,0 +1,293 @@
+"""ctypes binding of libflingsim.so (include/flingsim.h) -- the batched, multi-episode face of the hot path.
+
+`FlingSim` owns a context of `n_envs` cloth episodes on one MI355X; `FlingSim.env(i)` returns a view with the
+reference's `pyflex` method names (PyFlex/bindings/pyflex.cpp:1135-1208) so code written against `pyflex` reads the same.
+There is no CPU fallback: construction raises if the HIP library is missing or no GPU is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+FS_SOLVER_AUTO, FS_SOLVER_STREAM, FS_SOLVER_FUSED = 0, 1, 2
+
+_lib = None
+
+
+class FlingSimError(RuntimeError):
+    pass
+
+
+def load_library(build_if_missing=True):
+    """dlopen libflingsim.so and declare every prototype of include/flingsim.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise FlingSimError(f"{path} is missing: run `python -m flingbot_amd.build`")
+        _build.build_lib()
+    lib = C.CDLL(path)
+    fp, ip, vp, ci, cf = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_float
+    u8p = C.POINTER(C.c_ubyte)
+    proto = {
+        "fs_last_error": (C.c_char_p, []),
+        "fs_version": (ci, []),
+        "fs_create": (vp, [ci, ci, ci, ci]),
+        "fs_destroy": (None, [vp]),
+        "fs_n_envs": (ci, [vp]),
+        "fs_set_solver": (ci, [vp, ci]),
+        "fs_get_solver": (ci, [vp]),
+        "fs_set_scene": (ci, [vp, ci, fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
+        "fs_step": (ci, [vp, ci, ci]),
+        "fs_sync": (ci, [vp]),
+        "fs_stream": (vp, [vp]),
+        "fs_n_particles": (ci, [vp, ci]),
+        "fs_n_springs": (ci, [vp, ci]),
+        "fs_n_triangles": (ci, [vp, ci]),
+        "fs_n_shapes": (ci, [vp, ci]),
+        "fs_get_positions": (ci, [vp, ci, fp, ci]),
+        "fs_set_positions": (ci, [vp, ci, fp, ci]),
+        "fs_get_velocities": (ci, [vp, ci, fp, ci]),
+        "fs_set_velocities": (ci, [vp, ci, fp, ci]),
+        "fs_get_phases": (ci, [vp, ci, ip, ci]),
+        "fs_set_phases": (ci, [vp, ci, ip, ci]),
+        "fs_get_rest_positions": (ci, [vp, ci, fp, ci]),
+        "fs_get_normals": (ci, [vp, ci, fp, ci]),
+        "fs_get_edges": (ci, [vp, ci, ip, ci]),
+        "fs_get_faces": (ci, [vp, ci, ip, ci]),
+        "fs_get_spring_lengths": (ci, [vp, ci, fp, ci]),
+        "fs_get_spring_stiffness": (ci, [vp, ci, fp, ci]),
+        "fs_get_params": (ci, [vp, ci, fp, ci]),
+        "fs_get_scene_bounds": (ci, [vp, ci, fp, fp]),
+        "fs_add_sphere": (ci, [vp, ci, cf, fp, fp]),
+        "fs_clear_shapes": (ci, [vp, ci]),
+        "fs_get_shape_states": (ci, [vp, ci, fp, ci]),
+        "fs_set_shape_states": (ci, [vp, ci, fp, ci]),
+        "fs_get_camera_params": (ci, [vp, ci, fp]),
+        "fs_set_camera_params": (ci, [vp, ci, fp]),
+        "fs_render": (ci, [vp, ci, u8p, ci, fp, ci]),
+        "fs_coverage": (ci, [vp, fp, ci]),
+        "fs_get_last_neighbors": (ci, [vp, ci, ip, ip]),
+        "fs_device_positions": (vp, [vp, ci]),
+    }
+    for name, (res, args) in proto.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._fs_symbols = tuple(proto)
+    _lib = lib
+    return lib
+
+
+def _f(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).ravel())
+
+
+def _i(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32).ravel())
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class FlingSim:
+    """A context of `n_envs` independent cloth episodes stepped in one batched launch."""
+
+    def __init__(self, n_envs=1, device=0, camera_width=720, camera_height=720, solver=FS_SOLVER_AUTO):
+        self.lib = load_library()
+        self.h = self.lib.fs_create(int(device), int(n_envs), int(camera_width), int(camera_height))
+        if not self.h:
+            raise FlingSimError("fs_create failed: " + self.lib.fs_last_error().decode())
+        self.n_envs = int(n_envs)
+        self.device = int(device)
+        self.set_solver(solver)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise FlingSimError(self.lib.fs_last_error().decode())
+        return rc
+
+    def set_solver(self, solver):
+        self._ck(self.lib.fs_set_solver(self.h, int(solver)))
+
+    def env(self, i=0):
+        return EnvView(self, i)
+
+    # ---- batched
+    def step(self, n_steps=1, env=-1):
+        self._ck(self.lib.fs_step(self.h, int(env), int(n_steps)))
+
+    def sync(self):
+        self._ck(self.lib.fs_sync(self.h))
+
+    def stream(self):
+        return self.lib.fs_stream(self.h)
+
+    def coverage(self):
+        out = np.empty(self.n_envs, np.float32)
+        self._ck(self.lib.fs_coverage(self.h, _fp(out), out.size))
+        return out
+
+    # ---- per env, pyflex-shaped
+    def set_scene(self, env, scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):
+        sp = _f(scene_params)
+        v, st, be, sh, fa = _f(vertices), _i(stretch_edges), _i(bend_edges), _i(shear_edges), _i(faces)
+        self._ck(self.lib.fs_set_scene(self.h, env, _fp(sp), sp.size, _fp(v), v.size, _ip(st), st.size, _ip(be),
+                                       be.size, _ip(sh), sh.size, _ip(fa), fa.size))
+
+    def n_particles(self, env=0):
+        return self._ck(self.lib.fs_n_particles(self.h, env))
+
+    def n_springs(self, env=0):
+        return self._ck(self.lib.fs_n_springs(self.h, env))
+
+    def n_triangles(self, env=0):
+        return self._ck(self.lib.fs_n_triangles(self.h, env))
+
+    def n_shapes(self, env=0):
+        return self._ck(self.lib.fs_n_shapes(self.h, env))
+
+    def _getf(self, fn, env, size):
+        out = np.empty(size, np.float32)
+        self._ck(getattr(self.lib, fn)(self.h, env, _fp(out), out.size))
+        return out
+
+    def _geti(self, fn, env, size):
+        out = np.empty(size, np.int32)
+        self._ck(getattr(self.lib, fn)(self.h, env, _ip(out), out.size))
+        return out
+
+    def get_positions(self, env=0):
+        return self._getf("fs_get_positions", env, 4 * self.n_particles(env))
+
+    def set_positions(self, env, p):
+        p = _f(p)
+        self._ck(self.lib.fs_set_positions(self.h, env, _fp(p), p.size))
+
+    def get_velocities(self, env=0):
+        return self._getf("fs_get_velocities", env, 3 * self.n_particles(env))
+
+    def set_velocities(self, env, v):
+        v = _f(v)
+        self._ck(self.lib.fs_set_velocities(self.h, env, _fp(v), v.size))
+
+    def get_phases(self, env=0):
+        return self._geti("fs_get_phases", env, self.n_particles(env))
+
+    def set_phases(self, env, ph):
+        ph = _i(ph)
+        self._ck(self.lib.fs_set_phases(self.h, env, _ip(ph), ph.size))
+
+    def get_restPositions(self, env=0):
+        return self._getf("fs_get_rest_positions", env, 4 * self.n_particles(env))
+
+    def get_normals(self, env=0):
+        return self._getf("fs_get_normals", env, 4 * self.n_particles(env))
+
+    def get_edges(self, env=0):
+        return self._geti("fs_get_edges", env, 2 * self.n_springs(env))
+
+    def get_faces(self, env=0):
+        return self._geti("fs_get_faces", env, 3 * self.n_triangles(env))
+
+    def get_spring_lengths(self, env=0):
+        return self._getf("fs_get_spring_lengths", env, self.n_springs(env))
+
+    def get_spring_stiffness(self, env=0):
+        return self._getf("fs_get_spring_stiffness", env, self.n_springs(env))
+
+    def get_params(self, env=0):
+        return self._getf("fs_get_params", env, 32)
+
+    def get_scene_bounds(self, env=0):
+        lo, up = np.empty(3, np.float32), np.empty(3, np.float32)
+        self._ck(self.lib.fs_get_scene_bounds(self.h, env, _fp(lo), _fp(up)))
+        return lo, up
+
+    def add_sphere(self, env, radius, pos, quat):
+        pos, quat = _f(pos), _f(quat)
+        self._ck(self.lib.fs_add_sphere(self.h, env, C.c_float(radius), _fp(pos), _fp(quat)))
+
+    def clear_shapes(self, env=0):
+        self._ck(self.lib.fs_clear_shapes(self.h, env))
+
+    def get_shape_states(self, env=0):
+        return self._getf("fs_get_shape_states", env, 14 * self.n_shapes(env))
+
+    def set_shape_states(self, env, s):
+        s = _f(s)
+        self._ck(self.lib.fs_set_shape_states(self.h, env, _fp(s), s.size))
+
+    def get_camera_params(self, env=0):
+        out = np.empty(8, np.float32)
+        self._ck(self.lib.fs_get_camera_params(self.h, env, _fp(out)))
+        return out
+
+    def set_camera_params(self, env, p):
+        p = _f(p)
+        assert p.size >= 8
+        self._ck(self.lib.fs_set_camera_params(self.h, env, _fp(p)))
+
+    def render(self, env=0):
+        w, h = self.get_camera_params(env)[:2].astype(int)
+        rgba = np.empty(int(w) * int(h) * 4, np.uint8)
+        depth = np.empty(int(w) * int(h), np.float32)
+        self._ck(self.lib.fs_render(self.h, env, rgba.ctypes.data_as(C.POINTER(C.c_ubyte)), rgba.size, _fp(depth),
+                                    depth.size))
+        return rgba, depth
+
+    def get_last_neighbors(self, env=0):
+        n = self.n_particles(env)
+        counts = np.empty(n, np.int32)
+        lists = np.empty(n * 96, np.int32)
+        self._ck(self.lib.fs_get_last_neighbors(self.h, env, _ip(counts), _ip(lists)))
+        return counts, lists.reshape(n, 96)
+
+
+class EnvView:
+    """One episode of a FlingSim with the reference `pyflex` call names (no env argument)."""
+
+    def __init__(self, sim, env):
+        self.sim, self.e = sim, int(env)
+
+    def set_scene(self, scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):
+        self.sim.set_scene(self.e, scene_params, vertices, stretch_edges, bend_edges, shear_edges, faces)
+
+    def step(self, n=1):
+        self.sim.step(n, env=self.e)
+
+    @property
+    def n(self):
+        return self.sim.n_particles(self.e)
+
+    def get_n_particles(self):
+        return self.sim.n_particles(self.e)
+
+    def get_n_shapes(self):
+        return self.sim.n_shapes(self.e)
+
+    def __getattr__(self, name):
+        fn = getattr(self.sim, name)
+        if name.startswith("get_") or name in ("clear_shapes", "render"):
+            return lambda: fn(self.e)
+        return lambda *a: fn(self.e, *a)

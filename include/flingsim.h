@@ -1,0 +1,112 @@
+/*
+ * flingsim.h -- C-ABI of the MI355X-native FlingBot cloth hot path (libflingsim.so).
+ *
+ * This is the drop-in boundary: every entry point replaces one function of the reference's `pyflex` pybind11
+ * module (PyFlex/bindings/pyflex.cpp, cited per function) and takes only plain pointers and sizes, so the
+ * reference's own binding layer (pybind11), ctypes, cffi or any other FFI can bind it (INTEGRATION.md shows the stubs).
+ *
+ * Differences from the reference boundary, all additive:
+ *   - the reference is a process-global singleton (one g_solver, main.cpp:163); here a context owns `n_envs`
+ *     independent cloth episodes that step in ONE batched launch.  `pyflex.*` == env 0 of a 1-env context.
+ *   - errors are return codes (0 = ok, <0 = error) + fs_last_error(), instead of printf/exit (pyflex.cpp:103-107).
+ *   - the caller owns every host buffer; `n_*` arguments are ELEMENT counts (floats / ints), and are checked.
+ *
+ * There is no CPU fallback: fs_create fails if no HIP device is usable.
+ */
+#ifndef FLINGSIM_H
+#define FLINGSIM_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_ctx fs_ctx;
+
+#define FS_OK 0
+#define FS_ERR_ARG (-1)
+#define FS_ERR_HIP (-2)
+#define FS_ERR_STATE (-3)
+
+/* solver back-ends (fs_set_solver) */
+#define FS_SOLVER_AUTO 0    /* fused LDS-resident kernel when the episode fits one CU's LDS, else streaming */
+#define FS_SOLVER_STREAM 1  /* per-stage kernels over HBM-resident SoA state (any particle count) */
+#define FS_SOLVER_FUSED 2   /* one workgroup per episode, particle state resident in LDS for the whole step */
+
+const char *fs_last_error(void);
+int fs_version(void);
+
+/* pyflex.init (pyflex.cpp:15-124): create the solver/renderer context on HIP device `device` for `n_envs` episodes.
+   camera_width/height are the render target size (g_screenWidth/Height). */
+fs_ctx *fs_create(int device, int n_envs, int camera_width, int camera_height);
+/* pyflex.clean (pyflex.cpp:126-160) */
+void fs_destroy(fs_ctx *ctx);
+int fs_n_envs(const fs_ctx *ctx);
+int fs_set_solver(fs_ctx *ctx, int solver);
+int fs_get_solver(const fs_ctx *ctx);
+
+/* pyflex.set_scene (pyflex.cpp:229-244 -> main.cpp:613 Init -> softgym_cloth.h:33 Initialize).
+   scene_params[19] layout: flex_utils.py:332-342.  Empty `verts` selects the grid path (helpers.h:838). */
+int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int n_params, const float *verts, int n_vert_floats,
+                 const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints, const int *shear,
+                 int n_shear_ints, const int *faces, int n_face_ints);
+
+/* pyflex.step (pyflex.cpp:213-222 -> main.cpp:2120 UpdateFrame -> NvFlexUpdateSolver(dt, substeps)).
+   Advances env (or every env with a scene when env == -1) by n_steps frames.  Asynchronous on the context's HIP
+   stream; every getter synchronises. */
+int fs_step(fs_ctx *ctx, int env, int n_steps);
+int fs_sync(fs_ctx *ctx);
+/* the HIP stream (hipStream_t) the context launches on, for callers that time with HIP events */
+void *fs_stream(fs_ctx *ctx);
+
+/* counts: pyflex.get_n_particles :326, get_n_shapes :334; springs / triangles implied by get_edges / get_faces */
+int fs_n_particles(const fs_ctx *ctx, int env);
+int fs_n_springs(const fs_ctx *ctx, int env);
+int fs_n_triangles(const fs_ctx *ctx, int env);
+int fs_n_shapes(const fs_ctx *ctx, int env);
+
+/* particle mirrors.  get_positions :414 / set_positions :464 (float[4N] xyz + invMass),
+   get_velocities :753 / set_velocities :772 (float[3N]), get_phases :378 / set_phases :395 (int[N]),
+   get_restPositions (float[4N]), get_edges :433 (int[2M]), get_faces :449 (int[3T]). */
+int fs_get_positions(fs_ctx *ctx, int env, float *out, int n_floats);
+int fs_set_positions(fs_ctx *ctx, int env, const float *in, int n_floats);
+int fs_get_velocities(fs_ctx *ctx, int env, float *out, int n_floats);
+int fs_set_velocities(fs_ctx *ctx, int env, const float *in, int n_floats);
+int fs_get_phases(fs_ctx *ctx, int env, int *out, int n_ints);
+int fs_set_phases(fs_ctx *ctx, int env, const int *in, int n_ints);
+int fs_get_rest_positions(fs_ctx *ctx, int env, float *out, int n_floats);
+int fs_get_normals(fs_ctx *ctx, int env, float *out, int n_floats); /* NvFlexGetNormals, main.cpp:2286 */
+int fs_get_edges(fs_ctx *ctx, int env, int *out, int n_ints);
+int fs_get_faces(fs_ctx *ctx, int env, int *out, int n_ints);
+int fs_get_spring_lengths(fs_ctx *ctx, int env, float *out, int n_floats);
+int fs_get_spring_stiffness(fs_ctx *ctx, int env, float *out, int n_floats);
+/* effective NvFlexParams of the env as a packed float[32] (layout: DESIGN.md "parameter table") */
+int fs_get_params(fs_ctx *ctx, int env, float *out, int n_floats);
+/* pyflex.get_scene_lower / get_scene_upper (pyflex.cpp:865-889) */
+int fs_get_scene_bounds(fs_ctx *ctx, int env, float *lower3, float *upper3);
+
+/* shapes.  add_sphere :311 (helpers.h:484), clear_shapes (helpers.h:1677),
+   get_shape_states :789 / set_shape_states :832: float[14S] = pos3, prevPos3, quat4, prevQuat4 */
+int fs_add_sphere(fs_ctx *ctx, int env, float radius, const float *pos3, const float *quat4);
+int fs_clear_shapes(fs_ctx *ctx, int env);
+int fs_get_shape_states(fs_ctx *ctx, int env, float *out, int n_floats);
+int fs_set_shape_states(fs_ctx *ctx, int env, const float *in, int n_floats);
+
+/* camera.  get_camera_params :891 -> [w,h,px,py,pz,ax,ay,az]; set_camera_params :908 <- [px,py,pz,ax,ay,az,w,h] */
+int fs_get_camera_params(fs_ctx *ctx, int env, float *out8);
+int fs_set_camera_params(fs_ctx *ctx, int env, const float *in8);
+
+/* pyflex.render (pyflex.cpp:924-1133): RGBA8 bottom-up [h*w*4] and linear depth [h*w] of env. */
+int fs_render(fs_ctx *ctx, int env, unsigned char *rgba, int n_bytes, float *depth, int n_floats);
+
+/* coverage reward of every env (flex_utils.py:358-395 get_current_covered_area), out[n_envs] */
+int fs_coverage(fs_ctx *ctx, float *out, int n_floats);
+
+/* white-box access for tests: particle-contact candidate lists of the last substep, counts[N], lists[N*96] */
+int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
+/* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */
+void *fs_device_positions(fs_ctx *ctx, int env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

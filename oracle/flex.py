@@ -1,0 +1,199 @@
+"""ctypes front-end of the C oracle (oracle/flex_oracle.c).  TEST INFRASTRUCTURE, not product code.
+
+Mirrors the subset of the ``pyflex`` module surface (PyFlex/bindings/pyflex.cpp:1135-1208) the hot path uses so the
+parity tests can drive the oracle and the HIP path with the same calls.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def oracle_lib_path():
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def build_oracle(force=False):
+    """Compile liboracle.so (gcc) and, when /root/reference is present, oracle/_ref."""
+    srcs = [os.path.join(_HERE, f) for f in ("flex_oracle.c", "flex_oracle.h", "raster_oracle.c", "Makefile")]
+    lib = oracle_lib_path()
+    stale = force or not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+    if os.path.isdir("/root/reference/PyFlex/core") and os.path.exists(os.path.join(_HERE, "ref_camera_probe.cpp")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_ref/camera_ref"])
+    return lib
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(oracle_lib_path()):
+        build_oracle()
+    lib = C.CDLL(oracle_lib_path())
+    fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+    lib.orc_create.restype = vp
+    lib.orc_destroy.argtypes = [vp]
+    lib.orc_set_scene.argtypes = [vp, fp, fp, C.c_int, ip, C.c_int, ip, C.c_int, ip, C.c_int, ip, C.c_int]
+    lib.orc_step.argtypes = [vp, C.c_int]
+    for name in ("orc_n_particles", "orc_n_springs", "orc_n_triangles", "orc_n_shapes"):
+        getattr(lib, name).argtypes = [vp]
+    for name in ("orc_get_positions", "orc_set_positions", "orc_get_velocities", "orc_set_velocities",
+                 "orc_get_rest_positions", "orc_get_normals", "orc_get_spring_lengths", "orc_get_spring_stiffness",
+                 "orc_get_params", "orc_get_shape_states", "orc_set_shape_states"):
+        getattr(lib, name).argtypes = [vp, fp]
+    for name in ("orc_get_phases", "orc_set_phases", "orc_get_edges", "orc_get_faces"):
+        getattr(lib, name).argtypes = [vp, ip]
+    lib.orc_get_scene_bounds.argtypes = [vp, fp, fp]
+    lib.orc_add_sphere.argtypes = [vp, C.c_float, fp, fp]
+    lib.orc_clear_shapes.argtypes = [vp]
+    lib.orc_get_last_neighbors.argtypes = [vp, ip, ip]
+    _lib = lib
+    return lib
+
+
+def _f(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).ravel())
+
+
+def _i(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32).ravel())
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class OracleSim:
+    """One cloth episode on the CPU oracle, pyflex-shaped methods."""
+
+    def __init__(self):
+        self.lib = _load()
+        self.h = self.lib.orc_create()
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    # -- pyflex.set_scene (pyflex.cpp:229)
+    def set_scene(self, scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):
+        sp = _f(scene_params)
+        assert sp.size >= 19
+        v, st, be, sh, fa = _f(vertices), _i(stretch_edges), _i(bend_edges), _i(shear_edges), _i(faces)
+        rc = self.lib.orc_set_scene(self.h, _fp(sp), _fp(v), v.size, _ip(st), st.size, _ip(be), be.size,
+                                    _ip(sh), sh.size, _ip(fa), fa.size)
+        assert rc == 0
+
+    def step(self, n=1):
+        assert self.lib.orc_step(self.h, int(n)) == 0
+
+    @property
+    def n(self):
+        return self.lib.orc_n_particles(self.h)
+
+    @property
+    def m(self):
+        return self.lib.orc_n_springs(self.h)
+
+    @property
+    def t(self):
+        return self.lib.orc_n_triangles(self.h)
+
+    def get_n_particles(self):
+        return self.n
+
+    def get_n_shapes(self):
+        return self.lib.orc_n_shapes(self.h)
+
+    def _getf(self, fn, size):
+        out = np.empty(size, dtype=np.float32)
+        getattr(self.lib, fn)(self.h, _fp(out))
+        return out
+
+    def _geti(self, fn, size):
+        out = np.empty(size, dtype=np.int32)
+        getattr(self.lib, fn)(self.h, _ip(out))
+        return out
+
+    def get_positions(self):
+        return self._getf("orc_get_positions", 4 * self.n)
+
+    def set_positions(self, p):
+        p = _f(p)
+        assert p.size >= 4 * self.n
+        self.lib.orc_set_positions(self.h, _fp(p))
+
+    def get_velocities(self):
+        return self._getf("orc_get_velocities", 3 * self.n)
+
+    def set_velocities(self, v):
+        v = _f(v)
+        assert v.size >= 3 * self.n
+        self.lib.orc_set_velocities(self.h, _fp(v))
+
+    def get_phases(self):
+        return self._geti("orc_get_phases", self.n)
+
+    def set_phases(self, ph):
+        ph = _i(ph)
+        self.lib.orc_set_phases(self.h, _ip(ph))
+
+    def get_restPositions(self):
+        return self._getf("orc_get_rest_positions", 4 * self.n)
+
+    def get_normals(self):
+        return self._getf("orc_get_normals", 4 * self.n)
+
+    def get_edges(self):
+        return self._geti("orc_get_edges", 2 * self.m)
+
+    def get_faces(self):
+        return self._geti("orc_get_faces", 3 * self.t)
+
+    def get_spring_lengths(self):
+        return self._getf("orc_get_spring_lengths", self.m)
+
+    def get_spring_stiffness(self):
+        return self._getf("orc_get_spring_stiffness", self.m)
+
+    def get_params(self):
+        return self._getf("orc_get_params", 32)
+
+    def get_scene_bounds(self):
+        lo, up = np.empty(3, np.float32), np.empty(3, np.float32)
+        self.lib.orc_get_scene_bounds(self.h, _fp(lo), _fp(up))
+        return lo, up
+
+    def add_sphere(self, radius, pos, quat):
+        pos, quat = _f(pos), _f(quat)
+        assert self.lib.orc_add_sphere(self.h, C.c_float(radius), _fp(pos), _fp(quat)) == 0
+
+    def clear_shapes(self):
+        self.lib.orc_clear_shapes(self.h)
+
+    def get_shape_states(self):
+        return self._getf("orc_get_shape_states", 14 * self.get_n_shapes())
+
+    def set_shape_states(self, s):
+        s = _f(s)
+        assert s.size >= 14 * self.get_n_shapes()
+        self.lib.orc_set_shape_states(self.h, _fp(s))
+
+    def get_last_neighbors(self):
+        counts = np.empty(self.n, np.int32)
+        lists = np.empty(self.n * 96, np.int32)
+        self.lib.orc_get_last_neighbors(self.h, _ip(counts), _ip(lists))
+        return counts, lists.reshape(self.n, 96)

@@ -1,0 +1,666 @@
+/*
+ * flex_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See flex_oracle.h for provenance.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  All arithmetic is IEEE fp32 with a fixed
+ * operation order so the HIP kernels (also built with -ffp-contract=off, correctly rounded / and sqrt) can be
+ * compared bit for bit.
+ *
+ * PARITY UNPINNED: the solver arithmetic of the reference lives in closed-source NVIDIA FleX 1.2.0 which is absent
+ * from /root/reference; the reference has no tests or golden vectors.  Each decision is tagged
+ *   [D] documented in a reference header (cited)    [I] inferred / chosen from the published FleX paper.
+ */
+#include "flex_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_SHAPES 16
+#define ORC_MAX_NEIGHBORS 96 /* g_maxNeighborsPerParticle, main.cpp:826 */
+
+/* NvFlex.h:159-192 phase bits */
+#define PH_GROUP_MASK 0x000fffff
+#define PH_SELF_COLLIDE (1 << 20)
+#define PH_SELF_COLLIDE_FILTER (1 << 21)
+#define PH_CHANNEL_MASK 0x7f000000
+
+typedef struct {
+    int numIterations, numSubsteps;
+    float dt;
+    float gravity[3];
+    float radius, solidRestDistance, collisionDistance, shapeCollisionMargin, particleCollisionMargin;
+    float dynamicFriction, staticFriction, particleFriction;
+    float damping, sleepThreshold, relaxationFactor, maxAcceleration, maxSpeed;
+    float restitution, adhesion, dissipation;
+    int numPlanes;
+    float planes[8][4];
+    int maxNeighbors, maxContacts, relaxationMode;
+} orc_params;
+
+struct orc_sim {
+    int n, m, t;
+    float *pos;   /* 4n: x y z invMass  (NvFlex.h:545) */
+    float *vel;   /* 3n */
+    int *phase;   /* n */
+    float *rest;  /* 4n (main.cpp:971-973) */
+    int *sidx;    /* 2m */
+    float *slen;  /* m */
+    float *sk;    /* m */
+    int *tris;    /* 3t */
+    float *tnrm;  /* 3t initial triangle normals */
+    float *nrm;   /* 4n */
+    /* CSR adjacency particle -> (spring id) in ascending spring id */
+    int *adj_off; /* n+1 */
+    int *adj_spr; /* 2m: spring id */
+    /* shapes (spheres only are simulated; flingbot adds two, flex_utils.py:82-83) */
+    int ns;
+    float sh_radius[ORC_MAX_SHAPES];
+    float sh_pos[ORC_MAX_SHAPES][3], sh_prev[ORC_MAX_SHAPES][3];
+    float sh_rot[ORC_MAX_SHAPES][4], sh_prevrot[ORC_MAX_SHAPES][4];
+    orc_params p;
+    float scene_lower[3], scene_upper[3];
+    /* scratch */
+    float *xp, *xn, *x0, *v0;
+    int *ncount, *nlist;
+    int *cell_key, *cell_order;
+};
+
+static void free_scene(orc_sim *s) {
+    free(s->pos); free(s->vel); free(s->phase); free(s->rest); free(s->sidx); free(s->slen); free(s->sk);
+    free(s->tris); free(s->tnrm); free(s->nrm); free(s->adj_off); free(s->adj_spr);
+    free(s->xp); free(s->xn); free(s->x0); free(s->v0); free(s->ncount); free(s->nlist);
+    free(s->cell_key); free(s->cell_order);
+    memset(s, 0, sizeof(*s));
+}
+
+orc_sim *orc_create(void) { return (orc_sim *)calloc(1, sizeof(orc_sim)); }
+void orc_destroy(orc_sim *s) {
+    if (!s) return;
+    free_scene(s);
+    free(s);
+}
+
+/* ---------------------------------------------------------------- scene build */
+
+typedef struct { int n, cap; float *d; } fvec;
+typedef struct { int n, cap; int *d; } ivec;
+static void fpush(fvec *v, float x) {
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->d = (float *)realloc(v->d, sizeof(float) * v->cap); }
+    v->d[v->n++] = x;
+}
+static void ipush(ivec *v, int x) {
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 1024; v->d = (int *)realloc(v->d, sizeof(int) * v->cap); }
+    v->d[v->n++] = x;
+}
+
+typedef struct { fvec pos, vel, slen, sk, tnrm; ivec phase, sidx, tris; } builder;
+
+/* helpers.h:144-150 CreateSpring; Length() = maths.h:204-211 (sqrt of x*x+y*y+z*z, 0 if zero) */
+static void create_spring(builder *b, int i, int j, float stiffness) {
+    const float give = 0.0f;
+    float dx = b->pos.d[4 * i + 0] - b->pos.d[4 * j + 0];
+    float dy = b->pos.d[4 * i + 1] - b->pos.d[4 * j + 1];
+    float dz = b->pos.d[4 * i + 2] - b->pos.d[4 * j + 2];
+    float lsq = dx * dx + dy * dy + dz * dz;
+    float len = lsq ? sqrtf(lsq) : 0.0f;
+    ipush(&b->sidx, i);
+    ipush(&b->sidx, j);
+    fpush(&b->slen, (1.0f + give) * len);
+    fpush(&b->sk, stiffness);
+}
+
+/* helpers.h:838-924 CreateSpringGrid (dz == 1 for cloth) */
+static void create_spring_grid(builder *b, const float lower[3], int dx, int dy, int dz, float radius, int phase,
+                               float ks, float kb, float ksh, float invMass) {
+    int baseIndex = b->pos.n / 4;
+    for (int z = 0; z < dz; ++z)
+        for (int y = 0; y < dy; ++y)
+            for (int x = 0; x < dx; ++x) {
+                /* Vec3 position = lower + radius * Vec3(float(x), float(z), float(y)) */
+                float px = lower[0] + radius * (float)x;
+                float py = lower[1] + radius * (float)z;
+                float pz = lower[2] + radius * (float)y;
+                fpush(&b->pos, px); fpush(&b->pos, py); fpush(&b->pos, pz); fpush(&b->pos, invMass);
+                fpush(&b->vel, 0.0f); fpush(&b->vel, 0.0f); fpush(&b->vel, 0.0f);
+                ipush(&b->phase, phase);
+                if (x > 0 && y > 0) {
+                    ipush(&b->tris, baseIndex + (y - 1) * dx + (x - 1));
+                    ipush(&b->tris, baseIndex + (y - 1) * dx + x);
+                    ipush(&b->tris, baseIndex + y * dx + x);
+                    ipush(&b->tris, baseIndex + (y - 1) * dx + (x - 1));
+                    ipush(&b->tris, baseIndex + y * dx + x);
+                    ipush(&b->tris, baseIndex + y * dx + (x - 1));
+                    for (int k = 0; k < 2; ++k) { fpush(&b->tnrm, 0.0f); fpush(&b->tnrm, 1.0f); fpush(&b->tnrm, 0.0f); }
+                }
+            }
+    /* horizontal */
+    for (int y = 0; y < dy; ++y)
+        for (int x = 0; x < dx; ++x) {
+            int index0 = y * dx + x;
+            if (x > 0) create_spring(b, baseIndex + index0, baseIndex + y * dx + x - 1, ks);
+            if (x > 1) create_spring(b, baseIndex + index0, baseIndex + y * dx + x - 2, kb);
+            if (y > 0 && x < dx - 1) create_spring(b, baseIndex + index0, baseIndex + (y - 1) * dx + x + 1, ksh);
+            if (y > 0 && x > 0) create_spring(b, baseIndex + index0, baseIndex + (y - 1) * dx + x - 1, ksh);
+        }
+    /* vertical */
+    for (int x = 0; x < dx; ++x)
+        for (int y = 0; y < dy; ++y) {
+            int index0 = y * dx + x;
+            if (y > 0) create_spring(b, baseIndex + index0, baseIndex + (y - 1) * dx + x, ks);
+            if (y > 1) create_spring(b, baseIndex + index0, baseIndex + (y - 2) * dx + x, kb);
+        }
+}
+
+static void swap_int(int *a, int *b) { int t = *a; *a = *b; *b = t; }
+
+/* main.cpp:904-919: area-weighted vertex normals, SafeNormalize with fallback (0,1,0) */
+static void compute_normals(const float *pos, const int *tris, int n, int t, float *nrm) {
+    memset(nrm, 0, sizeof(float) * 4 * n);
+    for (int i = 0; i < t; ++i) {
+        const float *v0 = pos + 4 * tris[3 * i], *v1 = pos + 4 * tris[3 * i + 1], *v2 = pos + 4 * tris[3 * i + 2];
+        float ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2];
+        float bx = v2[0] - v0[0], by = v2[1] - v0[1], bz = v2[2] - v0[2];
+        float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+        for (int k = 0; k < 3; ++k) {
+            float *d = nrm + 4 * tris[3 * i + k];
+            d[0] += nx; d[1] += ny; d[2] += nz;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        float *d = nrm + 4 * i;
+        float l = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (l > 0.0f) {
+            float inv = 1.0f / sqrtf(l);
+            d[0] *= inv; d[1] *= inv; d[2] *= inv;
+        } else { d[0] = 0.0f; d[1] = 1.0f; d[2] = 0.0f; }
+        d[3] = 0.0f;
+    }
+}
+
+int orc_set_scene(orc_sim *s, const float *ptr, const float *verts, int n_vert_floats, const int *stretch,
+                  int n_stretch_ints, const int *bend, int n_bend_ints, const int *shear, int n_shear_ints,
+                  const int *faces, int n_face_ints) {
+    free_scene(s); /* Init destroys the previous solver, buffers and shapes (main.cpp:623-706) */
+    orc_params *p = &s->p;
+    /* ---- Init defaults, main.cpp:717-828 (only the fields that reach the cloth step) */
+    p->dt = 1.0f / 100.0f;
+    p->gravity[0] = 0.0f; p->gravity[1] = -9.8f; p->gravity[2] = 0.0f;
+    p->radius = 0.15f;
+    p->dynamicFriction = 0.0f; p->staticFriction = 0.0f; p->particleFriction = 0.0f;
+    p->numIterations = 3;
+    p->solidRestDistance = 0.0f;
+    p->dissipation = 0.0f; p->damping = 0.0f; p->particleCollisionMargin = 0.0f; p->shapeCollisionMargin = 0.0f;
+    p->collisionDistance = 0.0f; p->sleepThreshold = 0.0f; p->restitution = 0.0f; p->adhesion = 0.0f;
+    p->maxSpeed = FLT_MAX; p->maxAcceleration = 100.0f;
+    p->relaxationMode = 1; p->relaxationFactor = 1.0f;
+    p->numSubsteps = 20; p->numPlanes = 1;
+    p->maxNeighbors = 96; p->maxContacts = 6;
+    for (int k = 0; k < 3; ++k) { s->scene_lower[k] = FLT_MAX; s->scene_upper[k] = -FLT_MAX; }
+
+    /* ---- SoftgymCloth::Initialize, softgym_cloth.h:33-175 */
+    builder b; memset(&b, 0, sizeof(b));
+    float initX = ptr[0], initY = ptr[1], initZ = ptr[2];
+    int dimx = (int)ptr[3], dimz = (int)ptr[4];
+    float radius = 0.00625f;
+    float ks = ptr[5], kb = ptr[6], ksh = ptr[7];
+    int phase = (0 & PH_GROUP_MASK) | ((PH_SELF_COLLIDE | PH_SELF_COLLIDE_FILTER) & 0x00f00000) | PH_CHANNEL_MASK;
+    int flip_mesh = (int)ptr[18];
+    int num_verts = n_vert_floats / 3;
+    if (num_verts > 0) {
+        float mass = ptr[17] / (float)num_verts;
+        float invMass = 1.0f / mass;
+        float lower[3] = {initX, -initY, initZ};
+        int baseIndex = 0;
+        for (int i = 0; i < num_verts; ++i) {
+            fpush(&b.pos, verts[3 * i] + lower[0]); fpush(&b.pos, verts[3 * i + 1] + lower[1]);
+            fpush(&b.pos, verts[3 * i + 2] + lower[2]); fpush(&b.pos, invMass + 0.0f);
+            fpush(&b.vel, 0.0f); fpush(&b.vel, 0.0f); fpush(&b.vel, 0.0f);
+            ipush(&b.phase, phase);
+        }
+        int num_faces = n_face_ints / 3;
+        for (int i = 0; i < num_faces; ++i) {
+            for (int k = 0; k < 3; ++k) ipush(&b.tris, baseIndex + faces[3 * i + k]);
+            const float *p1 = b.pos.d + 4 * (baseIndex + faces[3 * i]);
+            const float *p2 = b.pos.d + 4 * (baseIndex + faces[3 * i + 1]);
+            const float *p3 = b.pos.d + 4 * (baseIndex + faces[3 * i + 2]);
+            float Ux = p2[0] - p1[0], Uy = p2[1] - p1[1], Uz = p2[2] - p1[2];
+            float Vx = p3[0] - p1[0], Vy = p3[1] - p1[1], Vz = p3[2] - p1[2];
+            float nx = Uy * Vz - Uz * Vy, ny = Uz * Vx - Ux * Vz, nz = Ux * Vy - Uy * Vx;
+            float lsq = nx * nx + ny * ny + nz * nz;
+            float l = lsq ? sqrtf(lsq) : 0.0f;
+            fpush(&b.tnrm, nx / l); fpush(&b.tnrm, ny / l); fpush(&b.tnrm, nz / l);
+        }
+        for (int i = 0; i < n_stretch_ints / 2; ++i) create_spring(&b, baseIndex + stretch[2 * i], baseIndex + stretch[2 * i + 1], ks);
+        for (int i = 0; i < n_bend_ints / 2; ++i) create_spring(&b, baseIndex + bend[2 * i], baseIndex + bend[2 * i + 1], kb);
+        for (int i = 0; i < n_shear_ints / 2; ++i) create_spring(&b, baseIndex + shear[2 * i], baseIndex + shear[2 * i + 1], ksh);
+    } else {
+        float mass = ptr[17] / (float)(dimx * dimz);
+        float lower[3] = {initX, -initY, initZ};
+        create_spring_grid(&b, lower, dimx, dimz, 1, radius, phase, ks, kb, ksh, 1.0f / mass);
+    }
+    if (flip_mesh) { /* softgym_cloth.h:137-152 */
+        for (int j = 0; j < dimz - 1; ++j)
+            for (int i = (dimx - 1) * 1 / 8; i < (dimx - 1) * 1 / 8 + 5; ++i) {
+                int idx = j * (dimx - 1) + i;
+                if (i != (dimx - 1) * 1 / 8 + 4) swap_int(&b.tris.d[idx * 6], &b.tris.d[idx * 6 + 1]);
+                if (i != (dimx - 1) * 1 / 8) swap_int(&b.tris.d[idx * 6 + 3], &b.tris.d[idx * 6 + 4]);
+            }
+    }
+    p->numSubsteps = 4;            /* softgym_cloth.h:154 */
+    p->numIterations = 30;         /* :155 */
+    p->dynamicFriction = 0.75f;    /* :157 */
+    p->particleFriction = 1.0f;    /* :158 */
+    p->damping = 1.0f;             /* :159 */
+    p->sleepThreshold = 0.02f;     /* :160 */
+    p->relaxationFactor = 1.0f;    /* :162 */
+    p->shapeCollisionMargin = 0.04f; /* :163 */
+    for (int k = 0; k < 3; ++k) { s->scene_lower[k] = -1.0f; s->scene_upper[k] = 1.0f; } /* :165-166 */
+    p->radius = radius * 1.8f;     /* :169 */
+    p->collisionDistance = 0.005f; /* :170 */
+
+    /* ---- back in Init, main.cpp:844-884: derived params and bounds */
+    if (p->solidRestDistance == 0.0f) p->solidRestDistance = p->radius;
+    if (p->collisionDistance == 0.0f) p->collisionDistance = p->solidRestDistance * 0.5f;
+    if (p->particleFriction == 0.0f) p->particleFriction = p->dynamicFriction * 0.1f;
+    if (p->shapeCollisionMargin == 0.0f) p->shapeCollisionMargin = p->collisionDistance * 0.5f;
+
+    s->n = b.pos.n / 4; s->m = b.slen.n; s->t = b.tris.n / 3;
+    for (int i = 0; i < s->n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float v = b.pos.d[4 * i + k];
+            if (v < s->scene_lower[k]) s->scene_lower[k] = v;
+            if (v > s->scene_upper[k]) s->scene_upper[k] = v;
+        }
+    for (int k = 0; k < 3; ++k) { s->scene_lower[k] -= p->collisionDistance; s->scene_upper[k] += p->collisionDistance; }
+    p->planes[0][0] = 0.0f; p->planes[0][1] = 1.0f; p->planes[0][2] = 0.0f; p->planes[0][3] = 0.0f; /* :882-884, tilt 0 */
+
+    int n = s->n, m = s->m, t = s->t;
+    s->pos = b.pos.d; s->vel = b.vel.d; s->phase = b.phase.d; s->sidx = b.sidx.d; s->slen = b.slen.d; s->sk = b.sk.d;
+    s->tris = b.tris.d; s->tnrm = b.tnrm.d;
+    if (!s->sidx) s->sidx = (int *)calloc(2, sizeof(int));
+    s->rest = (float *)malloc(sizeof(float) * 4 * (n + 1));
+    memcpy(s->rest, s->pos, sizeof(float) * 4 * n); /* main.cpp:971-973 */
+    s->nrm = (float *)malloc(sizeof(float) * 4 * (n + 1));
+    compute_normals(s->pos, s->tris, n, t, s->nrm);
+
+    /* CSR adjacency, ascending spring id per particle */
+    s->adj_off = (int *)calloc(n + 2, sizeof(int));
+    s->adj_spr = (int *)malloc(sizeof(int) * (2 * m + 1));
+    for (int e = 0; e < m; ++e) { s->adj_off[s->sidx[2 * e] + 1]++; s->adj_off[s->sidx[2 * e + 1] + 1]++; }
+    for (int i = 0; i < n; ++i) s->adj_off[i + 1] += s->adj_off[i];
+    int *fill = (int *)calloc(n + 1, sizeof(int));
+    for (int e = 0; e < m; ++e)
+        for (int k = 0; k < 2; ++k) {
+            int i = s->sidx[2 * e + k];
+            s->adj_spr[s->adj_off[i] + fill[i]++] = e;
+        }
+    free(fill);
+
+    s->xp = (float *)malloc(sizeof(float) * 4 * (n + 1));
+    s->xn = (float *)malloc(sizeof(float) * 4 * (n + 1));
+    s->x0 = (float *)malloc(sizeof(float) * 4 * (n + 1));
+    s->v0 = (float *)malloc(sizeof(float) * 3 * (n + 1));
+    s->ncount = (int *)calloc(n + 1, sizeof(int));
+    s->nlist = (int *)malloc(sizeof(int) * ORC_MAX_NEIGHBORS * (n + 1));
+    s->cell_key = (int *)malloc(sizeof(int) * 4 * (n + 1));
+    s->cell_order = (int *)malloc(sizeof(int) * (n + 1));
+    s->ns = 0;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- solver step */
+
+static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
+
+static const int *g_sort_keys; /* qsort context: 3 ints per particle */
+static int cmp_cell(const void *a, const void *b) {
+    const int *ka = g_sort_keys + 3 * (*(const int *)a), *kb = g_sort_keys + 3 * (*(const int *)b);
+    for (int k = 0; k < 3; ++k)
+        if (ka[k] != kb[k]) return ka[k] < kb[k] ? -1 : 1;
+    return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b);
+}
+
+/* lower bound over sorted cell_order by (cx,cy,cz) */
+static int cell_lower_bound(const orc_sim *s, const int *keys, int cx, int cy, int cz) {
+    int lo = 0, hi = s->n;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        const int *k = keys + 3 * s->cell_order[mid];
+        int less = (k[0] != cx) ? (k[0] < cx) : (k[1] != cy) ? (k[1] < cy) : (k[2] < cz);
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/*
+ * Particle-contact candidates, built once per substep on the predicted positions
+ * ([D] stage order NvFlex.h:200-204 vs per-iteration :211-215):
+ *  pair (i,j), i != j, |x*_i - x*_j|^2 < radius^2 (particleCollisionMargin = 0, NvFlex.h:146),
+ *  same group needs eNvFlexPhaseSelfCollide on both (NvFlex.h:165),
+ *  eNvFlexPhaseSelfCollideFilter on either drops pairs with |rest_i - rest_j|^2 < radius^2 (NvFlex.h:166,564-565),
+ *  list = ascending j, truncated to the 96 smallest (maxNeighborsPerParticle, main.cpp:826)   [I: ordering/truncation]
+ */
+static void find_neighbors(orc_sim *s) {
+    const int n = s->n;
+    const float r = s->p.radius + s->p.particleCollisionMargin;
+    const float r2 = r * r;
+    const float inv = 1.0f / r;
+    int *keys = s->cell_key;
+    for (int i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) keys[3 * i + k] = (int)floorf(s->xp[4 * i + k] * inv);
+        s->cell_order[i] = i;
+    }
+    g_sort_keys = keys;
+    qsort(s->cell_order, n, sizeof(int), cmp_cell);
+    int tmp[4096];
+    for (int i = 0; i < n; ++i) {
+        int cnt = 0, total_cap = 4096;
+        const float *xi = s->xp + 4 * i;
+        int gi = s->phase[i] & PH_GROUP_MASK;
+        for (int dx = -1; dx <= 1; ++dx)
+            for (int dy = -1; dy <= 1; ++dy) {
+                /* the three dz cells are contiguous in the sort order */
+                int cx = keys[3 * i] + dx, cy = keys[3 * i + 1] + dy, cz0 = keys[3 * i + 2] - 1;
+                int q = cell_lower_bound(s, keys, cx, cy, cz0);
+                for (; q < n; ++q) {
+                    int j = s->cell_order[q];
+                    const int *kj = keys + 3 * j;
+                    if (kj[0] != cx || kj[1] != cy || kj[2] > cz0 + 2) break;
+                    if (j == i) continue;
+                    const float *xj = s->xp + 4 * j;
+                    float ddx = xi[0] - xj[0], ddy = xi[1] - xj[1], ddz = xi[2] - xj[2];
+                    float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    if (!(d2 < r2)) continue;
+                    int gj = s->phase[j] & PH_GROUP_MASK;
+                    if (gi == gj) {
+                        if (!((s->phase[i] & PH_SELF_COLLIDE) && (s->phase[j] & PH_SELF_COLLIDE))) continue;
+                        if ((s->phase[i] | s->phase[j]) & PH_SELF_COLLIDE_FILTER) {
+                            const float *ri = s->rest + 4 * i, *rj = s->rest + 4 * j;
+                            float ex = ri[0] - rj[0], ey = ri[1] - rj[1], ez = ri[2] - rj[2];
+                            float e2 = ex * ex + ey * ey + ez * ez;
+                            if (e2 < r2) continue;
+                        }
+                    }
+                    if (cnt < total_cap) tmp[cnt++] = j;
+                }
+            }
+        qsort(tmp, cnt, sizeof(int), cmp_int);
+        if (cnt > s->p.maxNeighbors) cnt = s->p.maxNeighbors;
+        s->ncount[i] = cnt;
+        memcpy(s->nlist + (size_t)ORC_MAX_NEIGHBORS * i, tmp, sizeof(int) * cnt);
+    }
+}
+
+/* friction on a contact: t = tangential relative displacement since substep start, pen = penetration depth.
+   [I] Macklin 2014 section 6.1: full stick below mu_s*pen, else scaled by min(mu_k*pen/|t|, 1).  Returns scale. */
+static inline float friction_scale(float tl, float pen, float mu_s, float mu_k) {
+    if (tl < mu_s * pen) return 1.0f;
+    float lim = mu_k * pen;
+    return (tl > lim) ? lim / tl : 1.0f;
+}
+
+static void substep(orc_sim *s, int sub, float h, float inv_h) {
+    const orc_params *p = &s->p;
+    const int n = s->n;
+    float *xp = s->xp, *xn = s->xn, *x0 = s->x0, *v0 = s->v0;
+    const float S = (float)p->numSubsteps;
+
+    /* 1. predict (NvFlex.h:99 gravity, :117 damping [form I], :545 invMass 0 = kinematic) */
+    for (int i = 0; i < n; ++i) {
+        const float w = s->pos[4 * i + 3];
+        for (int k = 0; k < 3; ++k) { x0[4 * i + k] = s->pos[4 * i + k]; v0[3 * i + k] = s->vel[3 * i + k]; }
+        x0[4 * i + 3] = w;
+        xp[4 * i + 3] = w;
+        if (w > 0.0f) {
+            for (int k = 0; k < 3; ++k) {
+                float v = s->vel[3 * i + k];
+                v = v + h * (p->gravity[k] - p->damping * v);
+                xp[4 * i + k] = x0[4 * i + k] + h * v;
+            }
+        } else {
+            for (int k = 0; k < 3; ++k) xp[4 * i + k] = x0[4 * i + k];
+        }
+    }
+
+    /* 2. neighbours (once per substep) */
+    find_neighbors(s);
+
+    /* 3. shapes at this substep: linear sweep prev -> current over the frame [I] (prev transforms: NvFlex.h:981-982) */
+    float sc[ORC_MAX_SHAPES][3], sd[ORC_MAX_SHAPES][3];
+    for (int q = 0; q < s->ns; ++q) {
+        float a1 = (float)(sub + 1) / S, a0 = (float)sub / S;
+        for (int k = 0; k < 3; ++k) {
+            float dlt = s->sh_pos[q][k] - s->sh_prev[q][k];
+            float c1 = s->sh_prev[q][k] + dlt * a1;
+            float c0 = s->sh_prev[q][k] + dlt * a0;
+            sc[q][k] = c1;
+            sd[q][k] = c1 - c0;
+        }
+    }
+
+    const float restd = p->solidRestDistance, restd2 = restd * restd;
+    const float cd = p->collisionDistance;
+    /* 4. Jacobi iterations with local relaxation (NvFlex.h:86-90,152-153) */
+    for (int it = 0; it < p->numIterations; ++it) {
+        for (int i = 0; i < n; ++i) {
+            const float wi = xp[4 * i + 3];
+            const float xi0 = xp[4 * i], xi1 = xp[4 * i + 1], xi2 = xp[4 * i + 2];
+            if (!(wi > 0.0f)) { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; xn[4 * i + 3] = wi; continue; }
+            float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+            int cnt = 0;
+            /* 4a. distance constraints (NvFlex.h:656-667), ascending spring id */
+            for (int a = s->adj_off[i]; a < s->adj_off[i + 1]; ++a) {
+                int e = s->adj_spr[a];
+                int j = (s->sidx[2 * e] == i) ? s->sidx[2 * e + 1] : s->sidx[2 * e];
+                const float wj = xp[4 * j + 3];
+                float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
+                float l2 = ex * ex + ey * ey + ez * ez;
+                float len = sqrtf(l2);
+                if (!(len > 0.0f)) continue;
+                float C = len - s->slen[e];
+                float k = s->sk[e];
+                if (k < 0.0f) { if (!(C > 0.0f)) continue; k = -k; } /* tether: unilateral */
+                float ratio = wi / (wi + wj);
+                float sc_ = (k * ratio) * (C / len);
+                d0 = d0 - ex * sc_; d1 = d1 - ey * sc_; d2 = d2 - ez * sc_;
+                cnt++;
+            }
+            /* 4b. particle-particle contacts (NvFlex.h:101 solidRestDistance, :107 particleFriction, :108 inelastic) */
+            const float ri0 = xi0 - x0[4 * i], ri1 = xi1 - x0[4 * i + 1], ri2 = xi2 - x0[4 * i + 2];
+            for (int a = 0; a < s->ncount[i]; ++a) {
+                int j = s->nlist[(size_t)ORC_MAX_NEIGHBORS * i + a];
+                const float wj = xp[4 * j + 3];
+                float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
+                float l2 = ex * ex + ey * ey + ez * ez;
+                if (!(l2 < restd2)) continue;
+                float dist = sqrtf(l2);
+                float nx, ny, nz;
+                if (dist > 0.0f) { float inv = 1.0f / dist; nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+                float pen = restd - dist;
+                float ratio = wi / (wi + wj);
+                float cn = pen * ratio;
+                float c0 = nx * cn, c1 = ny * cn, c2 = nz * cn;
+                if (p->particleFriction > 0.0f) {
+                    float rx = ri0 - (xp[4 * j] - x0[4 * j]);
+                    float ry = ri1 - (xp[4 * j + 1] - x0[4 * j + 1]);
+                    float rz = ri2 - (xp[4 * j + 2] - x0[4 * j + 2]);
+                    float rn = rx * nx + ry * ny + rz * nz;
+                    float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
+                    float tl2 = tx * tx + ty * ty + tz * tz;
+                    if (tl2 > 0.0f) {
+                        float tl = sqrtf(tl2);
+                        float fs = friction_scale(tl, pen, p->particleFriction, p->particleFriction) * ratio;
+                        c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+                    }
+                }
+                d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
+                cnt++;
+            }
+            /* 4c. planes (NvFlex.h:145 collisionDistance, :149 plane form, :105-106 friction) */
+            for (int q = 0; q < p->numPlanes; ++q) {
+                const float *pl = p->planes[q];
+                float sdist = pl[0] * xi0 + pl[1] * xi1 + pl[2] * xi2 + pl[3];
+                if (!(sdist < cd)) continue;
+                float pen = cd - sdist;
+                float c0 = pl[0] * pen, c1 = pl[1] * pen, c2 = pl[2] * pen;
+                float rn = ri0 * pl[0] + ri1 * pl[1] + ri2 * pl[2];
+                float tx = ri0 - pl[0] * rn, ty = ri1 - pl[1] * rn, tz = ri2 - pl[2] * rn;
+                float tl2 = tx * tx + ty * ty + tz * tz;
+                if (tl2 > 0.0f) {
+                    float tl = sqrtf(tl2);
+                    float fs = friction_scale(tl, pen, p->staticFriction, p->dynamicFriction);
+                    c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+                }
+                d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
+                cnt++;
+            }
+            /* 4d. kinematic spheres (NvFlex.h:941-987), all channels set so every particle collides (NvFlex.h:163,965) */
+            for (int q = 0; q < s->ns; ++q) {
+                float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
+                float l2 = ex * ex + ey * ey + ez * ez;
+                float lim = s->sh_radius[q] + cd;
+                if (!(l2 < lim * lim)) continue;
+                float dist = sqrtf(l2);
+                float nx, ny, nz;
+                if (dist > 0.0f) { float inv = 1.0f / dist; nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+                float pen = lim - dist;
+                float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
+                float rx = ri0 - sd[q][0], ry = ri1 - sd[q][1], rz = ri2 - sd[q][2];
+                float rn = rx * nx + ry * ny + rz * nz;
+                float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
+                float tl2 = tx * tx + ty * ty + tz * tz;
+                if (tl2 > 0.0f) {
+                    float tl = sqrtf(tl2);
+                    float fs = friction_scale(tl, pen, p->staticFriction, p->dynamicFriction);
+                    c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+                }
+                d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
+                cnt++;
+            }
+            /* 4e. applyDeltas, eNvFlexRelaxationLocal: delta / constraint count * relaxationFactor */
+            if (cnt > 0) {
+                float sc_ = p->relaxationFactor / (float)cnt;
+                xn[4 * i] = xi0 + d0 * sc_; xn[4 * i + 1] = xi1 + d1 * sc_; xn[4 * i + 2] = xi2 + d2 * sc_;
+            } else { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; }
+            xn[4 * i + 3] = wi;
+        }
+        float *t = xp; xp = xn; xn = t;
+    }
+    s->xp = xp; s->xn = xn;
+
+    /* 5. finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping
+          (NvFlex.h:110 "velocity magnitude < threshold => considered fixed"; Macklin 2014 section 4.5 freezes the
+          position when the particle moved less than the threshold; we also zero the velocity [I]) */
+    const float maxdv = p->maxAcceleration * h;
+    const float thr2 = p->sleepThreshold * p->sleepThreshold;
+    for (int i = 0; i < n; ++i) {
+        const float w = s->pos[4 * i + 3];
+        if (!(w > 0.0f)) { for (int k = 0; k < 3; ++k) s->vel[3 * i + k] = 0.0f; continue; }
+        float v[3], dv[3];
+        for (int k = 0; k < 3; ++k) { v[k] = (xp[4 * i + k] - x0[4 * i + k]) * inv_h; dv[k] = v[k] - v0[3 * i + k]; }
+        float dv2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+        if (dv2 > maxdv * maxdv) {
+            float sc_ = maxdv / sqrtf(dv2);
+            for (int k = 0; k < 3; ++k) v[k] = v0[3 * i + k] + dv[k] * sc_;
+        }
+        float v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        if (p->maxSpeed < FLT_MAX && v2 > p->maxSpeed * p->maxSpeed) {
+            float sc_ = p->maxSpeed / sqrtf(v2);
+            for (int k = 0; k < 3; ++k) v[k] = v[k] * sc_;
+            v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        }
+        if (v2 < thr2) { /* asleep: "considered fixed" -> keeps its position, zero velocity [I] */
+            for (int k = 0; k < 3; ++k) s->vel[3 * i + k] = 0.0f;
+        } else {
+            for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
+        }
+    }
+}
+
+int orc_step(orc_sim *s, int n_steps) {
+    if (!s || s->n <= 0) return -1;
+    for (int f = 0; f < n_steps; ++f) {
+        const float h = s->p.dt / (float)s->p.numSubsteps;
+        const float inv_h = 1.0f / h;
+        for (int sub = 0; sub < s->p.numSubsteps; ++sub) substep(s, sub, h, inv_h);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- accessors (pyflex.cpp:326-922) */
+
+int orc_n_particles(const orc_sim *s) { return s->n; }
+int orc_n_springs(const orc_sim *s) { return s->m; }
+int orc_n_triangles(const orc_sim *s) { return s->t; }
+int orc_n_shapes(const orc_sim *s) { return s->ns; }
+
+int orc_get_positions(const orc_sim *s, float *o) { memcpy(o, s->pos, sizeof(float) * 4 * s->n); return 0; }
+int orc_set_positions(orc_sim *s, const float *in) { memcpy(s->pos, in, sizeof(float) * 4 * s->n); return 0; }
+int orc_get_velocities(const orc_sim *s, float *o) { memcpy(o, s->vel, sizeof(float) * 3 * s->n); return 0; }
+int orc_set_velocities(orc_sim *s, const float *in) { memcpy(s->vel, in, sizeof(float) * 3 * s->n); return 0; }
+int orc_get_phases(const orc_sim *s, int *o) { memcpy(o, s->phase, sizeof(int) * s->n); return 0; }
+int orc_set_phases(orc_sim *s, const int *in) { memcpy(s->phase, in, sizeof(int) * s->n); return 0; }
+int orc_get_rest_positions(const orc_sim *s, float *o) { memcpy(o, s->rest, sizeof(float) * 4 * s->n); return 0; }
+int orc_get_normals(orc_sim *s, float *o) {
+    compute_normals(s->pos, s->tris, s->n, s->t, s->nrm);
+    memcpy(o, s->nrm, sizeof(float) * 4 * s->n);
+    return 0;
+}
+int orc_get_edges(const orc_sim *s, int *o) { memcpy(o, s->sidx, sizeof(int) * 2 * s->m); return 0; }
+int orc_get_faces(const orc_sim *s, int *o) { memcpy(o, s->tris, sizeof(int) * 3 * s->t); return 0; }
+int orc_get_spring_lengths(const orc_sim *s, float *o) { memcpy(o, s->slen, sizeof(float) * s->m); return 0; }
+int orc_get_spring_stiffness(const orc_sim *s, float *o) { memcpy(o, s->sk, sizeof(float) * s->m); return 0; }
+int orc_get_scene_bounds(const orc_sim *s, float *lo, float *up) {
+    memcpy(lo, s->scene_lower, sizeof(float) * 3);
+    memcpy(up, s->scene_upper, sizeof(float) * 3);
+    return 0;
+}
+
+int orc_get_params(const orc_sim *s, float *o) {
+    const orc_params *p = &s->p;
+    memset(o, 0, sizeof(float) * 32);
+    o[0] = (float)p->numIterations; o[1] = (float)p->numSubsteps; o[2] = p->dt;
+    o[3] = p->gravity[0]; o[4] = p->gravity[1]; o[5] = p->gravity[2];
+    o[6] = p->radius; o[7] = p->solidRestDistance; o[8] = p->collisionDistance; o[9] = p->shapeCollisionMargin;
+    o[10] = p->particleCollisionMargin; o[11] = p->dynamicFriction; o[12] = p->staticFriction; o[13] = p->particleFriction;
+    o[14] = p->damping; o[15] = p->sleepThreshold; o[16] = p->relaxationFactor; o[17] = p->maxAcceleration;
+    o[18] = p->maxSpeed; o[19] = p->restitution; o[20] = p->adhesion; o[21] = p->dissipation;
+    o[22] = (float)p->numPlanes; o[23] = p->planes[0][0]; o[24] = p->planes[0][1]; o[25] = p->planes[0][2];
+    o[26] = p->planes[0][3]; o[27] = (float)p->maxNeighbors; o[28] = (float)p->maxContacts; o[29] = (float)p->relaxationMode;
+    return 0;
+}
+
+/* helpers.h:484-499 AddSphere: prev := current */
+int orc_add_sphere(orc_sim *s, float radius, const float *pos, const float *quat) {
+    if (s->ns >= ORC_MAX_SHAPES) return -1;
+    int q = s->ns++;
+    s->sh_radius[q] = radius;
+    for (int k = 0; k < 3; ++k) { s->sh_pos[q][k] = pos[k]; s->sh_prev[q][k] = pos[k]; }
+    for (int k = 0; k < 4; ++k) { s->sh_rot[q][k] = quat[k]; s->sh_prevrot[q][k] = quat[k]; }
+    return 0;
+}
+int orc_clear_shapes(orc_sim *s) { s->ns = 0; return 0; }
+/* pyflex.cpp:789-822 layout: pos3, prevPos3, quat4, prevQuat4 */
+int orc_get_shape_states(const orc_sim *s, float *o) {
+    for (int q = 0; q < s->ns; ++q) {
+        for (int k = 0; k < 3; ++k) { o[14 * q + k] = s->sh_pos[q][k]; o[14 * q + 3 + k] = s->sh_prev[q][k]; }
+        for (int k = 0; k < 4; ++k) { o[14 * q + 6 + k] = s->sh_rot[q][k]; o[14 * q + 10 + k] = s->sh_prevrot[q][k]; }
+    }
+    return 0;
+}
+int orc_set_shape_states(orc_sim *s, const float *in) {
+    for (int q = 0; q < s->ns; ++q) {
+        for (int k = 0; k < 3; ++k) { s->sh_pos[q][k] = in[14 * q + k]; s->sh_prev[q][k] = in[14 * q + 3 + k]; }
+        for (int k = 0; k < 4; ++k) { s->sh_rot[q][k] = in[14 * q + 6 + k]; s->sh_prevrot[q][k] = in[14 * q + 10 + k]; }
+    }
+    return 0;
+}
+
+int orc_get_last_neighbors(const orc_sim *s, int *counts, int *lists) {
+    memcpy(counts, s->ncount, sizeof(int) * s->n);
+    memcpy(lists, s->nlist, sizeof(int) * (size_t)ORC_MAX_NEIGHBORS * s->n);
+    return 0;
+}

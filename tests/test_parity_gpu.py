@@ -1,0 +1,173 @@
+"""GPU parity tests: the HIP solver (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bar: integer/index data bit-exact; positions/velocities BIT-EXACT as well (stronger than the 1e-4 relative fp32
+tolerance north_star asks for) -- both sides run the same fp32 operation order without FMA contraction.
+The 1e-4 relative tolerance is still asserted explicitly so the documented bar is visible in the test.
+"""
+import numpy as np
+import pytest
+
+import scenarios as sc
+from conftest import cloth_params
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # north_star: positions within 1e-4 relative fp32
+
+
+def _sims(solver, n_envs=1):
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=solver)
+    return ctx, OracleSim()
+
+
+def _assert_state_equal(hip, orc, what=""):
+    ph, po = hip.get_positions(), orc.get_positions()
+    vh, vo = hip.get_velocities(), orc.get_velocities()
+    scale = max(1.0, float(np.abs(po).max()))
+    assert np.abs(ph - po).max() <= REL_TOL * scale, f"{what}: positions outside the 1e-4 bar"
+    assert np.array_equal(ph.view(np.uint32), po.view(np.uint32)), \
+        f"{what}: positions not bit-exact (max abs diff {np.abs(ph - po).max():.3e})"
+    assert np.array_equal(vh.view(np.uint32), vo.view(np.uint32)), \
+        f"{what}: velocities not bit-exact (max abs diff {np.abs(vh - vo).max():.3e})"
+
+
+SOLVERS = [1, 2]  # FS_SOLVER_STREAM, FS_SOLVER_FUSED
+
+
+@pytest.mark.parametrize("dims", [(32, 32), (64, 64), (5, 3), (1, 1), (2, 1)])
+def test_topology_bit_exact(gpu_required, dims):
+    ctx, orc = _sims(1)
+    hip = ctx.env(0)
+    p = cloth_params(*dims, pos=(0.3, 1.7, -0.2), stiff=(0.8, 1.0, 0.9), mass=0.37)
+    hip.set_scene(p)
+    orc.set_scene(p)
+    assert hip.n == orc.n
+    assert np.array_equal(hip.get_edges(), orc.get_edges())
+    assert np.array_equal(hip.get_faces(), orc.get_faces())
+    assert np.array_equal(hip.get_spring_lengths().view(np.uint32), orc.get_spring_lengths().view(np.uint32))
+    assert np.array_equal(hip.get_spring_stiffness().view(np.uint32), orc.get_spring_stiffness().view(np.uint32))
+    assert np.array_equal(hip.get_positions().view(np.uint32), orc.get_positions().view(np.uint32))
+    assert np.array_equal(hip.get_restPositions().view(np.uint32), orc.get_restPositions().view(np.uint32))
+    assert np.array_equal(hip.get_phases(), orc.get_phases())
+    assert np.array_equal(hip.get_params().view(np.uint32), orc.get_params().view(np.uint32))
+    assert np.array_equal(hip.get_velocities(), np.zeros(3 * hip.n, np.float32))
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_drop_32_bit_exact_every_step(gpu_required, solver):
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    for s in (hip, orc):
+        s.set_scene(cloth_params(32, 32, pos=(0.0, -0.1, 0.0)))
+    for k in range(50):
+        hip.step()
+        orc.step()
+        _assert_state_equal(hip, orc, f"drop step {k}")
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_crumple_bit_exact_and_neighbors(gpu_required, solver):
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    sc.scenario_crumple(hip, 32, 32, seed=3)
+    sc.scenario_crumple(orc, 32, 32, seed=3)
+    _assert_state_equal(hip, orc, "crumple end")
+    ch, lh = hip.get_last_neighbors()
+    co, lo = orc.get_last_neighbors()
+    assert co.sum() > 100, "scenario must exercise self-collision"
+    assert np.array_equal(ch, co)
+    for i in np.nonzero(co)[0]:
+        assert np.array_equal(lh[i, :co[i]], lo[i, :co[i]])
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_fling_with_pickers_bit_exact(gpu_required, solver):
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    ph = sc.scenario_fling(hip, 32, 32)
+    po = sc.scenario_fling(orc, 32, 32)
+    assert ph.picked == po.picked  # particle indices bit-exact
+    _assert_state_equal(hip, orc, "fling end")
+    assert np.array_equal(hip.get_shape_states(), orc.get_shape_states())
+
+
+def test_crumple_64_fused(gpu_required):
+    ctx, orc = _sims(2)
+    hip = ctx.env(0)
+    sc.scenario_crumple(hip, 64, 64, seed=1, lift_steps=30, settle_steps=30)
+    sc.scenario_crumple(orc, 64, 64, seed=1, lift_steps=30, settle_steps=30)
+    _assert_state_equal(hip, orc, "crumple 64")
+
+
+def test_large_cloth_uses_stream_path(gpu_required):
+    """80x80 = 6400 particles does not fit the fused kernel: AUTO must fall back to streaming and stay exact."""
+    from flingbot_amd import sim as fsim
+
+    ctx, orc = _sims(0)
+    hip = ctx.env(0)
+    for s in (hip, orc):
+        s.set_scene(cloth_params(80, 80, pos=(0.0, -0.05, 0.0)))
+    hip.step(12)
+    orc.step(12)
+    _assert_state_equal(hip, orc, "80x80")
+    ctx.set_solver(2)
+    with pytest.raises(fsim.FlingSimError):
+        hip.step()
+
+
+def test_batched_envs_match_single(gpu_required):
+    """Episodes in one batched launch are independent: each equals the oracle run of its own seed."""
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    n_envs = 5
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=0)
+    orcs = [OracleSim() for _ in range(n_envs)]
+    dims = [(32, 32), (32, 32), (16, 24), (32, 32), (40, 20)]
+    for e in range(n_envs):
+        p = cloth_params(*dims[e], pos=(0.0, -0.05 - 0.01 * e, 0.0))
+        ctx.set_scene(e, p)
+        orcs[e].set_scene(p)
+        rng = np.random.RandomState(e)
+        pos = orcs[e].get_positions().reshape(-1, 4).copy()
+        pos[:, 1] += (rng.rand(pos.shape[0]) * 0.01).astype(np.float32)
+        ctx.set_positions(e, pos.ravel())
+        orcs[e].set_positions(pos.ravel())
+    ctx.step(20)  # all envs, one launch per stage
+    for e in range(n_envs):
+        orcs[e].step(20)
+        _assert_state_equal(ctx.env(e), orcs[e], f"batched env {e}")
+
+
+def test_mesh_path_bit_exact(gpu_required):
+    """Explicit mesh (softgym_cloth.h:69-132): triangulated 6x5 sheet with hand-made edge lists."""
+    ctx, orc = _sims(0)
+    hip = ctx.env(0)
+    nx, nz, sp = 6, 5, 0.0125
+    verts = np.array([[x * sp, 0.0, z * sp] for z in range(nz) for x in range(nx)], np.float32)
+    idx = lambda x, z: z * nx + x
+    faces, stretch, bend, shear = [], [], [], []
+    for z in range(nz):
+        for x in range(nx):
+            if x + 1 < nx: stretch.append((idx(x, z), idx(x + 1, z)))
+            if z + 1 < nz: stretch.append((idx(x, z), idx(x, z + 1)))
+            if x + 2 < nx: bend.append((idx(x, z), idx(x + 2, z)))
+            if z + 2 < nz: bend.append((idx(x, z), idx(x, z + 2)))
+            if x + 1 < nx and z + 1 < nz:
+                shear.append((idx(x, z), idx(x + 1, z + 1)))
+                shear.append((idx(x + 1, z), idx(x, z + 1)))
+                faces.append((idx(x, z), idx(x + 1, z), idx(x + 1, z + 1)))
+                faces.append((idx(x, z), idx(x + 1, z + 1), idx(x, z + 1)))
+    p = cloth_params(0, 0, pos=(0.0, -0.08, 0.0), mass=0.05)
+    for s in (hip, orc):
+        s.set_scene(p, verts.ravel(), np.array(stretch).ravel(), np.array(bend).ravel(), np.array(shear).ravel(),
+                    np.array(faces).ravel())
+    assert hip.n == nx * nz
+    assert np.array_equal(hip.get_edges(), orc.get_edges())
+    assert np.array_equal(hip.get_spring_lengths().view(np.uint32), orc.get_spring_lengths().view(np.uint32))
+    hip.step(30)
+    orc.step(30)
+    _assert_state_equal(hip, orc, "mesh")
