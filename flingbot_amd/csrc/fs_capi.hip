@@ -41,6 +41,8 @@ fs_ctx::~fs_ctx() {
     if (h_stage) (void)hipHostFree(h_stage);
     if (render_scratch) (void)hipFree(render_scratch);
     if (d_coverage) (void)hipFree(d_coverage);
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (ev_stop) (void)hipEventDestroy(ev_stop);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -80,7 +82,7 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
               fs_hip_ok(hipMalloc((void **)&ctx->d_envs, sizeof(FsEnvDev) * n_envs), "hipMalloc(envs)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_shapes, sizeof(FsShapesDev) * n_envs), "hipMalloc(shapes)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_ids, sizeof(int) * n_envs), "hipMalloc(ids)") &&
-              fs_hip_ok(hipMalloc((void **)&ctx->d_coverage, sizeof(float) * n_envs), "hipMalloc(cov)") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_coverage, sizeof(double) * n_envs), "hipMalloc(cov)") &&
               fs_hip_ok(hipHostMalloc((void **)&ctx->h_ids, sizeof(int) * n_envs, hipHostMallocDefault), "hipHostMalloc") &&
               fs_hip_ok(hipMemset(ctx->d_envs, 0, sizeof(FsEnvDev) * n_envs), "hipMemset") &&
               fs_hip_ok(hipMemset(ctx->d_shapes, 0, sizeof(FsShapesDev) * n_envs), "hipMemset");
@@ -155,6 +157,8 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         topo->ell_len = c.take<float>(ell + 1);
         topo->ell_k = c.take<float>(ell + 1);
         topo->tris = c.take<int>(size_t(3) * s.t + 1);
+        topo->vt_off = c.take<int>(n + 1);
+        topo->vt_tri = c.take<int>(size_t(3) * s.t + 1);
         return c.off;
     };
     topo->bytes = carve(nullptr);
@@ -173,6 +177,8 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
     up(topo->ell_len, s.ell_len.data(), ell * 4);
     up(topo->ell_k, s.ell_k.data(), ell * 4);
     up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
+    up(topo->vt_off, s.vt_off.data(), (n + 1) * 4);
+    up(topo->vt_tri, s.vt_tri.data(), size_t(3) * s.t * 4);
     if (!ok) return nullptr;
     ctx->topo_cache.push_back(topo);
     return topo;
@@ -282,6 +288,45 @@ extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
             }
     }
     return solver == FS_SOLVER_FUSED ? fs_step_fused(ctx, ids, n_steps) : fs_step_stream(ctx, ids, n_steps);
+}
+
+extern "C" int fs_step_timed(fs_ctx *ctx, int env, int n_steps, float *elapsed_ms) {
+    if (!ctx || !elapsed_ms) { fs_set_error("null argument"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    // ids upload etc. happen before the start event is reached on the stream only if we flush first
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventRecord(a, ctx->stream));
+    int rc = fs_step(ctx, env, n_steps);
+    HIP_TRY(hipEventRecord(b, ctx->stream));
+    HIP_TRY(hipEventSynchronize(b));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return rc;
+}
+
+// HIP-event stopwatch on the context's stream: start records an event, stop records a second one, waits for it and
+// returns the device time between them.
+extern "C" int fs_timer_start(fs_ctx *ctx) {
+    if (!ctx) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->ev_start) {
+        HIP_TRY(hipEventCreate(&ctx->ev_start));
+        HIP_TRY(hipEventCreate(&ctx->ev_stop));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    return FS_OK;
+}
+extern "C" int fs_timer_stop(fs_ctx *ctx, float *elapsed_ms) {
+    if (!ctx || !elapsed_ms || !ctx->ev_start) { fs_set_error("fs_timer_stop without fs_timer_start"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return FS_OK;
 }
 
 extern "C" int fs_sync(fs_ctx *ctx) {
@@ -523,9 +568,9 @@ extern "C" int fs_render(fs_ctx *ctx, int env, unsigned char *rgba, int n_bytes,
     return fs_render_env(ctx, env, rgba, depth);
 }
 
-extern "C" int fs_coverage(fs_ctx *ctx, float *out, int n_floats) {
+extern "C" int fs_coverage(fs_ctx *ctx, double *out, int n_doubles) {
     if (!ctx || !out) return FS_ERR_ARG;
-    CHECK_LEN(n_floats, ctx->n_envs);
+    CHECK_LEN(n_doubles, ctx->n_envs);
     HIP_TRY(hipSetDevice(ctx->device));
     return fs_coverage_all(ctx, out);
 }

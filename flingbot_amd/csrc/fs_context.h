@@ -24,6 +24,7 @@ struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
     int *ell_j = nullptr;
     float *ell_len = nullptr, *ell_k = nullptr;
     int *tris = nullptr;  // 3t
+    int *vt_off = nullptr, *vt_tri = nullptr;  // vertex -> triangles CSR
     int t = 0;
     ~FsTopologyDev();
 };
@@ -63,7 +64,8 @@ struct fs_ctx {
     // renderer scratch (fs_render.hip)
     void *render_scratch = nullptr;
     size_t render_scratch_bytes = 0;
-    float *d_coverage = nullptr;
+    double *d_coverage = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // fs_timer_start / fs_timer_stop
 
     ~fs_ctx();
 };
@@ -79,4 +81,4 @@ bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env);
 // renderer / coverage
 int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth);
 int fs_normals_env(fs_ctx *ctx, int env, float *out4n);
-int fs_coverage_all(fs_ctx *ctx, float *out);
+int fs_coverage_all(fs_ctx *ctx, double *out);

@@ -145,6 +145,16 @@ void build_adjacency(FsHostScene &s) {
         }
 }
 
+void build_vertex_triangles(FsHostScene &s) {
+    s.vt_off.assign(size_t(s.n) + 1, 0);
+    for (size_t c = 0; c < s.tris.size(); ++c) s.vt_off[size_t(s.tris[c]) + 1]++;
+    for (int i = 0; i < s.n; ++i) s.vt_off[i + 1] += s.vt_off[i];
+    s.vt_tri.assign(s.tris.size(), 0);
+    std::vector<int> cursor(s.vt_off.begin(), s.vt_off.end() - 1);
+    for (int t = 0; t < s.t; ++t)
+        for (int c = 0; c < 3; ++c) s.vt_tri[cursor[s.tris[3 * size_t(t) + c]]++] = t;
+}
+
 }  // namespace
 
 std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const float *verts, int n_vert_floats,
@@ -236,5 +246,6 @@ std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const 
     p.planes[0][0] = 0.0f; p.planes[0][1] = 1.0f; p.planes[0][2] = 0.0f; p.planes[0][3] = 0.0f;
 
     build_adjacency(s);
+    build_vertex_triangles(s);
     return "";
 }

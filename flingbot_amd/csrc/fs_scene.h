@@ -32,6 +32,8 @@ struct FsHostScene {
     std::vector<float> adj_len, adj_k;
     std::vector<int> ell_j;
     std::vector<float> ell_len, ell_k;
+    // vertex -> incident triangles (ascending triangle id), for the vertex-normal gather
+    std::vector<int> vt_off, vt_tri;
 };
 
 // Returns "" on success, otherwise an error message.

@@ -70,7 +70,15 @@ def load_library(build_if_missing=True):
         "fs_get_camera_params": (ci, [vp, ci, fp]),
         "fs_set_camera_params": (ci, [vp, ci, fp]),
         "fs_render": (ci, [vp, ci, u8p, ci, fp, ci]),
-        "fs_coverage": (ci, [vp, fp, ci]),
+        "fs_coverage": (ci, [vp, C.POINTER(C.c_double), ci]),
+        "fs_step_timed": (ci, [vp, ci, ci, fp]),
+        "fs_timer_start": (ci, [vp]),
+        "fs_timer_stop": (ci, [vp, fp]),
+        "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
+        "fs_host_scene_free": (None, [vp]),
+        "fs_host_scene_counts": (ci, [vp, ip, ip, ip, ip]),
+        "fs_host_scene_copy": (ci, [vp, ci, vp, ci]),
+        "fs_camera_matrices": (ci, [fp, fp, ci, ci, fp, fp, fp]),
         "fs_get_last_neighbors": (ci, [vp, ci, ip, ip]),
         "fs_device_positions": (vp, [vp, ci]),
     }
@@ -144,9 +152,23 @@ class FlingSim:
         return self.lib.fs_stream(self.h)
 
     def coverage(self):
-        out = np.empty(self.n_envs, np.float32)
-        self._ck(self.lib.fs_coverage(self.h, _fp(out), out.size))
+        out = np.empty(self.n_envs, np.float64)
+        self._ck(self.lib.fs_coverage(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), out.size))
         return out
+
+    def step_timed(self, n_steps=1, env=-1):
+        """fs_step bracketed by HIP events on the context's stream -> elapsed device milliseconds."""
+        ms = C.c_float(0.0)
+        self._ck(self.lib.fs_step_timed(self.h, int(env), int(n_steps), C.byref(ms)))
+        return float(ms.value)
+
+    def timer_start(self):
+        self._ck(self.lib.fs_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float(0.0)
+        self._ck(self.lib.fs_timer_stop(self.h, C.byref(ms)))
+        return float(ms.value)
 
     # ---- per env, pyflex-shaped
     def set_scene(self, env, scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):
@@ -291,3 +313,50 @@ class EnvView:
         if name.startswith("get_") or name in ("clear_shapes", "render"):
             return lambda: fn(self.e)
         return lambda *a: fn(self.e, *a)
+
+
+# ---- host-only helpers (no GPU needed): scene builder and camera set-up of the C-ABI
+SCENE_ARRAYS = {"positions": (0, np.float32), "velocities": (1, np.float32), "phases": (2, np.int32),
+                "springs": (3, np.int32), "spring_lengths": (4, np.float32), "spring_stiffness": (5, np.float32),
+                "triangles": (6, np.int32), "tri_normals": (7, np.float32), "adj_offsets": (8, np.int32),
+                "adj_neighbors": (9, np.int32), "bounds": (10, np.float32), "params": (11, np.float32)}
+
+
+def host_scene(scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):
+    """Run the product's host scene builder (fs_host_scene_build) and return every array as numpy."""
+    lib = load_library()
+    sp = _f(scene_params)
+    v, st, be, sh, fa = _f(vertices), _i(stretch_edges), _i(bend_edges), _i(shear_edges), _i(faces)
+    h = lib.fs_host_scene_build(_fp(sp), sp.size, _fp(v), v.size, _ip(st), st.size, _ip(be), be.size, _ip(sh), sh.size,
+                                _ip(fa), fa.size)
+    if not h:
+        raise FlingSimError(lib.fs_last_error().decode())
+    try:
+        cnt = [C.c_int(0) for _ in range(4)]
+        lib.fs_host_scene_counts(h, *[C.byref(c) for c in cnt])
+        n, m, t, deg = [c.value for c in cnt]
+        sizes = {"positions": 4 * n, "velocities": 3 * n, "phases": n, "springs": 2 * m, "spring_lengths": m,
+                 "spring_stiffness": m, "triangles": 3 * t, "tri_normals": 3 * t, "adj_offsets": n + 1,
+                 "adj_neighbors": 2 * m, "bounds": 6, "params": 32}
+        out = {"n": n, "m": m, "t": t, "max_deg": deg}
+        for name, (code, dt) in SCENE_ARRAYS.items():
+            a = np.zeros(max(sizes[name], 1), dt)
+            rc = lib.fs_host_scene_copy(h, code, a.ctypes.data_as(C.c_void_p), a.size)
+            if rc < 0:
+                raise FlingSimError(lib.fs_last_error().decode())
+            out[name] = a[:sizes[name]]
+        return out
+    finally:
+        lib.fs_host_scene_free(h)
+
+
+def camera_matrices(cam_pos, cam_angle, width, height, scene_lower, scene_upper):
+    """fs_camera_matrices -> dict(view[4,4], proj[4,4], light[4,4], lightpos[3], lightdir[3]) (row-major)."""
+    lib = load_library()
+    a = [_f(x) for x in (cam_pos, cam_angle, scene_lower, scene_upper)]
+    out = np.zeros(54, np.float32)
+    rc = lib.fs_camera_matrices(_fp(a[0]), _fp(a[1]), int(width), int(height), _fp(a[2]), _fp(a[3]), _fp(out))
+    if rc < 0:
+        raise FlingSimError("fs_camera_matrices failed")
+    return {"view": out[0:16].reshape(4, 4), "proj": out[16:32].reshape(4, 4), "light": out[32:48].reshape(4, 4),
+            "lightpos": out[48:51], "lightdir": out[51:54]}

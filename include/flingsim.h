@@ -55,6 +55,12 @@ int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int n_params, 
    stream; every getter synchronises. */
 int fs_step(fs_ctx *ctx, int env, int n_steps);
 int fs_sync(fs_ctx *ctx);
+/* fs_step bracketed by HIP events recorded on the context's stream; returns the elapsed device time of the launch(es)
+   in milliseconds.  Used by bench.py for the per-launch kernel duration (roofline). */
+int fs_step_timed(fs_ctx *ctx, int env, int n_steps, float *elapsed_ms);
+/* HIP-event stopwatch on the context's stream (non-blocking start; stop waits for the stream to reach it). */
+int fs_timer_start(fs_ctx *ctx);
+int fs_timer_stop(fs_ctx *ctx, float *elapsed_ms);
 /* the HIP stream (hipStream_t) the context launches on, for callers that time with HIP events */
 void *fs_stream(fs_ctx *ctx);
 
@@ -98,13 +104,40 @@ int fs_set_camera_params(fs_ctx *ctx, int env, const float *in8);
 /* pyflex.render (pyflex.cpp:924-1133): RGBA8 bottom-up [h*w*4] and linear depth [h*w] of env. */
 int fs_render(fs_ctx *ctx, int env, unsigned char *rgba, int n_bytes, float *depth, int n_floats);
 
-/* coverage reward of every env (flex_utils.py:358-395 get_current_covered_area), out[n_envs] */
-int fs_coverage(fs_ctx *ctx, float *out, int n_floats);
+/* coverage reward of every env (flex_utils.py:358-395 get_current_covered_area with pos=None, particle radius
+   0.00625), out[n_envs] in float64 like the reference's return value; envs without a scene report 0. */
+int fs_coverage(fs_ctx *ctx, double *out, int n_doubles);
 
 /* white-box access for tests: particle-contact candidate lists of the last substep, counts[N], lists[N*96] */
 int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
 /* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */
 void *fs_device_positions(fs_ctx *ctx, int env);
+
+/* ---- host-only entry points (no HIP device needed) ------------------------------------------------------------
+   Scene builder exposed on its own so host logic can be checked without a GPU: same arguments as fs_set_scene. */
+typedef struct fs_host_scene fs_host_scene;
+#define FS_SCENE_POSITIONS 0        /* float[4N] */
+#define FS_SCENE_VELOCITIES 1       /* float[3N] */
+#define FS_SCENE_PHASES 2           /* int[N] */
+#define FS_SCENE_SPRINGS 3          /* int[2M]   (pyflex.get_edges) */
+#define FS_SCENE_SPRING_LENGTHS 4   /* float[M] */
+#define FS_SCENE_SPRING_STIFFNESS 5 /* float[M] */
+#define FS_SCENE_TRIANGLES 6        /* int[3T]   (pyflex.get_faces) */
+#define FS_SCENE_TRI_NORMALS 7      /* float[3T] */
+#define FS_SCENE_ADJ_OFFSETS 8      /* int[N+1]  particle -> spring CSR */
+#define FS_SCENE_ADJ_NEIGHBORS 9    /* int[2M] */
+#define FS_SCENE_BOUNDS 10          /* float[6] lower, upper */
+#define FS_SCENE_PARAMS 11          /* float[32] packed parameter table */
+fs_host_scene *fs_host_scene_build(const float *scene_params, int n_params, const float *verts, int n_vert_floats,
+                                   const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints,
+                                   const int *shear, int n_shear_ints, const int *faces, int n_face_ints);
+void fs_host_scene_free(fs_host_scene *h);
+int fs_host_scene_counts(const fs_host_scene *h, int *n, int *m, int *t, int *max_deg);
+int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, int n_elems);
+/* RenderScene camera / light set-up (main.cpp:1411-1438; core/maths.h:507-598): out[0:16] view, [16:32] proj,
+   [32:48] lightTransform (row-major, column vectors), [48:51] lightPos, [51:54] lightDir. */
+int fs_camera_matrices(const float *cam_pos3, const float *cam_angle3, int width, int height,
+                       const float *scene_lower3, const float *scene_upper3, float *out54);
 
 #ifdef __cplusplus
 }

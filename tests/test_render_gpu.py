@@ -1,0 +1,130 @@
+"""GPU tests of the observation side of the hot path: coverage reward, vertex normals, rasteriser."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import cloth_params
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _grid_for(n):
+    """A (dimx, dimz) grid with exactly n particles."""
+    for dx in range(int(np.sqrt(n)), 0, -1):
+        if n % dx == 0:
+            return dx, n // dx
+    raise AssertionError
+
+
+def test_coverage_matches_reference_vectors(gpu_required):
+    """fs_coverage == the reference's get_current_covered_area on its own golden vectors (exact float64)."""
+    from flingbot_amd import sim as fsim
+    from oracle.coverage import covered_area
+
+    g = np.load(os.path.join(GOLD, "coverage_golden.npz"))
+    names = [k[4:] for k in g.files if k.startswith("pos_")]
+    ctx = fsim.FlingSim(n_envs=len(names) + 1)  # last env has no scene -> 0
+    for e, k in enumerate(names):
+        pos = g["pos_" + k]
+        ctx.set_scene(e, cloth_params(*_grid_for(pos.shape[0])))
+        ctx.set_positions(e, pos.ravel())
+    cov = ctx.coverage()
+    for e, k in enumerate(names):
+        ref = float(g["area_" + k])
+        assert covered_area(g["pos_" + k].ravel()) == ref  # oracle pinned to the reference vector
+        assert cov[e] == ref, (k, cov[e], ref)
+    assert cov[-1] == 0.0
+
+
+def test_coverage_after_simulation(gpu_required):
+    from flingbot_amd import sim as fsim
+    from oracle.coverage import covered_area
+    import scenarios as sc
+
+    ctx = fsim.FlingSim(n_envs=2)
+    sc.scenario_crumple(ctx.env(0), 32, 32, seed=5, lift_steps=20, settle_steps=30)
+    sc.scenario_drop(ctx.env(1), 24, 40, steps=30)
+    cov = ctx.coverage()
+    for e in range(2):
+        assert cov[e] == covered_area(ctx.get_positions(e))
+
+
+def test_vertex_normals_match_oracle(gpu_required):
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+    import scenarios as sc
+
+    ctx, orc = fsim.FlingSim(n_envs=1), OracleSim()
+    sc.scenario_crumple(ctx.env(0), 32, 32, seed=2, lift_steps=20, settle_steps=10)
+    sc.scenario_crumple(orc, 32, 32, seed=2, lift_steps=20, settle_steps=10)
+    nh, no = ctx.get_normals(0), orc.get_normals()
+    assert np.abs(np.linalg.norm(nh.reshape(-1, 4)[:, :3], axis=1) - 1.0).max() < 1e-5
+    assert np.array_equal(nh.view(np.uint32), no.view(np.uint32)), np.abs(nh - no).max()
+
+
+def test_render_flat_cloth_geometry(gpu_required):
+    """Geometric pins of the rasteriser: flat cloth at height h under the top-down FlingBot camera
+    (pos (0,2,0), fov 39.5978 deg): depth = 2 - h inside the projected rectangle, ~2.0 on the ground; the cloth covers
+    (side * 720 / (2 * d * tan(fov/2)))^2 pixels; rows are bottom-up, world +x -> -y_ndc, +z -> -x_ndc."""
+    from flingbot_amd import sim as fsim
+    import scenarios as sc
+
+    ctx = fsim.FlingSim(n_envs=1)
+    env = ctx.env(0)
+    env.set_scene(cloth_params(64, 64, pos=(0.0, 2.0, 0.0)))
+    h = 0.05
+    w = env.get_positions().reshape(-1, 4)[0, 3]
+    p = sc.flat_positions(64, 64, y=h, inv_mass=w)
+    p[:, 0] += 0.1  # shift +x to check the axis convention
+    env.set_positions(p.ravel())
+    rgba, depth = env.render()
+    assert rgba.shape == (720 * 720 * 4,) and depth.shape == (720 * 720,)
+    img = rgba.reshape(720, 720, 4)
+    d = depth.reshape(720, 720)
+    ground = np.abs(d - 2.0) < 1e-4
+    cloth = np.abs(d - (2.0 - h)) < 1e-4
+    assert ground.sum() + cloth.sum() == 720 * 720
+    side = 63 * 0.00625
+    px_per_m = 720 / (2 * (2.0 - h) * np.tan(np.radians(39.5978 / 2)))
+    expect = (side * px_per_m) ** 2
+    assert abs(cloth.sum() - expect) / expect < 0.02, (cloth.sum(), expect)
+    rows, cols = np.nonzero(cloth)
+    # world +x maps to -y_ndc: the cloth (shifted to +x) sits BELOW the image centre in the bottom-up buffer
+    assert rows.mean() < 359.5 - 0.1 * px_per_m * 0.8
+    assert abs(cols.mean() - 359.5) < 1.5
+    # colours: cloth is the pink g_colors[4] * 1.5, ground is the near-black plane; alpha 255 everywhere
+    c = img[cloth][:, :3].astype(float).mean(0)
+    assert c[0] > c[2] > c[1] and c[0] > 100, c
+    gcol = img[ground][:, :3].astype(float).mean(0)
+    assert gcol.max() < 40, gcol
+    assert (img[..., 3] == 255).all()
+    # the cloth throws a shadow: some ground pixels are darker than the lit ground
+    gl = img[ground][:, 0].astype(int)
+    assert gl.min() < gl.max()
+
+
+def test_render_pickers_visible_and_idempotent(gpu_required):
+    from flingbot_amd import sim as fsim
+    import scenarios as sc
+
+    ctx = fsim.FlingSim(n_envs=1)
+    env = ctx.env(0)
+    env.set_scene(cloth_params(32, 32, pos=(0.0, 2.0, 0.0)))
+    w = env.get_positions().reshape(-1, 4)[0, 3]
+    env.set_positions(sc.flat_positions(32, 32, y=0.01, inv_mass=w).ravel())
+    env.add_sphere(0.02, [0.4, 0.5, -0.4], [1, 0, 0, 0])
+    env.add_sphere(0.02, [-0.4, 0.5, -0.4], [1, 0, 0, 0])
+    before = env.get_positions().copy()
+    rgba1, depth1 = env.render()
+    rgba2, depth2 = env.render()
+    assert np.array_equal(rgba1, rgba2) and np.array_equal(depth1, depth2)
+    assert np.array_equal(before, env.get_positions())  # render never ticks the solver (pyflex.cpp:1079-1087)
+    d = depth1.reshape(720, 720)
+    sph = (d > 1.47) & (d < 1.53)
+    # two discs of radius 0.02 m at distance 1.5: r_px = 0.02 * 720 / (2 * 1.5 * tan(fov/2))
+    r_px = 0.02 * 720 / (2 * 1.5 * np.tan(np.radians(39.5978 / 2)))
+    assert abs(sph.sum() - 2 * np.pi * r_px ** 2) / (2 * np.pi * r_px ** 2) < 0.15, sph.sum()
+    img = rgba1.reshape(720, 720, 4)
+    assert img[sph][:, :3].mean() > 120  # 0.9 grey spheres
