@@ -96,8 +96,9 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
 extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
 extern "C" int fs_n_envs(const fs_ctx *ctx) { return ctx ? ctx->n_envs : FS_ERR_ARG; }
 extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
-    if (!ctx || solver < 0 || solver > 2) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
-    ctx->solver = solver;
+    if (!ctx || solver < 0 || solver > 3) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    ctx->force_generic_fused = (solver == FS_SOLVER_FUSED_GENERIC);
+    ctx->solver = solver == FS_SOLVER_FUSED_GENERIC ? FS_SOLVER_FUSED : solver;
     return FS_OK;
 }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
@@ -156,6 +157,9 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         topo->ell_j = c.take<int>(ell + 1);
         topo->ell_len = c.take<float>(ell + 1);
         topo->ell_k = c.take<float>(ell + 1);
+        topo->dict = c.take<float>(512);
+        topo->code_w = c.take<uint32_t>(size_t(8) * n + 1);
+        topo->nbr_w = c.take<uint32_t>(size_t(8) * n + 1);
         topo->tris = c.take<int>(size_t(3) * s.t + 1);
         topo->vt_off = c.take<int>(n + 1);
         topo->vt_tri = c.take<int>(size_t(3) * s.t + 1);
@@ -176,6 +180,12 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
     up(topo->ell_j, s.ell_j.data(), ell * 4);
     up(topo->ell_len, s.ell_len.data(), ell * 4);
     up(topo->ell_k, s.ell_k.data(), ell * 4);
+    topo->dict_size = s.dict_size;
+    up(topo->dict, s.dict.data(), 512 * 4);
+    if (s.dict_size > 0) {
+        up(topo->code_w, s.code_w.data(), size_t(8) * n * 4);
+        up(topo->nbr_w, s.nbr_w.data(), size_t(8) * n * 4);
+    }
     up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
     up(topo->vt_off, s.vt_off.data(), (n + 1) * 4);
     up(topo->vt_tri, s.vt_tri.data(), size_t(3) * s.t * 4);
@@ -241,6 +251,7 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     d.n = scene.n; d.m = scene.m; d.max_deg = scene.max_deg; d.has_scene = 1;
     d.rest = topo->rest; d.adj_off = topo->adj_off; d.adj_j = topo->adj_j; d.adj_len = topo->adj_len; d.adj_k = topo->adj_k;
     d.ell_j = topo->ell_j; d.ell_len = topo->ell_len; d.ell_k = topo->ell_k;
+    d.dict_size = topo->dict_size; d.dict = topo->dict; d.code_w = topo->code_w; d.nbr_w = topo->nbr_w;
     d.p = scene.params;
 
     // uploads (main.cpp:1025-1085): positions, velocities (zero), phases

@@ -20,10 +20,33 @@ struct FsAcc {
     int cnt;
 };
 
-__device__ __forceinline__ float fs_friction_scale(float tl, float pen, float mu_s, float mu_k) {
+// Reciprocal square root for every length inside the constraint sweeps: integer seed + three Newton steps, a fixed
+// sequence of IEEE fp32 multiplies / subtracts (max error 2.5 ulp).  Being a pure function of add/mul it gives the
+// same bits on the CPU oracle and on the GPU, and replaces the ~30 instruction correctly-rounded sqrt + divide
+// sequences (two quarter-rate ops among them) by 15 full-rate VALU ops.
+__device__ __forceinline__ float fs_rsqrt(float x) {
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
+    const float xh = 0.5f * x;
+    y = y * (1.5f - (xh * y) * y);
+    y = y * (1.5f - (xh * y) * y);
+    y = y * (1.5f - (xh * y) * y);
+    return y;
+}
+
+// friction scale on a tangential displacement of length tl = tl2 * inv_tl under penetration pen
+__device__ __forceinline__ float fs_friction_scale(float tl, float inv_tl, float pen, float mu_s, float mu_k) {
     if (tl < mu_s * pen) return 1.0f;
     float lim = mu_k * pen;
-    return (tl > lim) ? lim / tl : 1.0f;
+    return (tl > lim) ? lim * inv_tl : 1.0f;
+}
+
+// wi / (wi + wj), correctly rounded.  Shortcuts for the two cases that cover a cloth (equal masses: x / 2x == 0.5;
+// pinned neighbour: x / x == 1) are exact, so the result equals the IEEE division bit for bit while the ~10
+// instruction division sequence is skipped by whole waves.
+__device__ __forceinline__ float fs_mass_ratio(float wi, float wj) {
+    if (wj == wi) return 0.5f;
+    if (wj == 0.0f) return 1.0f;
+    return wi / (wi + wj);
 }
 
 // distance constraint between particle i (xi, wi) and j (xj.w = invMass), rest length L, stiffness k (<0: tether)
@@ -31,19 +54,47 @@ __device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float 
                                           float k) {
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
     float l2 = ex * ex + ey * ey + ez * ez;
-    float len = sqrtf(l2);
+    float inv_len = fs_rsqrt(l2);
+    float len = l2 * inv_len;
     if (!(len > 0.0f)) return;
     float C = len - L;
     if (k < 0.0f) {
         if (!(C > 0.0f)) return;
         k = -k;
     }
-    float ratio = wi / (wi + xj.w);
-    float sc = (k * ratio) * (C / len);
+    float ratio = fs_mass_ratio(wi, xj.w);
+    float sc = (k * ratio) * (C * inv_len);
     a.d0 = a.d0 - ex * sc;
     a.d1 = a.d1 - ey * sc;
     a.d2 = a.d2 - ez * sc;
     a.cnt++;
+}
+
+// Branch-free form of fs_spring for straight-line scheduling (the fused kernel batches its LDS gathers in front of
+// it).  Every lane evaluates the same instruction stream; inactive constraints (zero length, slack tether) are
+// masked with selects, so an active constraint performs exactly the operations of fs_spring, in the same order.
+__device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, float xi2, float wi, const FsVec4 xj, float L,
+                                             float k) {
+    float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
+    float l2 = ex * ex + ey * ey + ez * ez;
+    float inv_len = fs_rsqrt(l2);
+    float len = l2 * inv_len;
+    float C = len - L;
+    const bool tether = k < 0.0f;
+    const bool active = (len > 0.0f) && (!tether || (C > 0.0f));
+    const float kk = tether ? -k : k;
+    // wi / (wi + wj): exact shortcuts (see fs_mass_ratio); the division runs only if some lane of the wave needs it
+    const float wj = xj.w;
+    float ratio = (wj == wi) ? 0.5f : 1.0f;
+    const bool odd = active && (wj != wi) && (wj != 0.0f);
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
+    // an inactive constraint contributes sc = +0: d - e * 0 == d for every finite e (the accumulators start at +0
+    // and can never become -0), so one select on the scale replaces three on the accumulators
+    float sc = active ? (kk * ratio) * (C * inv_len) : 0.0f;
+    a.d0 = a.d0 - ex * sc;
+    a.d1 = a.d1 - ey * sc;
+    a.d2 = a.d2 - ez * sc;
+    a.cnt += active ? 1 : 0;
 }
 
 // particle-particle contact; (ri*) = xi - x0_i, rj = xj - x0_j (displacement since substep start)
@@ -53,16 +104,16 @@ __device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float x
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
     float l2 = ex * ex + ey * ey + ez * ez;
     if (!(l2 < restd2)) return;
-    float dist = sqrtf(l2);
+    float inv = fs_rsqrt(l2);
+    float dist = l2 * inv;
     float nx, ny, nz;
     if (dist > 0.0f) {
-        float inv = 1.0f / dist;
         nx = ex * inv; ny = ey * inv; nz = ez * inv;
     } else {
         nx = 0.0f; ny = 1.0f; nz = 0.0f;
     }
     float pen = restd - dist;
-    float ratio = wi / (wi + xj.w);
+    float ratio = fs_mass_ratio(wi, xj.w);
     float cn = pen * ratio;
     float c0 = nx * cn, c1 = ny * cn, c2 = nz * cn;
     if (mu > 0.0f) {
@@ -71,8 +122,9 @@ __device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float x
         float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
         float tl2 = tx * tx + ty * ty + tz * tz;
         if (tl2 > 0.0f) {
-            float tl = sqrtf(tl2);
-            float fs = fs_friction_scale(tl, pen, mu, mu) * ratio;
+            float inv_tl = fs_rsqrt(tl2);
+            float tl = tl2 * inv_tl;
+            float fs = fs_friction_scale(tl, inv_tl, pen, mu, mu) * ratio;
             c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
         }
     }
@@ -91,8 +143,9 @@ __device__ __forceinline__ void fs_plane_contact(FsAcc &a, float xi0, float xi1,
     float tx = ri0 - p0 * rn, ty = ri1 - p1 * rn, tz = ri2 - p2 * rn;
     float tl2 = tx * tx + ty * ty + tz * tz;
     if (tl2 > 0.0f) {
-        float tl = sqrtf(tl2);
-        float fs = fs_friction_scale(tl, pen, mu_s, mu_k);
+        float inv_tl = fs_rsqrt(tl2);
+        float tl = tl2 * inv_tl;
+        float fs = fs_friction_scale(tl, inv_tl, pen, mu_s, mu_k);
         c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
     }
     a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
@@ -107,10 +160,10 @@ __device__ __forceinline__ void fs_sphere_contact(FsAcc &a, float xi0, float xi1
     float l2 = ex * ex + ey * ey + ez * ez;
     float lim = r + cd;
     if (!(l2 < lim * lim)) return;
-    float dist = sqrtf(l2);
+    float inv = fs_rsqrt(l2);
+    float dist = l2 * inv;
     float nx, ny, nz;
     if (dist > 0.0f) {
-        float inv = 1.0f / dist;
         nx = ex * inv; ny = ey * inv; nz = ez * inv;
     } else {
         nx = 0.0f; ny = 1.0f; nz = 0.0f;
@@ -122,8 +175,9 @@ __device__ __forceinline__ void fs_sphere_contact(FsAcc &a, float xi0, float xi1
     float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
     float tl2 = tx * tx + ty * ty + tz * tz;
     if (tl2 > 0.0f) {
-        float tl = sqrtf(tl2);
-        float fs = fs_friction_scale(tl, pen, mu_s, mu_k);
+        float inv_tl = fs_rsqrt(tl2);
+        float tl = tl2 * inv_tl;
+        float fs = fs_friction_scale(tl, inv_tl, pen, mu_s, mu_k);
         c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
     }
     a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;

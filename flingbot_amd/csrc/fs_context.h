@@ -23,6 +23,9 @@ struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
     float *adj_len = nullptr, *adj_k = nullptr;
     int *ell_j = nullptr;
     float *ell_len = nullptr, *ell_k = nullptr;
+    int dict_size = 0;
+    float *dict = nullptr;
+    uint32_t *code_w = nullptr, *nbr_w = nullptr;
     int *tris = nullptr;  // 3t
     int *vt_off = nullptr, *vt_tri = nullptr;  // vertex -> triangles CSR
     int t = 0;
@@ -51,6 +54,7 @@ struct fs_ctx {
     int device = 0;
     int n_envs = 0;
     int solver = 0;
+    bool force_generic_fused = false;  // FS_SOLVER_FUSED_GENERIC: fused kernel with the streamed ELL adjacency
     hipStream_t stream = nullptr;
     std::vector<FsEnv> envs;
     FsEnvDev *d_envs = nullptr;       // [n_envs]

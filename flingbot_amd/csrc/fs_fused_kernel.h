@@ -4,12 +4,14 @@
 // positions (3 x 16 KiB) and the spatial-hash bins (24 KiB) all fit the 160 KiB LDS of one CU, so the 4 substeps x
 // 30 Jacobi iterations of a frame (reference softgym_cloth.h:154-155) run without touching HBM for particle state:
 // 1024 threads (16 waves, 4 per SIMD), 4 particles per thread held in registers across the frame, neighbour
-// positions gathered from LDS with ds_read_b128.  HBM/L2 traffic is the read-only spring adjacency (shared by all
-// episodes of the same cloth, L2-resident) and the per-particle contact candidate lists.  Grid = #episodes: 256 CUs
-// advance 256 episodes concurrently.
+// positions gathered from LDS with ds_read_b128.  Grid = #episodes: 256 CUs advance 256 episodes concurrently.
 //
-// Arithmetic is the same per-particle code as the streaming kernels (fs_constraints.h), so both back-ends and the
-// CPU oracle agree bit for bit.
+// Two variants share all arithmetic (fs_constraints.h), so they and the CPU oracle agree bit for bit:
+//   * compact  -- the spring adjacency lives in REGISTERS: per particle 16 slots of {16-bit neighbour id, 8-bit code}
+//                 (12 VGPRs), the code indexing a <= 256-entry dictionary of distinct (rest length, stiffness) pairs
+//                 held in LDS.  A grid cloth has a few dozen distinct pairs.  No global memory traffic in the
+//                 iteration loop apart from the contact-candidate lists.
+//   * generic  -- adjacency streamed from an L2-resident ELL table (any degree, any number of distinct springs).
 #pragma once
 #include "fs_constraints.h"
 
@@ -18,26 +20,252 @@
 #define FS_FUSED_MAX_PARTICLES (FS_FUSED_THREADS * FS_FUSED_PPT)
 #define FS_FUSED_MAX_DEG 64
 #define FS_FUSED_BUCKETS 4096  // 32 x 4 x 32 wrapped cells (>= 3 per axis: a 3x3x3 block never aliases itself)
+#define FS_FUSED_SLOTS 16      // compact adjacency slots per particle
 
-// LDS carve (bytes): X float4[4096] | X0x,X0y,X0z float[4096] | cursor int[4096] | items ushort[4096] | scan int[16]
+// LDS carve (bytes), exactly the 160 KiB of one CU:
+//   X  float4[4096]  current Jacobi iterate (xyz + invMass)                          64 KiB
+//   X0 float[3][4096] substep-start position (own displacement + neighbours' for friction)  48 KiB
+//   XN float[3][4096] next iterate, published into X after the barrier                48 KiB
+//      -- aliased, while no iteration is running, by the spatial hash: cursor int[4096] | items u16[4096] | scan
 #define FS_FUSED_OFF_X 0
-#define FS_FUSED_OFF_X0 (FS_FUSED_MAX_PARTICLES * 16)
-#define FS_FUSED_OFF_CUR (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
+#define FS_FUSED_OFF_X0 (FS_FUSED_OFF_X + FS_FUSED_MAX_PARTICLES * 16)
+#define FS_FUSED_OFF_XN (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
+#define FS_FUSED_OFF_CUR FS_FUSED_OFF_XN
 #define FS_FUSED_OFF_ITEMS (FS_FUSED_OFF_CUR + FS_FUSED_BUCKETS * 4)
 #define FS_FUSED_OFF_SCAN (FS_FUSED_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
-#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_SCAN + 64)
+#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_XN + FS_FUSED_MAX_PARTICLES * 12)
+#define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
+
+#define FS_GLOBAL __attribute__((address_space(1)))
+typedef FS_GLOBAL const int *fs_gci;
+typedef FS_GLOBAL int *fs_gi;
+typedef FS_GLOBAL const float *fs_gcf;
+typedef FS_GLOBAL const uint32_t *fs_gcu;
+typedef FS_GLOBAL const FsVec4 *fs_gcv4;
+typedef FS_GLOBAL FsVec4 *fs_gv4;
+
+// 16-byte global load/store through builtin vector types (address-space qualified structs cannot be copied in C++)
+typedef float fs_f4 __attribute__((ext_vector_type(4)));
+typedef float fs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ FsVec4 fs_ld4(const FsVec4 *p, size_t i) {
+    const fs_f4 v = ((FS_GLOBAL const fs_f4 *)p)[i];
+    return FsVec4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void fs_st4(FsVec4 *p, size_t i, const FsVec4 v) {
+    ((FS_GLOBAL fs_f4 *)p)[i] = fs_f4{v.x, v.y, v.z, v.w};
+}
 
 __device__ __forceinline__ int fs_fused_bucket(int cx, int cy, int cz) {
     return (cx & 31) | ((cy & 3) << 5) | ((cz & 31) << 7);
 }
 
+// Scalars of one episode, read once (uniform => SGPRs) so the hot loops never reload them through the descriptor.
+struct FsFusedConsts {
+    int n, substeps, iters, ncap, n_shapes, n_planes;
+    float h, inv_h, g0, g1, g2, damping;
+    float rad2, inv_rad, restd, restd2, mu_p, mu_s, mu_k, cd, relax, maxdv2, maxdv, thr2, max_speed;
+    float pl0, pl1, pl2, pl3;
+};
+
+__device__ __forceinline__ FsFusedConsts fs_fused_consts(const FsEnvDev &E, const FsShapesDev &sh) {
+    const FsParams &p = E.p;
+    FsFusedConsts c;
+    c.n = E.n; c.substeps = p.numSubsteps; c.iters = p.numIterations;
+    c.ncap = p.maxNeighbors < FS_MAX_NEIGHBORS ? p.maxNeighbors : FS_MAX_NEIGHBORS;
+    c.n_shapes = sh.count; c.n_planes = p.numPlanes;
+    c.h = p.dt / (float)p.numSubsteps;
+    c.inv_h = 1.0f / c.h;
+    c.g0 = p.gravity[0]; c.g1 = p.gravity[1]; c.g2 = p.gravity[2]; c.damping = p.damping;
+    const float rad = p.radius + p.particleCollisionMargin;
+    c.rad2 = rad * rad; c.inv_rad = 1.0f / rad;
+    c.restd = p.solidRestDistance; c.restd2 = c.restd * c.restd;
+    c.mu_p = p.particleFriction; c.mu_s = p.staticFriction; c.mu_k = p.dynamicFriction;
+    c.cd = p.collisionDistance; c.relax = p.relaxationFactor;
+    c.maxdv = p.maxAcceleration * c.h; c.maxdv2 = c.maxdv * c.maxdv;
+    c.thr2 = p.sleepThreshold * p.sleepThreshold; c.max_speed = p.maxSpeed;
+    c.pl0 = p.planes[0][0]; c.pl1 = p.planes[0][1]; c.pl2 = p.planes[0][2]; c.pl3 = p.planes[0][3];
+    return c;
+}
+
+// predict one particle (same arithmetic as fs_k_predict)
+__device__ __forceinline__ FsVec4 fs_fused_predict(const FsFusedConsts &c, const FsVec4 pos, const FsVec4 vel) {
+    FsVec4 xp = pos;
+    if (pos.w > 0.0f) {
+        float vx = vel.x + c.h * (c.g0 - c.damping * vel.x);
+        float vy = vel.y + c.h * (c.g1 - c.damping * vel.y);
+        float vz = vel.z + c.h * (c.g2 - c.damping * vel.z);
+        xp.x = pos.x + c.h * vx;
+        xp.y = pos.y + c.h * vy;
+        xp.z = pos.z + c.h * vz;
+    }
+    return xp;
+}
+
+// finalize one particle (same arithmetic as fs_k_finalize)
+__device__ __forceinline__ void fs_fused_finalize(const FsFusedConsts &c, FsVec4 &pos, FsVec4 &vel, const FsVec4 xp) {
+    if (!(pos.w > 0.0f)) {
+        vel = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
+    float vx = (xp.x - pos.x) * c.inv_h, vy = (xp.y - pos.y) * c.inv_h, vz = (xp.z - pos.z) * c.inv_h;
+    float ax = vx - vel.x, ay = vy - vel.y, az = vz - vel.z;
+    float dv2 = ax * ax + ay * ay + az * az;
+    if (dv2 > c.maxdv2) {
+        float sc = c.maxdv / sqrtf(dv2);
+        vx = vel.x + ax * sc; vy = vel.y + ay * sc; vz = vel.z + az * sc;
+    }
+    float v2 = vx * vx + vy * vy + vz * vz;
+    if (c.max_speed < 3.402823466e+38f && v2 > c.max_speed * c.max_speed) {
+        float sc = c.max_speed / sqrtf(v2);
+        vx = vx * sc; vy = vy * sc; vz = vz * sc;
+        v2 = vx * vx + vy * vy + vz * vz;
+    }
+    if (v2 < c.thr2) {
+        vel = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
+        vel = FsVec4{vx, vy, vz, 0.0f};
+        pos.x = xp.x; pos.y = xp.y; pos.z = xp.z;
+    }
+}
+
+// spatial hash of the predicted positions in LDS: histogram -> exclusive scan -> scatter.
+// On return cursor[b] == end of bucket b (start == cursor[b-1]) and items[] holds particle ids grouped by bucket.
+__device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, const FsVec4 (&xp)[FS_FUSED_PPT], int *cursor,
+                                                    unsigned short *items, int *wave_tot) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int bucket[FS_FUSED_PPT];
+#pragma unroll
+    for (int k = 0; k < FS_FUSED_PPT; ++k) {
+        const int i = t + k * FS_FUSED_THREADS;
+        bucket[k] = fs_fused_bucket((int)floorf(xp[k].x * c.inv_rad), (int)floorf(xp[k].y * c.inv_rad),
+                                    (int)floorf(xp[k].z * c.inv_rad));
+        if (i < c.n) atomicAdd(&cursor[bucket[k]], 1);
+    }
+    __syncthreads();
+    {
+        constexpr int PER = FS_FUSED_BUCKETS / FS_FUSED_THREADS;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { loc[k] = cursor[t * PER + k]; sum += loc[k]; }
+        int inc = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { cursor[t * PER + k] = run; run += loc[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FS_FUSED_PPT; ++k) {
+        const int i = t + k * FS_FUSED_THREADS;
+        if (i < c.n) {
+            int slot = atomicAdd(&cursor[bucket[k]], 1);
+            items[slot] = (unsigned short)i;
+        }
+    }
+    __syncthreads();
+}
+
+// particle-contact candidates of particle i (ascending id, the <= ncap smallest); list written slot-major to global
+struct FsFindConsts {  // by value: a reference would force the caller's constants onto the stack
+    int n, ncap;
+    float rad2, inv_rad;
+};
+__device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, const FsVec4 *X,
+                                                       const int *cursor, const unsigned short *items, fs_gci phase,
+                                                       const FsVec4 *rest, fs_gi nlist) {
+    const int n = c.n;
+    const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
+    int cnt = 0, phi = 0;
+    FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+    bool have_meta = false;
+    for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int b = fs_fused_bucket(cx + dx, cy + dy, cz + dz);
+                const int beg = (b == 0) ? 0 : cursor[b - 1];
+                const int end = cursor[b];
+                for (int q = beg; q < end; ++q) {
+                    const int j = items[q];
+                    if (j == i) continue;
+                    const FsVec4 xj = X[j];
+                    float ex = xi.x - xj.x, ey = xi.y - xj.y, ez = xi.z - xj.z;
+                    float d2 = ex * ex + ey * ey + ez * ez;
+                    if (!(d2 < c.rad2)) continue;
+                    // the bucket may alias a far-away cell: require the true cell to be the visited one
+                    if ((int)floorf(xj.x * c.inv_rad) != cx + dx || (int)floorf(xj.y * c.inv_rad) != cy + dy ||
+                        (int)floorf(xj.z * c.inv_rad) != cz + dz)
+                        continue;
+                    if (!have_meta) {
+                        phi = phase[i];
+                        ri = fs_ld4(rest, i);
+                        have_meta = true;
+                    }
+                    const FsVec4 rj = fs_ld4(rest, j);
+                    if (!fs_pair_allowed(phi, phase[j], ri, rj, c.rad2)) continue;
+                    if (cnt == c.ncap) {
+                        if (j > nlist[(size_t)(c.ncap - 1) * n + i]) continue;
+                        cnt = c.ncap - 1;
+                    }
+                    int s = cnt;
+                    while (s > 0) {
+                        int prev = nlist[(size_t)(s - 1) * n + i];
+                        if (prev < j) break;
+                        nlist[(size_t)s * n + i] = prev;
+                        --s;
+                    }
+                    nlist[(size_t)s * n + i] = j;
+                    ++cnt;
+                }
+            }
+    return cnt;
+}
+
+// planes + kinematic spheres for one particle
+__device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedConsts &c, const FsParams &p,
+                                                        const FsShapesDev &sh, int sub, float xi0, float xi1, float xi2,
+                                                        float ri0, float ri1, float ri2) {
+    if (c.n_planes == 1) {
+        fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.pl0, c.pl1, c.pl2, c.pl3, c.cd, c.mu_s, c.mu_k);
+    } else {
+        for (int q = 0; q < c.n_planes; ++q)
+            fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2],
+                             p.planes[q][3], c.cd, c.mu_s, c.mu_k);
+    }
+    const float S = (float)c.substeps;
+    for (int q = 0; q < c.n_shapes; ++q) {
+        float c0, c1, c2, s0, s1, s2;
+        fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
+        fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, c.cd, c.mu_s, c.mu_k);
+    }
+}
+
+// SLOTS > 0: packed (dictionary-coded) adjacency with that many slots (12 or 16); SLOTS == 0: plain ELL adjacency.
+//
+// Register discipline (1024 threads => 128 VGPRs, and every attempt to keep per-particle state of the thread's four
+// particles in registers made hipcc interleave four inlined copies of the body and spill): the particle loop is a
+// ROLLED loop and nothing per-particle survives it in registers.  The current iterate is X (LDS), the new one goes to
+// XN (LDS) and is published after the barrier; the velocity lives in global memory (touched twice per substep); the
+// packed adjacency (2 x SLOTS/2 dwords per particle, shared by all episodes of the same cloth, L2/L1 resident) and the
+// head of the contact-candidate list are fetched one particle ahead of their use.
+template <int SLOTS>
 __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvDev *envs, const FsShapesDev *shapes,
                                                                     const int *ids, int n_steps) {
+    constexpr bool COMPACT = SLOTS > 0;
+    constexpr int JW = COMPACT ? SLOTS / 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     FsVec4 *X = (FsVec4 *)(smem + FS_FUSED_OFF_X);
     float *X0x = (float *)(smem + FS_FUSED_OFF_X0);
     float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
     float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
+    float *XNx = (float *)(smem + FS_FUSED_OFF_XN);
+    float *XNy = XNx + FS_FUSED_MAX_PARTICLES;
+    float *XNz = XNy + FS_FUSED_MAX_PARTICLES;
     int *cursor = (int *)(smem + FS_FUSED_OFF_CUR);
     unsigned short *items = (unsigned short *)(smem + FS_FUSED_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FS_FUSED_OFF_SCAN);
@@ -45,218 +273,161 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     const int e = ids[blockIdx.x];
     const FsEnvDev &E = envs[e];
     const FsShapesDev &sh = shapes[e];
-    const FsParams &p = E.p;
-    const int n = E.n;
+    const FsFusedConsts c = fs_fused_consts(E, sh);
+    const int n = c.n;
+    const unsigned un = (unsigned)n;
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
 
-    const float h = p.dt / (float)p.numSubsteps;
-    const float inv_h = 1.0f / h;
-    const float rad = p.radius + p.particleCollisionMargin;
-    const float rad2 = rad * rad;
-    const float inv_rad = 1.0f / rad;
-    const float restd = p.solidRestDistance, restd2 = restd * restd;
-    const float maxdv = p.maxAcceleration * h;
-    const float thr2 = p.sleepThreshold * p.sleepThreshold;
-    const int ncap = p.maxNeighbors < FS_MAX_NEIGHBORS ? p.maxNeighbors : FS_MAX_NEIGHBORS;
+    FsVec4 *const g_pos = E.pos, *const g_vel = E.vel;
+    const FsVec4 *const g_rest = E.rest;
+    const fs_gci g_phase = (fs_gci)E.phase;
+    const fs_gi g_nlist = (fs_gi)E.nlist, g_ncount = (fs_gi)E.ncount;
+    const fs_gci g_ell_j = (fs_gci)E.ell_j;
+    const fs_gcf g_ell_len = (fs_gcf)E.ell_len, g_ell_k = (fs_gcf)E.ell_k;
+    const fs_gcu g_nbr = (fs_gcu)E.nbr_w, g_code = (fs_gcu)E.code_w;
+    const char FS_GLOBAL *g_dict = (const char FS_GLOBAL *)E.dict;
     const int max_deg = E.max_deg;
 
-    // own particles: i = t + k * 1024
-    FsVec4 pos[FS_FUSED_PPT], vel[FS_FUSED_PPT];
-#pragma unroll
-    for (int k = 0; k < FS_FUSED_PPT; ++k) {
-        const int i = t + k * FS_FUSED_THREADS;
-        if (i < n) {
-            pos[k] = E.pos[i];
-            vel[k] = E.vel[i];
-        } else {
-            pos[k] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
-            vel[k] = pos[k];
-        }
+    // own particles: i = t + k * 1024.  Load positions into X (w = invMass) and X0.
+    for (int i = t; i < n; i += FS_FUSED_THREADS) {
+        const FsVec4 p = fs_ld4(g_pos, i);
+        X[i] = p;
+        X0x[i] = p.x; X0y[i] = p.y; X0z[i] = p.z;
     }
 
-    for (int frame = 0; frame < n_steps; ++frame) {
-        for (int sub = 0; sub < p.numSubsteps; ++sub) {
-            // ---- predict (same arithmetic as fs_k_predict)
-            FsVec4 xp[FS_FUSED_PPT];
-            int ncnt[FS_FUSED_PPT];
-            for (int q = t; q < FS_FUSED_BUCKETS; q += FS_FUSED_THREADS) cursor[q] = 0;
-#pragma unroll
-            for (int k = 0; k < FS_FUSED_PPT; ++k) {
-                const int i = t + k * FS_FUSED_THREADS;
-                xp[k] = pos[k];
-                if (pos[k].w > 0.0f) {
-                    float vx = vel[k].x + h * (p.gravity[0] - p.damping * vel[k].x);
-                    float vy = vel[k].y + h * (p.gravity[1] - p.damping * vel[k].y);
-                    float vz = vel[k].z + h * (p.gravity[2] - p.damping * vel[k].z);
-                    xp[k].x = pos[k].x + h * vx;
-                    xp[k].y = pos[k].y + h * vy;
-                    xp[k].z = pos[k].z + h * vz;
-                }
-                if (i < n) {
-                    X[i] = xp[k];
-                    X0x[i] = pos[k].x; X0y[i] = pos[k].y; X0z[i] = pos[k].z;
-                }
-            }
-            __syncthreads();
-            // ---- spatial hash in LDS: histogram -> exclusive scan -> scatter
-            int bucket[FS_FUSED_PPT];
-#pragma unroll
-            for (int k = 0; k < FS_FUSED_PPT; ++k) {
-                const int i = t + k * FS_FUSED_THREADS;
-                bucket[k] = fs_fused_bucket((int)floorf(xp[k].x * inv_rad), (int)floorf(xp[k].y * inv_rad),
-                                            (int)floorf(xp[k].z * inv_rad));
-                if (i < n) atomicAdd(&cursor[bucket[k]], 1);
-            }
-            __syncthreads();
-            {
-                constexpr int PER = FS_FUSED_BUCKETS / FS_FUSED_THREADS;
-                int loc[PER], sum = 0;
-#pragma unroll
-                for (int k = 0; k < PER; ++k) { loc[k] = cursor[t * PER + k]; sum += loc[k]; }
-                int inc = sum;
-                for (int off = 1; off < 64; off <<= 1) {
-                    int o = __shfl_up(inc, off, 64);
-                    if (lane >= off) inc += o;
-                }
-                if (lane == 63) wave_tot[wave] = inc;
-                __syncthreads();
-                int run = inc - sum;
-                for (int w = 0; w < wave; ++w) run += wave_tot[w];
-#pragma unroll
-                for (int k = 0; k < PER; ++k) { cursor[t * PER + k] = run; run += loc[k]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < FS_FUSED_PPT; ++k) {
-                const int i = t + k * FS_FUSED_THREADS;
-                if (i < n) {
-                    int slot = atomicAdd(&cursor[bucket[k]], 1);
-                    items[slot] = (unsigned short)i;
-                }
-            }
-            __syncthreads();
-            // ---- particle-contact candidates (ascending id, <= 96 smallest), lists live in global memory
 #pragma unroll 1
+    for (int frame = 0; frame < n_steps; ++frame) {
+#pragma unroll 1
+        for (int sub = 0; sub < c.substeps; ++sub) {
+            // ---- predict from (X0, vel) into X; build the spatial hash (aliases XN, which is idle here)
+            for (int q = t; q < FS_FUSED_BUCKETS; q += FS_FUSED_THREADS) cursor[q] = 0;
+            FsVec4 xp[FS_FUSED_PPT];
+#pragma unroll
             for (int k = 0; k < FS_FUSED_PPT; ++k) {
                 const int i = t + k * FS_FUSED_THREADS;
-                int cnt = 0;
+                xp[k] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
                 if (i < n) {
-                    const FsVec4 xi = xp[k];
-                    const int cx = (int)floorf(xi.x * inv_rad), cy = (int)floorf(xi.y * inv_rad),
-                              cz = (int)floorf(xi.z * inv_rad);
-                    int phi = 0;
-                    FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
-                    bool have_meta = false;
-                    for (int dz = -1; dz <= 1; ++dz)
-                        for (int dy = -1; dy <= 1; ++dy)
-                            for (int dx = -1; dx <= 1; ++dx) {
-                                const int b = fs_fused_bucket(cx + dx, cy + dy, cz + dz);
-                                const int beg = (b == 0) ? 0 : cursor[b - 1];
-                                const int end = cursor[b];
-                                for (int q = beg; q < end; ++q) {
-                                    const int j = items[q];
-                                    if (j == i) continue;
-                                    const FsVec4 xj = X[j];
-                                    float ex = xi.x - xj.x, ey = xi.y - xj.y, ez = xi.z - xj.z;
-                                    float d2 = ex * ex + ey * ey + ez * ez;
-                                    if (!(d2 < rad2)) continue;
-                                    if ((int)floorf(xj.x * inv_rad) != cx + dx || (int)floorf(xj.y * inv_rad) != cy + dy ||
-                                        (int)floorf(xj.z * inv_rad) != cz + dz)
-                                        continue;
-                                    if (!have_meta) { phi = E.phase[i]; ri = E.rest[i]; have_meta = true; }
-                                    if (!fs_pair_allowed(phi, E.phase[j], ri, E.rest[j], rad2)) continue;
-                                    if (cnt == ncap) {
-                                        if (j > E.nlist[(size_t)(ncap - 1) * n + i]) continue;
-                                        cnt = ncap - 1;
-                                    }
-                                    int s = cnt;
-                                    while (s > 0) {
-                                        int prev = E.nlist[(size_t)(s - 1) * n + i];
-                                        if (prev < j) break;
-                                        E.nlist[(size_t)s * n + i] = prev;
-                                        --s;
-                                    }
-                                    E.nlist[(size_t)s * n + i] = j;
-                                    ++cnt;
-                                }
-                            }
-                    E.ncount[i] = cnt;
+                    const FsVec4 p0 = FsVec4{X0x[i], X0y[i], X0z[i], X[i].w};
+                    xp[k] = fs_fused_predict(c, p0, fs_ld4(g_vel, i));
+                    X[i] = xp[k];
                 }
-                ncnt[k] = cnt;
             }
-            // (no barrier needed: the iterations only read X / X0, which are stable since the predict barrier)
+            __syncthreads();
+            fs_fused_build_grid(c, xp, cursor, items, wave_tot);
+            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad};
+#pragma unroll 1
+            for (int i = t; i < n; i += FS_FUSED_THREADS)
+                g_ncount[i] = fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist);
+            __syncthreads();  // the hash is dead from here on: its LDS becomes XN
 
-            // ---- Jacobi iterations: gather from LDS, compute in registers, barrier, publish, barrier
-            for (int it = 0; it < p.numIterations; ++it) {
+            // ---- Jacobi iterations: X -> XN, barrier, publish XN -> X, barrier
+#pragma unroll 1
+            for (int it = 0; it < c.iters; ++it) {
+                // software pipeline over the thread's particles: adjacency words / candidate head of particle k+1 are
+                // requested before particle k is computed
+                uint32_t jw[JW], cw[JW];
+                int cnt = 0, cj[FS_FUSED_PREFETCH_CAND];
+                {
+                    unsigned i0 = t < n ? (unsigned)t : 0u;
+                    asm volatile("" : "+v"(i0));  // keep these iteration-invariant loads inside the loop
+                    if (COMPACT) {
 #pragma unroll
-                for (int k = 0; k < FS_FUSED_PPT; ++k) {
-                    const int i = t + k * FS_FUSED_THREADS;
-                    if (i < n && xp[k].w > 0.0f) {
-                        FsAcc a = {0.0f, 0.0f, 0.0f, 0};
-                        const float xi0 = xp[k].x, xi1 = xp[k].y, xi2 = xp[k].z, wi = xp[k].w;
-                        for (int s = 0; s < max_deg; ++s) {
-                            const int j = E.ell_j[(size_t)s * n + i];
-                            if (j < 0) break;
-                            fs_spring(a, xi0, xi1, xi2, wi, X[j], E.ell_len[(size_t)s * n + i], E.ell_k[(size_t)s * n + i]);
+                        for (int q = 0; q < JW; ++q) { jw[q] = g_nbr[(unsigned)q * un + i0]; cw[q] = g_code[(unsigned)q * un + i0]; }
+                    }
+                    cnt = g_ncount[i0];
+#pragma unroll
+                    for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = g_nlist[(unsigned)q * un + i0];
+                }
+#pragma unroll 1
+                for (int i = t; i < n; i += FS_FUSED_THREADS) {
+                    uint32_t jw_n[JW], cw_n[JW];
+                    int cnt_n, cj_n[FS_FUSED_PREFETCH_CAND];
+                    {
+                        unsigned in = i + FS_FUSED_THREADS < n ? (unsigned)(i + FS_FUSED_THREADS) : (unsigned)i;
+                        if (COMPACT) {
+#pragma unroll
+                            for (int q = 0; q < JW; ++q) { jw_n[q] = g_nbr[(unsigned)q * un + in]; cw_n[q] = g_code[(unsigned)q * un + in]; }
                         }
-                        const float ri0 = xi0 - pos[k].x, ri1 = xi1 - pos[k].y, ri2 = xi2 - pos[k].z;
-                        for (int s = 0; s < ncnt[k]; ++s) {
-                            const int j = E.nlist[(size_t)s * n + i];
+                        cnt_n = g_ncount[in];
+#pragma unroll
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
+                    }
+                    const FsVec4 xi = X[i];
+                    float nx = xi.x, ny = xi.y, nz = xi.z;
+                    if (xi.w > 0.0f) {
+                        FsAcc a = {0.0f, 0.0f, 0.0f, 0};
+                        const float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z, wi = xi.w;
+                        if (COMPACT) {
+                            // one spring per scheduling region; the LDS gather and dictionary fetch of spring s+1 are
+                            // issued in front of the arithmetic of spring s
+                            FsVec4 xj = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + (jw[0] & 0xffffu));
+                            fs_f2 lk = *(const fs_f2 FS_GLOBAL *)(g_dict + (cw[0] & 0xffffu));
+#pragma unroll
+                            for (int s = 0; s < SLOTS; ++s) {
+                                FsVec4 xj_next = xj;
+                                fs_f2 lk_next = lk;
+                                if (s + 1 < SLOTS) {
+                                    const uint32_t joff = (jw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
+                                    const uint32_t coff = (cw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
+                                    xj_next = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + joff);
+                                    lk_next = *(const fs_f2 FS_GLOBAL *)(g_dict + coff);
+                                }
+                                fs_spring_bf(a, xi0, xi1, xi2, wi, xj, lk.x, lk.y);
+                                __builtin_amdgcn_sched_barrier(0);
+                                xj = xj_next;
+                                lk = lk_next;
+                            }
+                        } else {
+                            for (int s = 0; s < max_deg; ++s) {
+                                const int j = g_ell_j[(unsigned)s * un + (unsigned)i];
+                                if (j < 0) break;
+                                fs_spring(a, xi0, xi1, xi2, wi, X[j], g_ell_len[(unsigned)s * un + (unsigned)i],
+                                          g_ell_k[(unsigned)s * un + (unsigned)i]);
+                            }
+                        }
+                        const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
+                        for (int s = 0; s < cnt; ++s) {
+                            int j;
+                            if (s < FS_FUSED_PREFETCH_CAND) {
+                                j = cj[0];
+#pragma unroll
+                                for (int q = 0; q + 1 < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj[q + 1];
+                            } else {
+                                j = g_nlist[(unsigned)s * un + (unsigned)i];
+                            }
                             const FsVec4 xj = X[j];
                             fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
-                                                xj.z - X0z[j], restd, restd2, p.particleFriction);
+                                                xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
                         }
-                        fs_shape_contacts(a, xi0, xi1, xi2, ri0, ri1, ri2, p, sh, sub);
-                        fs_apply(a, p.relaxationFactor, xp[k].x, xp[k].y, xp[k].z);
+                        fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                        fs_apply(a, c.relax, nx, ny, nz);
                     }
+                    XNx[i] = nx; XNy[i] = ny; XNz[i] = nz;
+                    if (COMPACT) {
+#pragma unroll
+                        for (int q = 0; q < JW; ++q) { jw[q] = jw_n[q]; cw[q] = cw_n[q]; }
+                    }
+                    cnt = cnt_n;
+#pragma unroll
+                    for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj_n[q];
                 }
                 __syncthreads();
-#pragma unroll
-                for (int k = 0; k < FS_FUSED_PPT; ++k) {
-                    const int i = t + k * FS_FUSED_THREADS;
-                    if (i < n) X[i] = xp[k];
+                for (int i = t; i < n; i += FS_FUSED_THREADS) {
+                    X[i].x = XNx[i]; X[i].y = XNy[i]; X[i].z = XNz[i];
                 }
                 __syncthreads();
             }
-
-            // ---- finalize (same arithmetic as fs_k_finalize)
-#pragma unroll
-            for (int k = 0; k < FS_FUSED_PPT; ++k) {
-                if (!(pos[k].w > 0.0f)) {
-                    vel[k] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
-                    continue;
-                }
-                float vx = (xp[k].x - pos[k].x) * inv_h, vy = (xp[k].y - pos[k].y) * inv_h, vz = (xp[k].z - pos[k].z) * inv_h;
-                float ax = vx - vel[k].x, ay = vy - vel[k].y, az = vz - vel[k].z;
-                float dv2 = ax * ax + ay * ay + az * az;
-                if (dv2 > maxdv * maxdv) {
-                    float sc = maxdv / sqrtf(dv2);
-                    vx = vel[k].x + ax * sc; vy = vel[k].y + ay * sc; vz = vel[k].z + az * sc;
-                }
-                float v2 = vx * vx + vy * vy + vz * vz;
-                if (p.maxSpeed < 3.402823466e+38f && v2 > p.maxSpeed * p.maxSpeed) {
-                    float sc = p.maxSpeed / sqrtf(v2);
-                    vx = vx * sc; vy = vy * sc; vz = vz * sc;
-                    v2 = vx * vx + vy * vy + vz * vz;
-                }
-                if (v2 < thr2) {
-                    vel[k] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
-                } else {
-                    vel[k] = FsVec4{vx, vy, vz, 0.0f};
-                    pos[k].x = xp[k].x; pos[k].y = xp[k].y; pos[k].z = xp[k].z;
-                }
+            // ---- finalize: new velocity to global, new substep-start position into X0 (own entries only; every other
+            //      thread is past the last iteration barrier and reads X0 again only after the next predict barrier)
+            for (int i = t; i < n; i += FS_FUSED_THREADS) {
+                const FsVec4 xf = X[i];
+                FsVec4 p0 = FsVec4{X0x[i], X0y[i], X0z[i], xf.w};
+                FsVec4 v = fs_ld4(g_vel, i);
+                fs_fused_finalize(c, p0, v, xf);
+                fs_st4(g_vel, i, v);
+                X0x[i] = p0.x; X0y[i] = p0.y; X0z[i] = p0.z;
             }
-            // next substep's predict overwrites X / X0 only after every thread left the last iteration barrier
         }
     }
-
-#pragma unroll
-    for (int k = 0; k < FS_FUSED_PPT; ++k) {
-        const int i = t + k * FS_FUSED_THREADS;
-        if (i < n) {
-            E.pos[i] = pos[k];
-            E.vel[i] = vel[k];
-        }
-    }
+    for (int i = t; i < n; i += FS_FUSED_THREADS) fs_st4(g_pos, i, FsVec4{X0x[i], X0y[i], X0z[i], X[i].w});
 }

@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace {
 
@@ -145,6 +146,46 @@ void build_adjacency(FsHostScene &s) {
         }
 }
 
+void build_compact_adjacency(FsHostScene &s) {
+    s.dict_size = 0;
+    s.dict.assign(512, 0.0f);
+    s.code_w.clear();
+    s.nbr_w.clear();
+    const int n = s.n;
+    if (s.max_deg > 16 || n > 4096) return;  // offsets must fit 16 bits: 4095 * 16 = 65520
+    std::vector<std::pair<uint32_t, uint32_t>> entries;  // bit patterns of (len, k)
+    std::vector<uint8_t> codes(size_t(16) * n, 0);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    for (int i = 0; i < n; ++i)
+        for (int a = s.adj_off[i]; a < s.adj_off[i + 1]; ++a) {
+            std::pair<uint32_t, uint32_t> key(bits(s.adj_len[a]), bits(s.adj_k[a]));
+            size_t c = 0;
+            for (; c < entries.size(); ++c)
+                if (entries[c] == key) break;
+            if (c == entries.size()) {
+                if (entries.size() == 256) return;  // too many distinct springs: compact form unavailable
+                entries.push_back(key);
+                s.dict[2 * c] = s.adj_len[a];
+                s.dict[2 * c + 1] = s.adj_k[a];
+            }
+            codes[size_t(a - s.adj_off[i]) * n + i] = uint8_t(c);
+        }
+    // 16-bit fields, two per word, already scaled to LDS byte offsets: neighbour id * 16 (float4 array) and
+    // dictionary code * 8 (float2 array)
+    s.code_w.assign(size_t(8) * n, 0u);
+    s.nbr_w.assign(size_t(8) * n, 0u);
+    for (int i = 0; i < n; ++i) {
+        const int deg = s.adj_off[i + 1] - s.adj_off[i];
+        for (int slot = 0; slot < 16; ++slot) {
+            const uint32_t j = slot < deg ? uint32_t(s.adj_j[s.adj_off[i] + slot]) : uint32_t(i);
+            const uint32_t c = slot < deg ? codes[size_t(slot) * n + i] : 0u;
+            s.code_w[size_t(slot / 2) * n + i] |= ((c * 8u) & 0xffffu) << (16 * (slot % 2));
+            s.nbr_w[size_t(slot / 2) * n + i] |= ((j * 16u) & 0xffffu) << (16 * (slot % 2));
+        }
+    }
+    s.dict_size = int(entries.size());
+}
+
 void build_vertex_triangles(FsHostScene &s) {
     s.vt_off.assign(size_t(s.n) + 1, 0);
     for (size_t c = 0; c < s.tris.size(); ++c) s.vt_off[size_t(s.tris[c]) + 1]++;
@@ -246,6 +287,7 @@ std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const 
     p.planes[0][0] = 0.0f; p.planes[0][1] = 1.0f; p.planes[0][2] = 0.0f; p.planes[0][3] = 0.0f;
 
     build_adjacency(s);
+    build_compact_adjacency(s);
     build_vertex_triangles(s);
     return "";
 }

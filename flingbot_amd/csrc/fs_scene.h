@@ -6,6 +6,8 @@
 //   CreateSpring              PyFlex/bindings/helpers.h:144-150
 //   Init (defaults, derived params, bounds, normals, rest pose)  PyFlex/bindings/main.cpp:613-1122
 #pragma once
+#include <stdint.h>
+
 #include <string>
 #include <vector>
 
@@ -32,6 +34,14 @@ struct FsHostScene {
     std::vector<float> adj_len, adj_k;
     std::vector<int> ell_j;
     std::vector<float> ell_len, ell_k;
+    // compact adjacency for the fused kernel: distinct (rest length, stiffness) pairs form a dictionary (<= 256
+    // entries, else dict_size = 0); per particle 16 slots of two 16-bit fields (packed 2 per word, [8][n] each):
+    // dictionary code * 8 and neighbour id * 16, i.e. ready-made LDS byte offsets.  Empty slots point at the
+    // particle itself (zero length => no-op).
+    int dict_size = 0;
+    std::vector<float> dict;        // 2 * 256: (len, k) pairs
+    std::vector<uint32_t> code_w;   // [8][n]
+    std::vector<uint32_t> nbr_w;    // [8][n]
     // vertex -> incident triangles (ascending triangle id), for the vertex-normal gather
     std::vector<int> vt_off, vt_tri;
 };

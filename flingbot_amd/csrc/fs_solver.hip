@@ -64,12 +64,31 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
     if (rc != FS_OK) return rc;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<12>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    FS_FUSED_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    FS_FUSED_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     FS_FUSED_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(fs_k_fused_step, dim3((unsigned)ids.size()), dim3(FS_FUSED_THREADS), FS_FUSED_LDS_BYTES, ctx->stream,
-                       ctx->d_envs, ctx->d_shapes, ctx->d_ids, n_steps);
+    // register-resident (dictionary-coded) adjacency when every episode of the launch has one
+    int slots = ctx->force_generic_fused ? 0 : 12;
+    for (int id : ids) {
+        const FsEnv &e = ctx->envs[id];
+        if (e.dev.dict_size <= 0 || e.host.max_deg > 16) slots = 0;
+        else if (e.host.max_deg > 12 && slots == 12) slots = 16;
+    }
+    const dim3 grid((unsigned)ids.size()), block(FS_FUSED_THREADS);
+    if (slots == 12)
+        hipLaunchKernelGGL(fs_k_fused_step<12>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
+                           ctx->d_ids, n_steps);
+    else if (slots == 16)
+        hipLaunchKernelGGL(fs_k_fused_step<16>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
+                           ctx->d_ids, n_steps);
+    else
+        hipLaunchKernelGGL(fs_k_fused_step<0>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
+                           ctx->d_ids, n_steps);
     HIP_TRY(hipGetLastError());
     return FS_OK;
 }

@@ -72,5 +72,11 @@ struct FsEnvDev {
     const int *ell_j;
     const float *ell_len;
     const float *ell_k;
+    // compact adjacency (fused kernel): dictionary of distinct (len, k) pairs + packed codes / neighbour ids
+    int dict_size;           // 0 = unavailable
+    int pad0;
+    const float *dict;       // [256][2]
+    const uint32_t *code_w;  // [8][n]
+    const uint32_t *nbr_w;   // [8][n]
     FsParams p;
 };

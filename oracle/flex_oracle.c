@@ -392,12 +392,30 @@ static void find_neighbors(orc_sim *s) {
     }
 }
 
-/* friction on a contact: t = tangential relative displacement since substep start, pen = penetration depth.
-   [I] Macklin 2014 section 6.1: full stick below mu_s*pen, else scaled by min(mu_k*pen/|t|, 1).  Returns scale. */
-static inline float friction_scale(float tl, float pen, float mu_s, float mu_k) {
+/* Reciprocal square root used for every length inside the constraint sweeps: classic integer seed + three Newton
+   steps, i.e. a fixed sequence of IEEE fp32 multiplies / subtracts (max error 2.5 ulp).  [I] The closed-source
+   reference certainly uses a hardware approximation here; spelling the approximation out in basic IEEE operations
+   makes the result a pure function of add/mul, identical on the CPU and on the GPU without libm or divide sequences. */
+#include <stdint.h>
+static inline float orc_rsqrt(float x) {
+    union { float f; uint32_t u; } v;
+    v.f = x;
+    v.u = 0x5f3759dfu - (v.u >> 1);
+    float y = v.f;
+    const float xh = 0.5f * x;
+    y = y * (1.5f - (xh * y) * y);
+    y = y * (1.5f - (xh * y) * y);
+    y = y * (1.5f - (xh * y) * y);
+    return y;
+}
+
+/* friction on a contact: t = tangential relative displacement since substep start (length tl = tl2 * inv_tl),
+   pen = penetration depth.  [I] Macklin 2014 section 6.1: full stick below mu_s*pen, else scaled by
+   min(mu_k*pen/|t|, 1).  Returns the scale applied to t. */
+static inline float friction_scale(float tl, float inv_tl, float pen, float mu_s, float mu_k) {
     if (tl < mu_s * pen) return 1.0f;
     float lim = mu_k * pen;
-    return (tl > lim) ? lim / tl : 1.0f;
+    return (tl > lim) ? lim * inv_tl : 1.0f;
 }
 
 static void substep(orc_sim *s, int sub, float h, float inv_h) {
@@ -456,13 +474,14 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 const float wj = xp[4 * j + 3];
                 float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
                 float l2 = ex * ex + ey * ey + ez * ez;
-                float len = sqrtf(l2);
+                float inv_len = orc_rsqrt(l2);
+                float len = l2 * inv_len;
                 if (!(len > 0.0f)) continue;
                 float C = len - s->slen[e];
                 float k = s->sk[e];
                 if (k < 0.0f) { if (!(C > 0.0f)) continue; k = -k; } /* tether: unilateral */
                 float ratio = wi / (wi + wj);
-                float sc_ = (k * ratio) * (C / len);
+                float sc_ = (k * ratio) * (C * inv_len);
                 d0 = d0 - ex * sc_; d1 = d1 - ey * sc_; d2 = d2 - ez * sc_;
                 cnt++;
             }
@@ -474,9 +493,10 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
                 float l2 = ex * ex + ey * ey + ez * ez;
                 if (!(l2 < restd2)) continue;
-                float dist = sqrtf(l2);
+                float inv = orc_rsqrt(l2);
+                float dist = l2 * inv;
                 float nx, ny, nz;
-                if (dist > 0.0f) { float inv = 1.0f / dist; nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                if (dist > 0.0f) { nx = ex * inv; ny = ey * inv; nz = ez * inv; }
                 else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
                 float pen = restd - dist;
                 float ratio = wi / (wi + wj);
@@ -490,8 +510,9 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                     float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
                     float tl2 = tx * tx + ty * ty + tz * tz;
                     if (tl2 > 0.0f) {
-                        float tl = sqrtf(tl2);
-                        float fs = friction_scale(tl, pen, p->particleFriction, p->particleFriction) * ratio;
+                        float inv_tl = orc_rsqrt(tl2);
+                        float tl = tl2 * inv_tl;
+                        float fs = friction_scale(tl, inv_tl, pen, p->particleFriction, p->particleFriction) * ratio;
                         c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
                     }
                 }
@@ -509,8 +530,9 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float tx = ri0 - pl[0] * rn, ty = ri1 - pl[1] * rn, tz = ri2 - pl[2] * rn;
                 float tl2 = tx * tx + ty * ty + tz * tz;
                 if (tl2 > 0.0f) {
-                    float tl = sqrtf(tl2);
-                    float fs = friction_scale(tl, pen, p->staticFriction, p->dynamicFriction);
+                    float inv_tl = orc_rsqrt(tl2);
+                    float tl = tl2 * inv_tl;
+                    float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
                     c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
@@ -522,9 +544,10 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float l2 = ex * ex + ey * ey + ez * ez;
                 float lim = s->sh_radius[q] + cd;
                 if (!(l2 < lim * lim)) continue;
-                float dist = sqrtf(l2);
+                float inv = orc_rsqrt(l2);
+                float dist = l2 * inv;
                 float nx, ny, nz;
-                if (dist > 0.0f) { float inv = 1.0f / dist; nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                if (dist > 0.0f) { nx = ex * inv; ny = ey * inv; nz = ez * inv; }
                 else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
                 float pen = lim - dist;
                 float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
@@ -533,8 +556,9 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
                 float tl2 = tx * tx + ty * ty + tz * tz;
                 if (tl2 > 0.0f) {
-                    float tl = sqrtf(tl2);
-                    float fs = friction_scale(tl, pen, p->staticFriction, p->dynamicFriction);
+                    float inv_tl = orc_rsqrt(tl2);
+                    float tl = tl2 * inv_tl;
+                    float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
                     c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
