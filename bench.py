@@ -106,32 +106,25 @@ def main():
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from flingbot_amd import distributed as fdist
+    from flingbot_amd import sim as fsim
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from flingbot_amd import sim as fsim
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, local_rank, world = fdist.init_from_env("nccl")  # one process per GPU; "nccl" is RCCL on ROCm
 
     E = args.episodes
     ctx = fsim.FlingSim(n_envs=E, device=local_rank, solver=args.solver)
-    for e in range(E):
-        setup_episode(ctx.env(e), seed=rank * E + e)  # episode e of rank r == global episode r*E + e
+    for e, g in enumerate(fdist.episode_range(rank, E)):
+        setup_episode(ctx.env(e), seed=g)  # global episode id = seed
     ctx.sync()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        fdist.barrier()
         ctx.sync()
         torch.cuda.synchronize()
 
@@ -144,19 +137,9 @@ def main():
         ctx.step(1)                        # one launch of the fused kernel: every episode advances one frame
     kern_ms_total = ctx.timer_stop()
     # episode-batch gather of the coverage rewards (the only exchange step of the path)
-    cov = torch.from_numpy(ctx.coverage()).to(torch.float32).cuda()
-    if dist is not None:
-        allcov = [torch.empty_like(cov) for _ in range(world)]
-        dist.all_gather(allcov, cov)
-        cov_all = torch.cat(allcov)
-    else:
-        cov_all = cov
+    cov_all = fdist.gather_rewards(ctx.coverage(), device="cuda")
     barrier()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = fdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
 
     if rank == 0:
         total_steps = E * world * args.steps
@@ -192,9 +175,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.warmup)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    fdist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
     ctx.close()
 
 

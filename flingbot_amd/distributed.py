@@ -1,0 +1,62 @@
+"""Episode sharding across GPUs: one process per GPU, episodes never communicate.
+
+The reference parallelises with one Ray actor process per environment and fractional GPU shares (utils.py:144-157); here
+each rank owns one MI355X and a batch of episodes (global episode g lives on rank g // episodes_per_rank).  The only
+exchange step of the path is the episode-batch gather of the per-episode coverage rewards (RCCL all_gather over xGMI
+with the "nccl" backend; "gloo" in the CPU tests): 4 bytes per episode, latency bound, once per action -- never per
+sim step.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns
+    (rank, local_rank, world).  World size 1 needs no process group."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, local_rank, world
+
+
+def episode_range(rank, episodes_per_rank):
+    """Global episode ids owned by `rank` (weak scaling: the per-rank batch is fixed)."""
+    return range(rank * episodes_per_rank, (rank + 1) * episodes_per_rank)
+
+
+def gather_rewards(local_rewards, device=None):
+    """all_gather of the per-episode rewards of every rank -> 1-D float32 tensor ordered by global episode id."""
+    t = torch.as_tensor(local_rewards, dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return torch.cat(parts)
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of a python float (the bench's timed-region length)."""
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,273 @@
+"""Value-map networks and the rotate/scale observation stack, with the module surface of the reference's
+learning/nets.py (BasicBlock :12, ResidualBlock :44, SpatialValueNet :81, crop_center :144, pad :150, transform :155,
+prepare_image :180, Policy :196, MaximumValuePolicy :232) so that `flingbot.pth` checkpoints load unchanged
+(state_dict keys: SURVEY.md 8b) and callers (run_sim.py, environment/simEnv.py) keep working.
+
+MI355X notes: the CNN is 18 3x3 convolutions with 16 channels on 64x64 maps -- memory/launch bound, so the forward
+runs channels-last on PyTorch-ROCm (MIOpen -> MFMA) with eval-mode BatchNorm folded into the convolutions
+(`SpatialValueNet.fold_batchnorm`), and `MaximumValuePolicy.act` batches all environments into ONE forward instead of
+looping per environment (nets.py:228-229).  cv2 / ray are not needed: padding and nearest resize are restated with
+numpy following OpenCV's conventions (BORDER_REPLICATE; INTER_NEAREST source index = floor(dst * src/dst)).
+"""
+import random
+from time import time
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+from scipy import ndimage as nd
+
+
+class BasicBlock(nn.Module):
+    """conv3x3 (no bias) [+ BatchNorm + non-linearity]; sub-module name `net` is part of the checkpoint layout."""
+
+    def __init__(self, inplanes, planes, kernel_size, stride, padding=1, norm_layer=None, non_linearity=nn.LeakyReLU):
+        super().__init__()
+        layers = [nn.Conv2d(inplanes, planes, kernel_size=kernel_size, stride=stride, padding=padding, bias=False)]
+        if non_linearity is not None:
+            layers += [nn.BatchNorm2d(planes), non_linearity()]
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, input):
+        return self.net(input)
+
+
+class ResidualBlock(nn.Module):
+    """y = relu(bn2(conv2(relu(bn1(conv1(x))))) + x); attribute names conv1/bn1/relu/conv2/bn2 are checkpoint keys."""
+
+    def __init__(self, inplanes, planes, kernel_size, stride, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.planes = planes
+        self.stride = stride
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=kernel_size, stride=stride, padding=1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=kernel_size, stride=stride, padding=1, bias=False)
+        self.bn2 = norm_layer(planes)
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out = out + x
+        return self.relu(out)
+
+
+class SpatialValueNet(nn.Module):
+    def __init__(self, rgb_only=False, depth_only=False, steps=0, device='cuda', **kwargs):
+        super().__init__()
+        self.device = device
+        self.rgb_only = rgb_only
+        self.depth_only = depth_only
+        self.input_channels = 3 if rgb_only else (1 if depth_only else 4)
+        self.net = self.setup_net()
+        mean = torch.tensor([0.18, 0.18, 0.18, 1.99])
+        std = torch.tensor([0.1, 0.1, 0.1, 0.006])
+        if rgb_only:
+            mean, std = mean[:3], std[:3]
+        elif depth_only:
+            mean, std = mean[3], std[3]
+        self.mean, self.std = mean, std  # plain attributes, not buffers: they are not in the reference's state_dict
+        self.steps = nn.parameter.Parameter(torch.tensor(steps), requires_grad=False)
+        self._folded = None
+
+    def setup_net(self):
+        blocks = [BasicBlock(self.input_channels, 16, 3, 1)]
+        blocks += [ResidualBlock(16, 16, 3, 1) for _ in range(8)]
+        blocks += [BasicBlock(16, 1, 3, 1, non_linearity=None)]
+        return nn.Sequential(*blocks)
+
+    def preprocess_obs(self, obs):
+        assert obs.dim() == 4
+        c = obs.shape[1]
+        if self.rgb_only:
+            if c == 4:
+                obs = obs[:, :3]
+            elif c != 3:
+                raise Exception
+        elif self.depth_only:
+            obs = obs[:, 3:4] if c == 4 else obs.squeeze().unsqueeze(dim=-3)
+        mean = self.mean.to(obs.device).reshape(1, -1, 1, 1)
+        std = self.std.to(obs.device).reshape(1, -1, 1, 1)
+        return (obs - mean) / std
+
+    def forward(self, obs):
+        if self._folded is not None and not self.training:
+            return self._folded(self.preprocess_obs(obs).contiguous(memory_format=torch.channels_last))
+        return self.net(self.preprocess_obs(obs))
+
+    # ---- inference fast path -------------------------------------------------------------------------------------
+    def fold_batchnorm(self):
+        """Build an eval-only copy of `net` with every BatchNorm folded into the preceding convolution
+        (w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)) in channels-last layout.
+        18 conv + 17 BN + activations become 18 conv(+bias) launches.  The parameters of `net` are untouched, so
+        state_dict() keeps the reference layout."""
+        self.eval()
+
+        def fold(conv, bn):
+            out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=True)
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            out.weight.data = conv.weight.data * scale.reshape(-1, 1, 1, 1)
+            out.bias.data = bn.bias.data - bn.running_mean * scale
+            return out
+
+        class FoldedResidual(nn.Module):
+            def __init__(self, blk):
+                super().__init__()
+                self.c1, self.c2 = fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2)
+
+            def forward(self, x):
+                return torch.relu(self.c2(torch.relu(self.c1(x))) + x)
+
+        first, last = self.net[0].net, self.net[-1].net
+        layers = [fold(first[0], first[1]), type(first[2])()]
+        layers += [FoldedResidual(b) for b in list(self.net)[1:-1]]
+        tail = nn.Conv2d(last[0].in_channels, last[0].out_channels, 3, 1, 1, bias=False)
+        tail.weight.data = last[0].weight.data.clone()
+        layers.append(tail)
+        folded = nn.Sequential(*layers).to(next(self.net.parameters()).device).eval()
+        folded = folded.to(memory_format=torch.channels_last)
+        for p in folded.parameters():
+            p.requires_grad_(False)
+        object.__setattr__(self, '_folded', folded)  # not registered: keeps state_dict identical to the reference
+        return self
+
+
+def crop_center(img, crop):
+    startx = img.shape[1] // 2 - (crop // 2)
+    starty = img.shape[0] // 2 - (crop // 2)
+    return img[starty:starty + crop, startx:startx + crop, ...]
+
+
+def pad(img, size):
+    """cv2.copyMakeBorder(img, n, n, n, n, BORDER_REPLICATE) with n = (size - h) // 2 (nets.py:150-152)."""
+    n = (size - img.shape[0]) // 2
+    widths = [(n, n), (n, n)] + [(0, 0)] * (img.ndim - 2)
+    return np.pad(img, widths, mode='edge')
+
+
+def resize_nearest(img, dim):
+    """cv2.resize(img, (dim, dim), interpolation=INTER_NEAREST): source index = floor(dst * src / dst_size)."""
+    h, w = img.shape[:2]
+    ys = np.minimum((np.arange(dim) * (h / dim)).astype(np.int64), h - 1)
+    xs = np.minimum((np.arange(dim) * (w / dim)).astype(np.int64), w - 1)
+    return img[ys][:, xs]
+
+
+def transform(img, rotation: float, scale: float, dim: int):
+    """One rotated / scaled copy of the observation (nets.py:155-174): (C,H,W) tensor -> (W,H,C) array, cubic-spline
+    rotation about the image centre (scipy.ndimage.rotate, reshape=False, mode='nearest'), centre crop (scale < 1) or
+    replicate pad (scale > 1) to int(scale * size), nearest resize to dim x dim, back to channel-first."""
+    if len(img.shape) == 3 and (img.shape[-1] == img.shape[-2]):
+        img = img.permute(2, 1, 0)
+    img = nd.rotate(input=img, angle=rotation, reshape=False, mode='nearest')
+    new_dim = int(scale * img.shape[0])
+    if scale < 1:
+        img = crop_center(img, new_dim)
+    elif scale > 1:
+        img = pad(img, new_dim)
+    img = resize_nearest(img, dim)
+    if len(img.shape) == 3:
+        img = img.swapaxes(-1, 0)
+    return torch.tensor(np.ascontiguousarray(img))
+
+
+def transform_async(*args, **kwargs):
+    """The reference wraps `transform` in ray.remote; without ray this is the same function run inline."""
+    return transform(*args, **kwargs)
+
+
+def prepare_image(img, transformations, dim: int, parallelize=False, log=False):
+    if log:
+        start = time()
+        print('preparing images')
+    imgs = [transform(img, *t, dim=dim) for t in transformations]
+    retval = torch.stack(imgs).float()
+    if log:
+        print(f'prepare_image took {float(time() - start):.02f}s')
+    return retval
+
+
+class Policy:
+    def __init__(self, action_primitives: List[str], num_rotations: int, scale_factors: List[float], obs_dim: int,
+                 pix_grasp_dist: int, pix_drag_dist: int, pix_place_dist: int, **kwargs):
+        assert len(action_primitives) > 0
+        self.action_primitives = action_primitives
+        # rotation angles in degrees, counter-clockwise: fling covers [-90, 90], the others the full circle
+        if 'fling' in action_primitives:
+            self.rotations = [(2 * i / (num_rotations - 1) - 1) * 90 for i in range(num_rotations)]
+        else:
+            self.rotations = [(2 * i / num_rotations - 1) * 180 for i in range(num_rotations)]
+        self.scale_factors = scale_factors
+        self.num_transforms = len(self.rotations) * len(self.scale_factors)
+        self.obs_dim = obs_dim
+        self.pix_grasp_dist = pix_grasp_dist
+        self.pix_drag_dist = pix_drag_dist
+        self.pix_place_dist = pix_place_dist
+
+    def get_action_single(self, obs):
+        raise NotImplementedError()
+
+    def act(self, obs):
+        return [self.get_action_single(o) for o in obs]
+
+
+class MaximumValuePolicy(nn.Module, Policy):
+    def __init__(self, action_expl_prob: float, action_expl_decay: float, value_expl_prob: float,
+                 value_expl_decay: float, device=None, **kwargs):
+        super().__init__()
+        Policy.__init__(self, **kwargs)
+        if device is None:
+            self.device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        else:
+            self.device = torch.device(device)
+        as_param = lambda v: nn.parameter.Parameter(torch.tensor(v), requires_grad=False)
+        self.action_expl_prob = as_param(action_expl_prob)
+        self.action_expl_decay = as_param(action_expl_decay)
+        self.value_expl_prob = as_param(value_expl_prob)
+        self.value_expl_decay = as_param(value_expl_decay)
+        # one value net per action primitive
+        self.value_nets = nn.ModuleDict({key: SpatialValueNet(device=self.device, **kwargs).to(self.device)
+                                         for key in self.action_primitives})
+        self.should_explore_action = lambda: self.action_expl_prob > random.random()
+        self.should_explore_value = lambda: self.value_expl_prob > random.random()
+        self.eval()
+
+    def decay_exploration(self):
+        self.action_expl_prob *= self.action_expl_decay
+        self.value_expl_prob *= self.value_expl_decay
+
+    def random_value_map(self):
+        return torch.rand(len(self.rotations) * len(self.scale_factors), self.obs_dim, self.obs_dim)
+
+    def _explore(self, value_maps):
+        """Value / action exploration on one environment's dict of value maps (nets.py:279-293)."""
+        value_maps = {k: (v if not self.should_explore_value() else self.random_value_map())
+                      for k, v in value_maps.items()}
+        if self.should_explore_action():
+            random_action, action_val_map = random.choice(list(value_maps.items()))
+            min_val = action_val_map.min()
+            value_maps = {k: (v if k == random_action else torch.ones(v.size()) * min_val)
+                          for k, v in value_maps.items()}
+        return value_maps
+
+    def get_action_single(self, obs):
+        return self.act([obs])[0]
+
+    def act(self, obs):
+        """list of [T,4,D,D] observation stacks -> list of {primitive: [T,D,D] cpu tensor}.  All environments go through
+        each value net in ONE batched forward (the reference loops per environment)."""
+        if len(obs) == 0:
+            return []
+        with torch.no_grad():
+            sizes = [o.shape[0] for o in obs]
+            batch = torch.cat([o.to(self.device, non_blocking=True) for o in obs], dim=0)
+            outs = {k: net(batch).squeeze(1).cpu().split(sizes) for k, net in self.value_nets.items()}
+            return [self._explore({k: outs[k][e] for k in outs}) for e in range(len(obs))]
+
+    def steps(self):
+        return sum([net.steps for net in self.value_nets.values()])
+
+    def forward(self, obs):
+        return self.act(obs)

@@ -81,6 +81,52 @@ def camera_vectors():
     print("camera:", len(out), "cases")
 
 
+def nets_vectors():
+    """Reference learning/nets.py (stubs: cv2, ray): state_dict layout, a seeded forward, policy rotations."""
+    import torch
+
+    stub("cv2")
+    ray = stub("ray")
+    ray.remote = lambda f: f
+    sys.path.insert(0, os.path.join(REF, "learning"))
+    import nets as refnets  # the reference module
+
+    torch.manual_seed(0)
+    kw = dict(action_primitives=["fling"], num_rotations=12, scale_factors=[1.0, 1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75],
+              obs_dim=64, pix_grasp_dist=16, pix_drag_dist=16, pix_place_dist=10, rgb_only=True, depth_only=False,
+              action_expl_prob=0.0, action_expl_decay=0.9, value_expl_prob=0.0, value_expl_decay=0.9, device="cpu")
+    pol = refnets.MaximumValuePolicy(**kw)
+    g = torch.Generator().manual_seed(1)
+    for m in pol.modules():  # make BatchNorm statistics non-trivial
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    pol.eval()
+    sd = pol.state_dict()
+    obs = torch.rand(3, 4, 24, 24, generator=g)
+    obs[:, 3] = 1.9 + 0.1 * obs[:, 3]
+    with torch.no_grad():
+        out = pol.value_nets["fling"](obs)
+        acted = pol.act([obs, obs[:2]])
+    arrays = {"sd::" + k: v.numpy() for k, v in sd.items()}
+    arrays.update(obs=obs.numpy(), out=out.numpy(), act0=acted[0]["fling"].numpy(), act1=acted[1]["fling"].numpy(),
+                  rotations=np.array(pol.rotations), num_transforms=np.array(pol.num_transforms))
+    np.savez_compressed(os.path.join(HERE, "nets_golden.npz"), **arrays)
+    with open(os.path.join(HERE, "nets_state_dict_keys.json"), "w") as fh:
+        json.dump({k: list(v.shape) for k, v in sd.items()}, fh, indent=0)
+    # rotate stage of transform() (scipy only; cv2 is absent so pad/resize cannot be run from the reference)
+    from scipy import ndimage as nd
+
+    img = torch.rand(4, 40, 40, generator=g)
+    rots = {}
+    for ang in (-90.0, -40.909, 0.0, 16.3636, 57.27, 90.0):
+        rots[f"rot_{ang}"] = nd.rotate(input=img.permute(2, 1, 0), angle=ang, reshape=False, mode="nearest")
+    np.savez_compressed(os.path.join(HERE, "rotate_golden.npz"), img=img.numpy(), **rots)
+    print("nets:", len(sd), "state_dict entries; out", tuple(out.shape))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils"]
     if "coverage" in which:

@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: two `gloo` ranks shard episodes, gather per-episode coverage rewards and reduce the timing, using
+the same helpers bench.py runs over RCCL on the GPU node (flingbot_amd/distributed.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["FS_ROOT"])
+import torch
+from flingbot_amd import distributed as fdist
+from oracle.coverage import covered_area
+
+rank, local_rank, world = fdist.init_from_env("gloo")
+E = 3
+episodes = list(fdist.episode_range(rank, E))
+cov = []
+for g in episodes:                      # each rank evaluates only its own episodes
+    rng = np.random.RandomState(g)
+    pos = np.concatenate([rng.rand(200, 3) * [0.4, 0.1, 0.3], np.ones((200, 1))], 1).astype(np.float32)
+    cov.append(covered_area(pos))
+allcov = fdist.gather_rewards(cov)
+tmax = fdist.max_over_ranks(1.0 + rank)
+fdist.barrier()
+print(json.dumps({"rank": rank, "world": world, "episodes": episodes, "cov": allcov.tolist(), "tmax": tmax}))
+torch.distributed.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    import json
+
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FS_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert outs[0]["episodes"] == [0, 1, 2] and outs[1]["episodes"] == [3, 4, 5]  # disjoint, complete partition
+    from oracle.coverage import covered_area
+
+    expect = []
+    for g in range(6):
+        rng = np.random.RandomState(g)
+        pos = np.concatenate([rng.rand(200, 3) * [0.4, 0.1, 0.3], np.ones((200, 1))], 1).astype(np.float32)
+        expect.append(np.float32(covered_area(pos)))
+    for o in outs:  # every rank ends with the full vector, ordered by global episode id
+        assert o["world"] == 2
+        assert np.array_equal(np.array(o["cov"], np.float32), np.array(expect, np.float32))
+        assert o["tmax"] == 2.0
+
+
+def test_single_rank_helpers_need_no_process_group():
+    from flingbot_amd import distributed as fdist
+
+    assert list(fdist.episode_range(3, 4)) == [12, 13, 14, 15]
+    assert fdist.gather_rewards([1.0, 2.0]).tolist() == [1.0, 2.0]
+    assert fdist.max_over_ranks(0.25) == 0.25
+    fdist.barrier()
