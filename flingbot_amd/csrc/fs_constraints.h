@@ -85,9 +85,12 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
     const float kk = tether ? -k : k;
     // wi / (wi + wj): exact shortcuts (see fs_mass_ratio); the division runs only if some lane of the wave needs it
     const float wj = xj.w;
-    float ratio = (wj == wi) ? 0.5f : 1.0f;
-    const bool odd = active && (wj != wi) && (wj != 0.0f);
-    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
+    float ratio = 0.5f;
+    if (__builtin_amdgcn_ballot_w64(wj != wi) != 0ull) {  // some lane has a pinned or differently weighted neighbour
+        ratio = (wj == wi) ? 0.5f : 1.0f;
+        const bool odd = active && (wj != wi) && (wj != 0.0f);
+        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
+    }
     // an inactive constraint contributes sc = +0: d - e * 0 == d for every finite e (the accumulators start at +0
     // and can never become -0), so one select on the scale replaces three on the accumulators
     float sc = active ? (kk * ratio) * (C * inv_len) : 0.0f;

@@ -15,25 +15,28 @@
 #pragma once
 #include "fs_constraints.h"
 
+#ifndef FS_FUSED_THREADS
 #define FS_FUSED_THREADS 1024
-#define FS_FUSED_PPT 4
+#endif
+#define FS_FUSED_PPT (4096 / FS_FUSED_THREADS)
 #define FS_FUSED_MAX_PARTICLES (FS_FUSED_THREADS * FS_FUSED_PPT)
 #define FS_FUSED_MAX_DEG 64
 #define FS_FUSED_BUCKETS 4096  // 32 x 4 x 32 wrapped cells (>= 3 per axis: a 3x3x3 block never aliases itself)
 #define FS_FUSED_SLOTS 16      // compact adjacency slots per particle
 
-// LDS carve (bytes), exactly the 160 KiB of one CU:
-//   X  float4[4096]  current Jacobi iterate (xyz + invMass)                          64 KiB
-//   X0 float[3][4096] substep-start position (own displacement + neighbours' for friction)  48 KiB
-//   XN float[3][4096] next iterate, published into X after the barrier                48 KiB
-//      -- aliased, while no iteration is running, by the spatial hash: cursor int[4096] | items u16[4096] | scan
+// LDS carve (bytes):
+//   X    float4[4096]   current Jacobi iterate (xyz + invMass)                               64 KiB
+//   X0   float[3][4096] substep-start position (own displacement + neighbours' for friction)  48 KiB
+//   DICT float2[256]    distinct (rest length, stiffness) pairs of the cloth                    2 KiB
+//   HASH cursor int[4096] | items u16[4096] | scan int[16]   (neighbour search only)           24 KiB
+// The next iterate needs no LDS: each thread carries its four new positions in a rotating set of registers.
 #define FS_FUSED_OFF_X 0
 #define FS_FUSED_OFF_X0 (FS_FUSED_OFF_X + FS_FUSED_MAX_PARTICLES * 16)
-#define FS_FUSED_OFF_XN (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
-#define FS_FUSED_OFF_CUR FS_FUSED_OFF_XN
+#define FS_FUSED_OFF_DICT (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
+#define FS_FUSED_OFF_CUR (FS_FUSED_OFF_DICT + 256 * 8)
 #define FS_FUSED_OFF_ITEMS (FS_FUSED_OFF_CUR + FS_FUSED_BUCKETS * 4)
 #define FS_FUSED_OFF_SCAN (FS_FUSED_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
-#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_XN + FS_FUSED_MAX_PARTICLES * 12)
+#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_SCAN + 64)
 #define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
 
 #define FS_GLOBAL __attribute__((address_space(1)))
@@ -155,7 +158,7 @@ __device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, cons
         if (lane == 63) wave_tot[wave] = inc;
         __syncthreads();
         int run = inc - sum;
-        for (int w = 0; w < wave; ++w) run += wave_tot[w];
+        for (int w = 0; w < wave; ++w) run += wave_tot[w];  // <= 16 waves
 #pragma unroll
         for (int k = 0; k < PER; ++k) { cursor[t * PER + k] = run; run += loc[k]; }
     }
@@ -263,9 +266,6 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     float *X0x = (float *)(smem + FS_FUSED_OFF_X0);
     float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
     float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
-    float *XNx = (float *)(smem + FS_FUSED_OFF_XN);
-    float *XNy = XNx + FS_FUSED_MAX_PARTICLES;
-    float *XNz = XNy + FS_FUSED_MAX_PARTICLES;
     int *cursor = (int *)(smem + FS_FUSED_OFF_CUR);
     unsigned short *items = (unsigned short *)(smem + FS_FUSED_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FS_FUSED_OFF_SCAN);
@@ -285,9 +285,12 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     const fs_gci g_ell_j = (fs_gci)E.ell_j;
     const fs_gcf g_ell_len = (fs_gcf)E.ell_len, g_ell_k = (fs_gcf)E.ell_k;
     const fs_gcu g_nbr = (fs_gcu)E.nbr_w, g_code = (fs_gcu)E.code_w;
-    const char FS_GLOBAL *g_dict = (const char FS_GLOBAL *)E.dict;
     const int max_deg = E.max_deg;
 
+    if (COMPACT && t < 256) {
+        const fs_gcf g_dict = (fs_gcf)E.dict;
+        *(float2 *)(smem + FS_FUSED_OFF_DICT + t * 8) = make_float2(g_dict[2 * t], g_dict[2 * t + 1]);
+    }
     // own particles: i = t + k * 1024.  Load positions into X (w = invMass) and X0.
     for (int i = t; i < n; i += FS_FUSED_THREADS) {
         const FsVec4 p = fs_ld4(g_pos, i);
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     for (int frame = 0; frame < n_steps; ++frame) {
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
-            // ---- predict from (X0, vel) into X; build the spatial hash (aliases XN, which is idle here)
+            // ---- predict from (X0, vel) into X; build the spatial hash
             for (int q = t; q < FS_FUSED_BUCKETS; q += FS_FUSED_THREADS) cursor[q] = 0;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
@@ -318,9 +321,8 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll 1
             for (int i = t; i < n; i += FS_FUSED_THREADS)
                 g_ncount[i] = fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist);
-            __syncthreads();  // the hash is dead from here on: its LDS becomes XN
 
-            // ---- Jacobi iterations: X -> XN, barrier, publish XN -> X, barrier
+            // ---- Jacobi iterations: gather from X, new positions in rotating registers, barrier, publish, barrier
 #pragma unroll 1
             for (int it = 0; it < c.iters; ++it) {
                 // software pipeline over the thread's particles: adjacency words / candidate head of particle k+1 are
@@ -338,12 +340,19 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                     for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = g_nlist[(unsigned)q * un + i0];
                 }
+                // new positions of the thread's particles: a rotating register file (r3 <- r2 <- r1 <- r0 <- new) so the
+                // ROLLED particle loop needs no dynamically indexed registers and no LDS staging
+                float rx[FS_FUSED_PPT], ry[FS_FUSED_PPT], rz[FS_FUSED_PPT];  // statically indexed only
+#pragma unroll
+                for (int q = 0; q < FS_FUSED_PPT; ++q) { rx[q] = 0.0f; ry[q] = 0.0f; rz[q] = 0.0f; }
 #pragma unroll 1
-                for (int i = t; i < n; i += FS_FUSED_THREADS) {
+                for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                    const int i_raw = t + k * FS_FUSED_THREADS;
+                    const int i = i_raw < n ? i_raw : 0;  // lanes past the end recompute particle 0 and discard it
                     uint32_t jw_n[JW], cw_n[JW];
                     int cnt_n, cj_n[FS_FUSED_PREFETCH_CAND];
                     {
-                        unsigned in = i + FS_FUSED_THREADS < n ? (unsigned)(i + FS_FUSED_THREADS) : (unsigned)i;
+                        unsigned in = i_raw + FS_FUSED_THREADS < n ? (unsigned)(i_raw + FS_FUSED_THREADS) : 0u;
                         if (COMPACT) {
 #pragma unroll
                             for (int q = 0; q < JW; ++q) { jw_n[q] = g_nbr[(unsigned)q * un + in]; cw_n[q] = g_code[(unsigned)q * un + in]; }
@@ -361,16 +370,16 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                             // one spring per scheduling region; the LDS gather and dictionary fetch of spring s+1 are
                             // issued in front of the arithmetic of spring s
                             FsVec4 xj = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + (jw[0] & 0xffffu));
-                            fs_f2 lk = *(const fs_f2 FS_GLOBAL *)(g_dict + (cw[0] & 0xffffu));
+                            float2 lk = *(const float2 *)(smem + FS_FUSED_OFF_DICT + (cw[0] & 0xffffu));
 #pragma unroll
                             for (int s = 0; s < SLOTS; ++s) {
                                 FsVec4 xj_next = xj;
-                                fs_f2 lk_next = lk;
+                                float2 lk_next = lk;
                                 if (s + 1 < SLOTS) {
                                     const uint32_t joff = (jw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
                                     const uint32_t coff = (cw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
                                     xj_next = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + joff);
-                                    lk_next = *(const fs_f2 FS_GLOBAL *)(g_dict + coff);
+                                    lk_next = *(const float2 *)(smem + FS_FUSED_OFF_DICT + coff);
                                 }
                                 fs_spring_bf(a, xi0, xi1, xi2, wi, xj, lk.x, lk.y);
                                 __builtin_amdgcn_sched_barrier(0);
@@ -386,23 +395,34 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                             }
                         }
                         const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
-                        for (int s = 0; s < cnt; ++s) {
-                            int j;
-                            if (s < FS_FUSED_PREFETCH_CAND) {
-                                j = cj[0];
+                        // candidates in chunks of FS_FUSED_PREFETCH_CAND: the ids of chunk c+1 are requested from the
+                        // (slot-major, L2-resident) list before chunk c is processed, so a long list costs one exposed
+                        // memory latency at most instead of one per candidate
+                        for (int s0 = 0; s0 < cnt; s0 += FS_FUSED_PREFETCH_CAND) {
+                            int cn[FS_FUSED_PREFETCH_CAND];
 #pragma unroll
-                                for (int q = 0; q + 1 < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj[q + 1];
-                            } else {
-                                j = g_nlist[(unsigned)s * un + (unsigned)i];
+                            for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) {
+                                const int sn = s0 + FS_FUSED_PREFETCH_CAND + q;
+                                cn[q] = sn < cnt ? g_nlist[(unsigned)sn * un + (unsigned)i] : 0;
                             }
-                            const FsVec4 xj = X[j];
-                            fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
-                                                xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+#pragma unroll 1
+                            for (int q = 0; q < FS_FUSED_PREFETCH_CAND && s0 + q < cnt; ++q) {  // one copy of the body
+                                const int j = cj[0];
+#pragma unroll
+                                for (int r = 0; r + 1 < FS_FUSED_PREFETCH_CAND; ++r) cj[r] = cj[r + 1];
+                                const FsVec4 xj = X[j];
+                                fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
+                                                    xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+                            }
+#pragma unroll
+                            for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cn[q];
                         }
                         fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
                         fs_apply(a, c.relax, nx, ny, nz);
                     }
-                    XNx[i] = nx; XNy[i] = ny; XNz[i] = nz;
+#pragma unroll
+                    for (int q = FS_FUSED_PPT - 1; q > 0; --q) { rx[q] = rx[q - 1]; ry[q] = ry[q - 1]; rz[q] = rz[q - 1]; }
+                    rx[0] = nx; ry[0] = ny; rz[0] = nz;
                     if (COMPACT) {
 #pragma unroll
                         for (int q = 0; q < JW; ++q) { jw[q] = jw_n[q]; cw[q] = cw_n[q]; }
@@ -412,8 +432,10 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj_n[q];
                 }
                 __syncthreads();
-                for (int i = t; i < n; i += FS_FUSED_THREADS) {
-                    X[i].x = XNx[i]; X[i].y = XNy[i]; X[i].z = XNz[i];
+#pragma unroll
+                for (int q = 0; q < FS_FUSED_PPT; ++q) {  // particle q of the thread sits in slot PPT-1-q
+                    const int i = t + q * FS_FUSED_THREADS;
+                    if (i < n) { FsVec4 &d = X[i]; d.x = rx[FS_FUSED_PPT - 1 - q]; d.y = ry[FS_FUSED_PPT - 1 - q]; d.z = rz[FS_FUSED_PPT - 1 - q]; }
                 }
                 __syncthreads();
             }

@@ -25,7 +25,7 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("FLINGSIM_LIB", _build.LIB)  # development override: an alternative build of the library
     if not os.path.exists(path):
         if not build_if_missing:
             raise FlingSimError(f"{path} is missing: run `python -m flingbot_amd.build`")
