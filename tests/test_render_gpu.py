@@ -128,3 +128,38 @@ def test_render_pickers_visible_and_idempotent(gpu_required):
     assert abs(sph.sum() - 2 * np.pi * r_px ** 2) / (2 * np.pi * r_px ** 2) < 0.15, sph.sum()
     img = rgba1.reshape(720, 720, 4)
     assert img[sph][:, :3].mean() > 120  # 0.9 grey spheres
+
+
+def test_render_matches_raster_oracle(gpu_required):
+    """HIP rasteriser vs the scalar C restatement (oracle/raster_oracle.c) on a crumpled cloth with both pickers in view:
+    depth bit-exact, alpha exact, colour within 1 LSB (device expf/powf vs libm differ in the last ulp)."""
+    from flingbot_amd import sim as fsim
+    from oracle.render import render as orc_render
+    import scenarios as sc
+
+    ctx = fsim.FlingSim(n_envs=1)
+    env = ctx.env(0)
+    sc.scenario_crumple(env, 32, 32, seed=7, lift_steps=25, settle_steps=20)
+    env.add_sphere(0.02, [0.35, 0.4, -0.3], [1, 0, 0, 0])
+    env.add_sphere(0.02, [-0.2, 0.1, 0.25], [1, 0, 0, 0])
+    st = env.get_shape_states().reshape(-1, 14).copy()
+    st[:, 3:6] = st[:, 0:3] + [0.01, 0.0, -0.02]  # prev != current: the renderer must draw the PREVIOUS position
+    env.set_shape_states(st.ravel())
+    rgba, depth = env.render()
+    cam = env.get_camera_params()  # [w, h, px, py, pz, ax, ay, az]
+    lo, up = env.get_scene_bounds()
+    m = fsim.camera_matrices(cam[2:5], cam[5:8], int(cam[0]), int(cam[1]), lo, up)
+    mats = np.concatenate([m["view"].ravel(), m["proj"].ravel(), m["light"].ravel(), m["lightpos"], m["lightdir"]])
+    ref_rgba, ref_depth = orc_render(mats, cam[2:5], int(cam[0]), int(cam[1]), env.get_positions(), env.get_normals(),
+                                     env.get_faces(), env.get_shape_states(), [0.02, 0.02])
+    assert np.array_equal(depth.view(np.uint32), ref_depth.view(np.uint32)), \
+        f"{(depth != ref_depth).sum()} depth pixels differ"
+    a, b = rgba.reshape(-1, 4).astype(int), ref_rgba.reshape(-1, 4).astype(int)
+    assert np.array_equal(a[:, 3], b[:, 3])
+    diff = np.abs(a[:, :3] - b[:, :3])
+    assert diff.max() <= 1, f"max colour difference {diff.max()}"
+    assert (diff > 0).mean() < 0.02
+    # the scene really contains all three kinds of primitives
+    d = depth.reshape(720, 720)
+    assert ((d > 1.55) & (d < 1.65)).sum() > 50 and ((d > 1.85) & (d < 1.95)).sum() > 50  # spheres at y = 0.4 and 0.1
+    assert (d < 1.999).sum() > 1500
