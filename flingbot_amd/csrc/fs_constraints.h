@@ -234,6 +234,13 @@ __device__ __forceinline__ bool fs_pair_allowed(int phi, int phj, const FsVec4 r
     return true;
 }
 
-__device__ __forceinline__ int fs_bucket(int cx, int cy, int cz) {
-    return (cx & (FS_GRID_BX - 1)) | ((cy & (FS_GRID_BY - 1)) << 5) | ((cz & (FS_GRID_BZ - 1)) << 9);
+// Spatial hash of an integer cell: multiplicative mix, top `bits` bits.  Any cell -> bucket map is correct here because
+// the search re-derives the TRUE cell of every candidate and accepts it only from the visit of that exact cell, so
+// aliasing (two of the 27 visited cells sharing a bucket, or far-away cells colliding) can never duplicate or invent a
+// neighbour; the hash only has to spread cells evenly for ANY cloth orientation.  (An axis-wrapped grid degenerates:
+// a sheet hanging vertically spans 36 cells along the axis that was given 4.)
+__device__ __forceinline__ int fs_cell_hash(int cx, int cy, int cz, int bits) {
+    const unsigned h = (unsigned)cx * 0x9E3779B1u + (unsigned)cy * 0x85EBCA77u + (unsigned)cz * 0xC2B2AE3Du;
+    return (int)((h ^ (h >> 15)) * 0x2C1B3C6Du >> (32 - bits));
 }
+__device__ __forceinline__ int fs_bucket(int cx, int cy, int cz) { return fs_cell_hash(cx, cy, cz, 14); }

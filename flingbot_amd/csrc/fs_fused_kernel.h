@@ -21,7 +21,7 @@
 #define FS_FUSED_PPT (4096 / FS_FUSED_THREADS)
 #define FS_FUSED_MAX_PARTICLES (FS_FUSED_THREADS * FS_FUSED_PPT)
 #define FS_FUSED_MAX_DEG 64
-#define FS_FUSED_BUCKETS 4096  // 32 x 4 x 32 wrapped cells (>= 3 per axis: a 3x3x3 block never aliases itself)
+#define FS_FUSED_BUCKETS 4096  // hashed cells (fs_cell_hash, 12 bits)
 #define FS_FUSED_SLOTS 16      // compact adjacency slots per particle
 
 // LDS carve (bytes):
@@ -58,9 +58,7 @@ __device__ __forceinline__ void fs_st4(FsVec4 *p, size_t i, const FsVec4 v) {
     ((FS_GLOBAL fs_f4 *)p)[i] = fs_f4{v.x, v.y, v.z, v.w};
 }
 
-__device__ __forceinline__ int fs_fused_bucket(int cx, int cy, int cz) {
-    return (cx & 31) | ((cy & 3) << 5) | ((cz & 31) << 7);
-}
+__device__ __forceinline__ int fs_fused_bucket(int cx, int cy, int cz) { return fs_cell_hash(cx, cy, cz, 12); }
 
 // Scalars of one episode, read once (uniform => SGPRs) so the hot loops never reload them through the descriptor.
 struct FsFusedConsts {

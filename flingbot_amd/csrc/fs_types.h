@@ -12,12 +12,8 @@
 #define FS_PHASE_SELF_COLLIDE_FILTER (1 << 21)
 #define FS_PHASE_CHANNEL_MASK 0x7f000000
 
-// wrapped uniform grid used for particle-neighbour search: 32 x 16 x 32 buckets; any 3x3x3 block of cells maps to 27
-// distinct buckets, so a neighbour is never visited twice.
-#define FS_GRID_BX 32
-#define FS_GRID_BY 16
-#define FS_GRID_BZ 32
-#define FS_GRID_BUCKETS (FS_GRID_BX * FS_GRID_BY * FS_GRID_BZ)
+// hashed uniform grid used for particle-neighbour search by the streaming path (fs_cell_hash, 14 bits)
+#define FS_GRID_BUCKETS 16384
 
 // Effective NvFlexParams subset that reaches the cloth step (reference NvFlex.h:95-154; values main.cpp:717-884,
 // softgym_cloth.h:154-170).
