@@ -30,8 +30,11 @@ FsTopologyDev::~FsTopologyDev() {
 fs_ctx::~fs_ctx() {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
-    for (auto &e : envs)
+    for (auto &e : envs) {
         if (e.slab) (void)hipFree(e.slab);
+        if (e.d_picked) (void)hipFree(e.d_picked);
+        if (e.d_saved_w) (void)hipFree(e.d_saved_w);
+    }
     envs.clear();
     topo_cache.clear();
     if (d_envs) (void)hipFree(d_envs);
@@ -219,6 +222,9 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     if (!err.empty()) { fs_set_error(err); return FS_ERR_ARG; }
     // Init tears down the previous solver, buffers and shapes (main.cpp:623-706)
     if (e->slab) { (void)hipFree(e->slab); e->slab = nullptr; }
+    if (e->d_picked) { (void)hipFree(e->d_picked); e->d_picked = nullptr; }
+    if (e->d_saved_w) { (void)hipFree(e->d_saved_w); e->d_saved_w = nullptr; }
+    e->picker_ready = false;
     e->has_scene = false;
     e->topo.reset();
     auto topo = make_topology(ctx, scene);
@@ -286,6 +292,10 @@ extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
         ids.push_back(env);
     }
     if (ids.empty() || n_steps == 0) return FS_OK;
+    return fs_step_ids(ctx, ids, n_steps, nullptr);
+}
+
+int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids) {
     int solver = ctx->solver;
     if (solver == FS_SOLVER_AUTO) {
         solver = FS_SOLVER_FUSED;
@@ -298,7 +308,7 @@ extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
                 return FS_ERR_STATE;
             }
     }
-    return solver == FS_SOLVER_FUSED ? fs_step_fused(ctx, ids, n_steps) : fs_step_stream(ctx, ids, n_steps);
+    return solver == FS_SOLVER_FUSED ? fs_step_fused(ctx, ids, n_steps, d_ids) : fs_step_stream(ctx, ids, n_steps, d_ids);
 }
 
 extern "C" int fs_step_timed(fs_ctx *ctx, int env, int n_steps, float *elapsed_ms) {

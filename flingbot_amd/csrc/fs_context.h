@@ -47,6 +47,11 @@ struct FsEnv {
     FsEnvDev dev;          // host copy of the descriptor
     FsShapesDev shapes;    // host copy
     float shape_rot[FS_MAX_SHAPES][4], shape_prev_rot[FS_MAX_SHAPES][4];
+    // on-device picker state (fs_picker.hip): picked particle per shape (-1 none), inverse masses saved at reset
+    int *d_picked = nullptr;   // [FS_MAX_SHAPES]
+    float *d_saved_w = nullptr;  // [n]
+    double picker_threshold = 0.005, particle_radius = 0.00625;
+    bool picker_ready = false;
     FsCamera cam;
 };
 
@@ -79,8 +84,11 @@ bool fs_hip_ok(hipError_t e, const char *what);
 void *fs_stage(fs_ctx *ctx, size_t bytes);
 
 // solver back-ends
-int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps);
-int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps);
+// d_ids: optional device copy of `ids` already resident (skips the upload); nullptr = upload ids to ctx->d_ids
+int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids = nullptr);
+int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids = nullptr);
+// picks the back-end like fs_step does and launches n_steps frames for `ids`
+int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids = nullptr);
 bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env);
 // renderer / coverage
 int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth);

@@ -1,0 +1,312 @@
+// fs_picker.hip -- on-device picker and `movep` trajectory executor.
+//
+// Native counterpart of the reference's host loop around the solver:
+//     SimEnv.movep                  environment/simEnv.py:739-769      (move pickers toward targets by `speed` per step)
+//     PickerPickPlace.step          environment/flex_utils.py:223-252  (delta_move 1.0, steps_limit 1)
+//     Picker.step / _set_pos        environment/flex_utils.py:114-205  (grasp nearest particle, pin + teleport it)
+// The reference pays 5-7 synchronising pyflex getters/setters plus Python per simulation step there.  The picker motion
+// is kinematic, so the HOST can compute the whole trajectory of a movep call up front (float64, rounded to float32
+// exactly where the numpy code rounds); the DEVICE then runs, per simulation step, one small picker kernel (un-pick,
+// nearest-particle grasp search, teleport of held particles, shape prev/current update) followed by the solver step,
+// without any host round trip.  Episodes of a batch finish after different step counts: per-step id lists select the
+// ones still moving.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/flingsim.h"
+#include "fs_context.h"
+
+#define HIP_TRY(call)                                     \
+    do {                                                  \
+        if (!fs_hip_ok((call), #call)) return FS_ERR_HIP; \
+    } while (0)
+
+struct FsPickerCmd {  // one Picker.step for one episode
+    float new_pos[FS_MAX_SHAPES][4];  // float32 picker centres after the move (w unused)
+    int grasp[FS_MAX_SHAPES];
+};
+
+// One workgroup per episode.  Mirrors Picker.step: every read of particle data refers to the arrays as they were at
+// entry (`particle_pos`), writes go to the updated copy (`new_particle_pos`) -- in place here, which is equivalent
+// because a particle is held by at most one picker.
+__global__ __launch_bounds__(256) void fs_k_picker_step(const FsEnvDev *envs, FsShapesDev *shapes, const int *ids,
+                                                        const FsPickerCmd *cmds, int *const *picked_ptrs,
+                                                        float *const *saved_w_ptrs, double threshold) {
+    const int slot = blockIdx.x;
+    const int e = ids[slot];
+    const FsEnvDev &E = envs[e];
+    FsShapesDev &sh = shapes[e];
+    const FsPickerCmd &cmd = cmds[slot];
+    int *picked = picked_ptrs[e];
+    const float *saved_w = saved_w_ptrs[e];
+    const int t = threadIdx.x, n = E.n, S = sh.count;
+    __shared__ double best_d[256];
+    __shared__ int best_i[256];
+    __shared__ int s_picked[FS_MAX_SHAPES];
+    if (t < S) s_picked[t] = picked[t];
+    __syncthreads();
+    // 1. un-pick: restore the inverse mass of released particles (flex_utils.py:134-140)
+    if (t == 0) {
+        for (int k = 0; k < S; ++k)
+            if (!cmd.grasp[k] && s_picked[k] >= 0) {
+                E.pos[s_picked[k]].w = saved_w[s_picked[k]];
+                s_picked[k] = -1;
+            }
+    }
+    __syncthreads();
+    // 2. pick + teleport, picker by picker (flex_utils.py:143-173)
+    for (int k = 0; k < S; ++k) {
+        if (cmd.grasp[k] && s_picked[k] < 0) {
+            // nearest particle within threshold of the picker BEFORE the move, not already held; ties -> lowest index
+            const double px = (double)sh.pos[k].x, py = (double)sh.pos[k].y, pz = (double)sh.pos[k].z;
+            double bd = 1.0e300;
+            int bi = -1;
+            for (int i = t; i < n; i += 256) {
+                const FsVec4 p = E.pos[i];
+                const double dx = (double)p.x - px, dy = (double)p.y - py, dz = (double)p.z - pz;
+                const double d = sqrt(dx * dx + dy * dy + dz * dz);
+                bool held = false;
+                for (int q = 0; q < S; ++q) held = held || (s_picked[q] == i);
+                if (d <= threshold && !held && (d < bd || (d == bd && i < bi))) { bd = d; bi = i; }
+            }
+            best_d[t] = bd;
+            best_i[t] = bi;
+            __syncthreads();
+            for (int off = 128; off > 0; off >>= 1) {
+                if (t < off) {
+                    const double od = best_d[t + off];
+                    const int oi = best_i[t + off];
+                    if (oi >= 0 && (best_i[t] < 0 || od < best_d[t] || (od == best_d[t] && oi < best_i[t]))) {
+                        best_d[t] = od;
+                        best_i[t] = oi;
+                    }
+                }
+                __syncthreads();
+            }
+            if (t == 0 && best_i[0] >= 0) s_picked[k] = best_i[0];
+            __syncthreads();
+        }
+        if (t == 0 && cmd.grasp[k] && s_picked[k] >= 0) {
+            FsVec4 p = E.pos[s_picked[k]];
+            // float32: particle + new_picker - picker, left to right (flex_utils.py:168-170)
+            p.x = (p.x + cmd.new_pos[k][0]) - sh.pos[k].x;
+            p.y = (p.y + cmd.new_pos[k][1]) - sh.pos[k].y;
+            p.z = (p.z + cmd.new_pos[k][2]) - sh.pos[k].z;
+            p.w = 0.0f;  // "set the mass to infinity"
+            E.pos[s_picked[k]] = p;
+        }
+        __syncthreads();
+    }
+    // 3. _set_pos: prev := current, current := new (flex_utils.py:114-119)
+    if (t < S) {
+        const float r = sh.pos[t].w;
+        sh.prev[t] = FsVec4{sh.pos[t].x, sh.pos[t].y, sh.pos[t].z, r};
+        sh.pos[t] = FsVec4{cmd.new_pos[t][0], cmd.new_pos[t][1], cmd.new_pos[t][2], r};
+        picked[t] = s_picked[t];
+    }
+}
+
+__global__ void fs_k_save_inv_mass(const FsVec4 *pos, float *saved_w, int n, int *picked) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) saved_w[i] = pos[i].w;
+    if (i < FS_MAX_SHAPES) picked[i] = -1;
+}
+
+static FsEnv *picker_env(fs_ctx *ctx, int env) {
+    if (!ctx || env < 0 || env >= ctx->n_envs || !ctx->envs[env].has_scene) {
+        fs_set_error("picker: bad env or no scene");
+        return nullptr;
+    }
+    return &ctx->envs[env];
+}
+
+// Picker.reset's bookkeeping (flex_utils.py:85,99-101): no particle held, remember every particle's inverse mass.
+extern "C" int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, double particle_radius) {
+    FsEnv *e = picker_env(ctx, env);
+    if (!e) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!e->d_picked) HIP_TRY(hipMalloc((void **)&e->d_picked, sizeof(int) * FS_MAX_SHAPES));
+    if (!e->d_saved_w) HIP_TRY(hipMalloc((void **)&e->d_saved_w, sizeof(float) * e->host.n));
+    e->picker_threshold = picker_threshold;
+    e->particle_radius = particle_radius;
+    hipLaunchKernelGGL(fs_k_save_inv_mass, dim3((e->host.n + 255) / 256), dim3(256), 0, ctx->stream, e->dev.pos,
+                       e->d_saved_w, e->host.n, e->d_picked);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    e->picker_ready = true;
+    return FS_OK;
+}
+
+extern "C" int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints) {
+    FsEnv *e = picker_env(ctx, env);
+    if (!e || !out) return FS_ERR_ARG;
+    if (!e->picker_ready) { fs_set_error("fs_picker_reset has not been called"); return FS_ERR_STATE; }
+    if (n_ints < e->shapes.count) { fs_set_error("buffer too small"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int tmp[FS_MAX_SHAPES];
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(tmp, e->d_picked, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int k = 0; k < e->shapes.count; ++k) out[k] = tmp[k];
+    return FS_OK;
+}
+
+namespace {
+struct Plan {  // host-side trajectory of one episode for one movep call
+    std::vector<FsPickerCmd> cmds;  // one per SIMULATION step
+    int iterations = 0;             // movep loop iterations (>= cmds.size(): iterations on the target take no step)
+    bool limit_hit = false;
+};
+
+inline double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+// simEnv.py:739-769 + flex_utils.py:223-252 on the kinematic picker state only (float64 math, float32 state)
+Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *grasp, double speed, int limit,
+                int min_steps, double eps) {
+    Plan plan;
+    const int S = shapes.count;
+    float cur[FS_MAX_SHAPES][3];
+    for (int k = 0; k < S; ++k) { cur[k][0] = shapes.pos[k].x; cur[k][1] = shapes.pos[k].y; cur[k][2] = shapes.pos[k].z; }
+    for (int step = 0; step < limit; ++step) {
+        double end[FS_MAX_SHAPES][3];
+        bool all_close = true;
+        for (int k = 0; k < S; ++k) {
+            double d[3];
+            for (int c = 0; c < 3; ++c) d[c] = targets[3 * k + c] - (double)cur[k][c];
+            const double dist = norm3(d);
+            if (!(dist < eps)) all_close = false;
+            for (int c = 0; c < 3; ++c)
+                end[k][c] = dist < speed ? targets[3 * k + c] : (double)cur[k][c] + (d[c] / dist) * speed;
+        }
+        if (all_close && (min_steps < 0 || step > min_steps)) {
+            plan.iterations = step;
+            return plan;
+        }
+        // PickerPickPlace.step
+        double num_step = 0.0;
+        for (int k = 0; k < S; ++k) {
+            double d[3];
+            for (int c = 0; c < 3; ++c) d[c] = (double)cur[k][c] - end[k][c];
+            const double ns = ceil(norm3(d) / 1.0);
+            if (ns > num_step) num_step = ns;
+        }
+        if (num_step < 0.1) continue;  // already on the targets: the reference returns without stepping the simulation
+        double delta[FS_MAX_SHAPES][3], sq = 0.0;
+        for (int k = 0; k < S; ++k)
+            for (int c = 0; c < 3; ++c) {
+                delta[k][c] = (end[k][c] - (double)cur[k][c]) / num_step;
+                sq += delta[k][c] * delta[k][c];
+            }
+        const double norm_delta = sqrt(sq);
+        bool all_within = true;
+        for (int k = 0; k < S; ++k) {
+            double d[3];
+            for (int c = 0; c < 3; ++c) d[c] = end[k][c] - (double)cur[k][c];
+            if (!(norm3(d) < norm_delta)) all_within = false;
+        }
+        if (all_within)
+            for (int k = 0; k < S; ++k)
+                for (int c = 0; c < 3; ++c) delta[k][c] = end[k][c] - (double)cur[k][c];
+        FsPickerCmd cmd;
+        memset(&cmd, 0, sizeof(cmd));
+        for (int k = 0; k < S; ++k) {
+            for (int c = 0; c < 3; ++c) {
+                cur[k][c] = (float)((double)cur[k][c] + delta[k][c]);  // Picker.step: float32 <- float32 + float64
+                cmd.new_pos[k][c] = cur[k][c];
+            }
+            cmd.grasp[k] = grasp[k] ? 1 : 0;
+        }
+        plan.cmds.push_back(cmd);
+    }
+    plan.limit_hit = true;
+    plan.iterations = limit;
+    return plan;
+}
+}  // namespace
+
+// movep for a batch of episodes: targets double[n][S][3], grasp int[n][S] (S = shapes of the episode, identical
+// for every episode of the batch), iterations_out int[n].  Returns FS_ERR_LIMIT if any episode ran into `limit`
+// (MoveJointsException in the reference); the trajectories are executed up to the limit in that case.
+extern "C" int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed,
+                              int limit, int min_steps, double eps, int *iterations_out) {
+    if (!ctx || n <= 0 || !envs || !targets || !grasp) { fs_set_error("fs_movep: bad arguments"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    int S = -1;
+    std::vector<Plan> plans(n);
+    size_t max_steps = 0;
+    for (int a = 0; a < n; ++a) {
+        FsEnv *e = picker_env(ctx, envs[a]);
+        if (!e) return FS_ERR_ARG;
+        if (!e->picker_ready) { fs_set_error("fs_movep: call fs_picker_reset first"); return FS_ERR_STATE; }
+        if (S < 0) S = e->shapes.count;
+        if (e->shapes.count != S || S <= 0) { fs_set_error("fs_movep: episodes need the same (non-zero) picker count"); return FS_ERR_STATE; }
+        plans[a] = plan_movep(e->shapes, targets + (size_t)a * S * 3, grasp + (size_t)a * S, speed, limit, min_steps, eps);
+        if (iterations_out) iterations_out[a] = plans[a].iterations;
+        if (plans[a].cmds.size() > max_steps) max_steps = plans[a].cmds.size();
+    }
+    bool any_limit = false;
+    for (auto &p : plans) any_limit = any_limit || p.limit_hit;
+    if (max_steps > 0) {
+        // per step: the ids of the episodes still moving + their commands, all uploaded once
+        std::vector<int> h_ids(max_steps * n, 0), h_count(max_steps, 0);
+        std::vector<FsPickerCmd> h_cmds(max_steps * n);
+        for (size_t s = 0; s < max_steps; ++s)
+            for (int a = 0; a < n; ++a)
+                if (s < plans[a].cmds.size()) {
+                    const int slot = h_count[s]++;
+                    h_ids[s * n + slot] = envs[a];
+                    h_cmds[s * n + slot] = plans[a].cmds[s];
+                }
+        std::vector<int *> h_picked(ctx->n_envs, nullptr);
+        std::vector<float *> h_saved(ctx->n_envs, nullptr);
+        for (int i = 0; i < ctx->n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
+        int *d_ids = nullptr;
+        FsPickerCmd *d_cmds = nullptr;
+        int **d_picked = nullptr;
+        float **d_saved = nullptr;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMalloc((void **)&d_ids, sizeof(int) * h_ids.size()));
+        HIP_TRY(hipMalloc((void **)&d_cmds, sizeof(FsPickerCmd) * h_cmds.size()));
+        HIP_TRY(hipMalloc((void **)&d_picked, sizeof(int *) * ctx->n_envs));
+        HIP_TRY(hipMalloc((void **)&d_saved, sizeof(float *) * ctx->n_envs));
+        HIP_TRY(hipMemcpy(d_ids, h_ids.data(), sizeof(int) * h_ids.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_cmds, h_cmds.data(), sizeof(FsPickerCmd) * h_cmds.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_picked, h_picked.data(), sizeof(int *) * ctx->n_envs, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_saved, h_saved.data(), sizeof(float *) * ctx->n_envs, hipMemcpyHostToDevice));
+        int rc = FS_OK;
+        for (size_t s = 0; s < max_steps && rc == FS_OK; ++s) {
+            const int cnt = h_count[s];
+            std::vector<int> ids(h_ids.begin() + s * n, h_ids.begin() + s * n + cnt);
+            const double thr = ctx->envs[ids[0]].picker_threshold + (double)ctx->envs[ids[0]].shapes.pos[0].w +
+                               ctx->envs[ids[0]].particle_radius;
+            hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes,
+                               d_ids + s * n, d_cmds + s * n, d_picked, d_saved, thr);
+            rc = fs_step_ids(ctx, ids, 1, d_ids + s * n);
+        }
+        hipError_t err = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_ids); (void)hipFree(d_cmds); (void)hipFree(d_picked); (void)hipFree(d_saved);
+        if (rc != FS_OK) return rc;
+        HIP_TRY(err);
+        // host mirrors of the shape states follow the planned trajectory
+        for (int a = 0; a < n; ++a) {
+            FsEnv &e = ctx->envs[envs[a]];
+            const auto &cm = plans[a].cmds;
+            if (cm.empty()) continue;
+            for (int k = 0; k < S; ++k) {
+                const float r = e.shapes.pos[k].w;
+                const float *pv = cm.size() >= 2 ? cm[cm.size() - 2].new_pos[k] : &e.shapes.pos[k].x;
+                e.shapes.prev[k] = FsVec4{pv[0], pv[1], pv[2], r};
+                e.shapes.pos[k] = FsVec4{cm.back().new_pos[k][0], cm.back().new_pos[k][1], cm.back().new_pos[k][2], r};
+            }
+        }
+    }
+    if (any_limit) { fs_set_error("fs_movep: step limit reached (MoveJointsException)"); return FS_ERR_LIMIT; }
+    return FS_OK;
+}
+
+extern "C" int fs_movep(fs_ctx *ctx, int env, const double *targets, const int *grasp, double speed, int limit,
+                        int min_steps, double eps, int *iterations_out) {
+    return fs_movep_batch(ctx, 1, &env, targets, grasp, speed, limit, min_steps, eps, iterations_out);
+}

@@ -20,9 +20,12 @@ static int upload_ids(fs_ctx *ctx, const std::vector<int> &ids) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Streaming back-end: per substep  predict -> grid scan -> grid scatter -> find neighbours -> I x iterate -> finalize
-int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
-    int rc = upload_ids(ctx, ids);
-    if (rc != FS_OK) return rc;
+int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids_in) {
+    const int *d_ids = d_ids_in ? d_ids_in : ctx->d_ids;
+    if (!d_ids_in) {
+        int rc = upload_ids(ctx, ids);
+        if (rc != FS_OK) return rc;
+    }
     int max_n = 0, substeps = 0, iters = 0;
     for (int id : ids) {
         const FsEnv &e = ctx->envs[id];
@@ -38,13 +41,13 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
     hipStream_t st = ctx->stream;
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
-            hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, ctx->d_ids);
-            hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, ctx->d_envs, ctx->d_ids);
-            hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, ctx->d_ids);
-            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, ctx->d_ids);
+            hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, d_ids);
+            hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, ctx->d_envs, d_ids);
+            hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, d_ids);
+            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, d_ids);
             for (int it = 0; it < iters; ++it)
-                hipLaunchKernelGGL(fs_k_iterate, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, ctx->d_ids, sub, it & 1);
-            hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, ctx->d_ids, iters & 1);
+                hipLaunchKernelGGL(fs_k_iterate, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1);
+            hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -59,9 +62,12 @@ bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env) {
            env.dev.p.numPlanes <= 1;
 }
 
-int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
-    int rc = upload_ids(ctx, ids);
-    if (rc != FS_OK) return rc;
+int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids_in) {
+    const int *d_ids = d_ids_in ? d_ids_in : ctx->d_ids;
+    if (!d_ids_in) {
+        int rc = upload_ids(ctx, ids);
+        if (rc != FS_OK) return rc;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<12>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -82,13 +88,13 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps) {
     const dim3 grid((unsigned)ids.size()), block(FS_FUSED_THREADS);
     if (slots == 12)
         hipLaunchKernelGGL(fs_k_fused_step<12>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
-                           ctx->d_ids, n_steps);
+                           d_ids, n_steps);
     else if (slots == 16)
         hipLaunchKernelGGL(fs_k_fused_step<16>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
-                           ctx->d_ids, n_steps);
+                           d_ids, n_steps);
     else
         hipLaunchKernelGGL(fs_k_fused_step<0>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
-                           ctx->d_ids, n_steps);
+                           d_ids, n_steps);
     HIP_TRY(hipGetLastError());
     return FS_OK;
 }

@@ -20,6 +20,10 @@ class FlingSimError(RuntimeError):
     pass
 
 
+class MoveLimitError(FlingSimError):
+    """fs_movep ran into its step limit (environment/exceptions.py MoveJointsException in the reference)."""
+
+
 def load_library(build_if_missing=True):
     """dlopen libflingsim.so and declare every prototype of include/flingsim.h."""
     global _lib
@@ -72,6 +76,10 @@ def load_library(build_if_missing=True):
         "fs_render": (ci, [vp, ci, u8p, ci, fp, ci]),
         "fs_coverage": (ci, [vp, C.POINTER(C.c_double), ci]),
         "fs_step_timed": (ci, [vp, ci, ci, fp]),
+        "fs_picker_reset": (ci, [vp, ci, C.c_double, C.c_double]),
+        "fs_picker_get_picked": (ci, [vp, ci, ip, ci]),
+        "fs_movep": (ci, [vp, ci, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
+        "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_timer_start": (ci, [vp]),
         "fs_timer_stop": (ci, [vp, fp]),
         "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
@@ -161,6 +169,31 @@ class FlingSim:
         ms = C.c_float(0.0)
         self._ck(self.lib.fs_step_timed(self.h, int(env), int(n_steps), C.byref(ms)))
         return float(ms.value)
+
+    # ---- on-device picker / movep (include/flingsim.h)
+    def picker_reset(self, env, picker_threshold=0.005, particle_radius=0.00625):
+        self._ck(self.lib.fs_picker_reset(self.h, int(env), float(picker_threshold), float(particle_radius)))
+
+    def picked(self, env):
+        out = np.full(self.n_shapes(env), -1, np.int32)
+        self._ck(self.lib.fs_picker_get_picked(self.h, int(env), _ip(out), out.size))
+        return out
+
+    def movep(self, envs, targets, grasp, speed=0.1, limit=1000, min_steps=None, eps=1e-4):
+        """SimEnv.movep for one episode (envs = int) or a batch (envs = sequence).  targets [n,S,3] float64, grasp [n,S].
+        Returns the iteration counts; raises MoveLimitError like the reference's MoveJointsException."""
+        single = np.isscalar(envs)
+        ids = _i([envs] if single else envs)
+        tg = np.ascontiguousarray(np.asarray(targets, np.float64).reshape(ids.size, -1, 3))
+        gr = _i(np.asarray(grasp).astype(np.int32).reshape(ids.size, -1))
+        iters = np.zeros(ids.size, np.int32)
+        rc = self.lib.fs_movep_batch(self.h, ids.size, _ip(ids), tg.ctypes.data_as(C.POINTER(C.c_double)), _ip(gr),
+                                     float(speed), int(limit), -1 if min_steps is None else int(min_steps), float(eps),
+                                     _ip(iters))
+        if rc == -4:
+            raise MoveLimitError(self.lib.fs_last_error().decode())
+        self._ck(rc)
+        return int(iters[0]) if single else iters
 
     def timer_start(self):
         self._ck(self.lib.fs_timer_start(self.h))

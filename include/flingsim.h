@@ -26,6 +26,7 @@ typedef struct fs_ctx fs_ctx;
 #define FS_ERR_ARG (-1)
 #define FS_ERR_HIP (-2)
 #define FS_ERR_STATE (-3)
+#define FS_ERR_LIMIT (-4) /* fs_movep: step limit reached (MoveJointsException, environment/exceptions.py) */
 
 /* solver back-ends (fs_set_solver) */
 #define FS_SOLVER_AUTO 0    /* fused LDS-resident kernel when the episode fits one CU's LDS, else streaming */
@@ -113,6 +114,24 @@ int fs_coverage(fs_ctx *ctx, double *out, int n_doubles);
 int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
 /* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */
 void *fs_device_positions(fs_ctx *ctx, int env);
+
+/* ---- on-device picker + movep executor (additive) -------------------------------------------
+   Native counterpart of the host loop the reference runs around pyflex.step(): SimEnv.movep (simEnv.py:739-769) ->
+   PickerPickPlace.step (flex_utils.py:223-252) -> Picker.step (flex_utils.py:121-205).  The pickers are the
+   episode's kinematic spheres (fs_add_sphere); results are identical to driving fs_step through those Python classes. */
+/* Picker.reset bookkeeping (flex_utils.py:85,99-101): nothing held; remember every particle's inverse mass. */
+int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, double particle_radius);
+/* picked particle index per picker (-1 = none) */
+int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
+/* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all
+   are within eps (and more than min_steps iterations ran; min_steps < 0 = None).  Runs every simulation step on the
+   device without host round trips.  iterations_out = loop iterations (what movep's `step` counts).
+   Returns FS_ERR_LIMIT when `limit` iterations were not enough. */
+int fs_movep(fs_ctx *ctx, int env, const double *targets, const int *grasp, double speed, int limit, int min_steps,
+             double eps, int *iterations_out);
+/* the same for n episodes at once: targets double[n][S][3], grasp int[n][S], iterations_out int[n] */
+int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed, int limit,
+                   int min_steps, double eps, int *iterations_out);
 
 /* ---- host-only entry points (no HIP device needed) ------------------------------------------------------------
    Scene builder exposed on its own so host logic can be checked without a GPU: same arguments as fs_set_scene. */

@@ -127,8 +127,88 @@ def nets_vectors():
     print("nets:", len(sd), "state_dict entries; out", tuple(out.shape))
 
 
+def picker_vectors():
+    """Reference Picker / PickerPickPlace (environment/flex_utils.py) driven through a `pyflex` stub that is backed by
+    the CPU oracle; the movep loop is simEnv.py:739-769 verbatim in behaviour (SimEnv itself needs ray/h5py/trimesh to
+    import, so its 30-line loop is driven from here).  Records the full particle / shape trajectory."""
+    sys.path.insert(0, ROOT)
+    from oracle import OracleSim
+
+    if not hasattr(np, "alltrue"):  # the reference targets numpy 1.x (flex_utils.py:245,251); same function
+        np.alltrue = np.all
+    orc = OracleSim()
+    pf = stub("pyflex")
+    for name in ("get_positions", "set_positions", "get_velocities", "set_velocities", "get_shape_states",
+                 "set_shape_states", "add_sphere", "get_phases", "set_phases"):
+        setattr(pf, name, getattr(orc, name))
+    pf.step = lambda *a, **k: orc.step(1)
+    stub("cv2")
+    sys.path.insert(0, os.path.join(REF, "environment"))
+    import importlib
+    import flex_utils
+    importlib.reload(flex_utils)  # bind to the oracle-backed stub
+
+    sp = np.array([0, 0.2, 0, 24, 24, 0.9, 0.9, 0.9, 2, 0, 2, 0, np.pi / 2, -np.pi / 2, 0, 720, 720, 0.3, 0])
+    orc.set_scene(sp)
+    orc.step(1)
+    n = orc.n
+    w = orc.get_positions().reshape(-1, 4)[0, 3]
+    xs = (np.arange(24) - 11.5) * 0.00625
+    xx, zz = np.meshgrid(xs, xs)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3] = xx.ravel(), 0.0125, zz.ravel(), w
+    orc.set_positions(pos.ravel())
+    orc.set_velocities(np.zeros(3 * n, np.float32))
+
+    tool = flex_utils.PickerPickPlace(num_picker=2, particle_radius=0.00625, picker_radius=0.02,
+                                      picker_low=(-5, 0, -5), picker_high=(5, 5, 5))
+    tool.reset([0.0, 0.1, 0.0])
+    grasp_states = [False, False]
+    log = {"pos": [], "shapes": [], "picked": [], "iters": []}
+
+    def movep(target, speed, limit=1000, min_steps=None, eps=1e-4):
+        target_pos = np.array(target)
+        for step in range(limit):
+            curr_pos = tool._get_pos()[0]
+            deltas = [(targ - curr) for targ, curr in zip(target_pos, curr_pos)]
+            dists = [np.linalg.norm(delta) for delta in deltas]
+            if all([dist < eps for dist in dists]) and (min_steps is None or step > min_steps):
+                log["iters"].append(step)
+                return
+            action = []
+            for targ, curr, delta, dist, gs in zip(target_pos, curr_pos, deltas, dists, grasp_states):
+                if dist < speed:
+                    action.extend([*targ, float(gs)])
+                else:
+                    delta = delta / dist
+                    action.extend([*(curr + delta * speed), float(gs)])
+            tool.step(np.array(action), step_sim_fn=lambda: orc.step(1))
+            log["pos"].append(orc.get_positions().copy())
+            log["shapes"].append(orc.get_shape_states().copy())
+            log["picked"].append([-1 if q is None else q for q in tool.picked_particles])
+        raise RuntimeError("limit")
+
+    p0 = pos[0, :3].astype(np.float64) + [0, 0.02, 0]
+    p1 = pos[23, :3].astype(np.float64) + [0, 0.02, 0]
+    program = [([p0, p1], 0.1, None, [False, False]),                               # approach (simEnv.py:297)
+               ([p0 + [0, 0.12, 0], p1 + [0, 0.12, 0]], 5e-3, None, [True, True]),   # grasp + lift (:299-304)
+               ([p0 + [0, 0.12, 0.02], p1 + [0, 0.12, 0.02]], 5e-4, 20, [True, True]),  # stretch-like, min_steps
+               ([p0 + [0, 0.12, -0.06], p1 + [0, 0.12, -0.06]], 6e-3, None, [True, True]),  # fling back
+               ([p0 + [0, 0.05, -0.06], p1 + [0, 0.05, -0.06]], 6e-3, None, [True, False])]  # release one picker
+    for target, speed, min_steps, gs in program:
+        grasp_states[:] = gs
+        movep(target, speed, min_steps=min_steps)
+    np.savez_compressed(os.path.join(HERE, "picker_golden.npz"), scene_params=sp, init_pos=pos,
+                        targets=np.array([t for t, _, _, _ in program]), speeds=np.array([s for _, s, _, _ in program]),
+                        min_steps=np.array([-1 if m is None else m for _, _, m, _ in program]),
+                        grasp=np.array([g for _, _, _, g in program]), iters=np.array(log["iters"]),
+                        picked=np.array(log["picked"]), shapes=np.array(log["shapes"]),
+                        pos_every_10=np.array(log["pos"][::10]), pos_last=log["pos"][-1])
+    print("picker:", len(log["pos"]), "sim steps, iters", log["iters"], "picked", log["picked"][-1])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils"]
+    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker"]
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:
@@ -137,3 +217,5 @@ if __name__ == "__main__":
         nets_vectors()
     if "envutils" in which and "envutils_vectors" in globals():
         envutils_vectors()
+    if "picker" in which:
+        picker_vectors()

@@ -326,3 +326,56 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt and "flex_oracle" not in txt, f
+
+
+# ---------------------------------------------------------------- picker / movep restatement vs the reference classes
+def replay_picker_program(sim, picker_cls=None, golden=None, record=None):
+    """Replays the recorded movep program of tests/golden/picker_golden.npz on `sim` with the restated picker."""
+    from oracle.picker import OraclePicker
+
+    g = golden
+    sim.set_scene(g["scene_params"])
+    sim.step(1)
+    sim.set_positions(g["init_pos"].ravel())
+    sim.set_velocities(np.zeros(3 * g["init_pos"].shape[0], np.float32))
+    tool = (picker_cls or OraclePicker)(sim)
+    # Picker.reset(center) puts two pickers at center -/+ r on x (flex_utils.py:64-72): r = sqrt(1) * 0.02 * 2
+    r = np.sqrt(2 - 1) * 0.02 * 2.
+    tool.reset([[0.0 + np.cos(2 * np.pi * i / 2) * r, 0.1, 0.0 + np.sin(2 * np.pi * i / 2) * r] for i in range(2)])
+    iters = []
+    for target, speed, ms, gs in zip(g["targets"], g["speeds"], g["min_steps"], g["grasp"]):
+        iters.append(tool.movep(target, list(gs), speed=float(speed), min_steps=None if ms < 0 else int(ms)))
+        if record is not None:
+            record(sim, tool)
+    return tool, iters
+
+
+def test_picker_restatement_matches_reference_classes():
+    """oracle/picker.py == the reference's Picker/PickerPickPlace + movep, both driving the CPU oracle: same picked
+    particle ids, same shape states and particle arrays bit for bit over 92 simulation steps."""
+    from oracle import OracleSim
+
+    g = np.load(os.path.join(GOLD, "picker_golden.npz"))
+    sim = OracleSim()
+    shapes, picked, poss = [], [], []
+    from oracle.picker import OraclePicker
+
+    class Rec(OraclePicker):
+        def step(self, action):
+            super().step(action)
+
+        def pick_place_step(self, action):
+            n = super().pick_place_step(action)
+            if n:
+                shapes.append(self.sim.get_shape_states().copy())
+                picked.append([-1 if q is None else q for q in self.picked_particles])
+                poss.append(self.sim.get_positions().copy())
+            return n
+
+    tool, iters = replay_picker_program(sim, Rec, g)
+    assert iters == g["iters"].tolist()
+    assert np.array_equal(np.array(picked), g["picked"])
+    assert np.array_equal(np.array(shapes).view(np.uint32), g["shapes"].view(np.uint32))
+    assert np.array_equal(np.array(poss[::10]).view(np.uint32), g["pos_every_10"].view(np.uint32))
+    assert np.array_equal(poss[-1].view(np.uint32), g["pos_last"].view(np.uint32))
+    assert g["picked"][-1].tolist() == [0, -1] and g["picked"][5].tolist() == [0, 23]
