@@ -349,21 +349,11 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     const int i = i_raw < n ? i_raw : 0;  // lanes past the end recompute particle 0 and discard it
                     uint32_t jw_n[JW], cw_n[JW];
                     int cnt_n, cj_n[FS_FUSED_PREFETCH_CAND];
-                    {
-                        unsigned in = i_raw + FS_FUSED_THREADS < n ? (unsigned)(i_raw + FS_FUSED_THREADS) : 0u;
-                        if (COMPACT) {
-#pragma unroll
-                            for (int q = 0; q < JW; ++q) { jw_n[q] = g_nbr[(unsigned)q * un + in]; cw_n[q] = g_code[(unsigned)q * un + in]; }
-                        }
-                        cnt_n = g_ncount[in];
-#pragma unroll
-                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
-                    }
                     const FsVec4 xi = X[i];
                     float nx = xi.x, ny = xi.y, nz = xi.z;
+                    FsAcc a = {0.0f, 0.0f, 0.0f, 0};
+                    const float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z, wi = xi.w;
                     if (xi.w > 0.0f) {
-                        FsAcc a = {0.0f, 0.0f, 0.0f, 0};
-                        const float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z, wi = xi.w;
                         if (COMPACT) {
                             // one spring per scheduling region; the LDS gather and dictionary fetch of spring s+1 are
                             // issued in front of the arithmetic of spring s
@@ -392,6 +382,22 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                                           g_ell_k[(unsigned)s * un + (unsigned)i]);
                             }
                         }
+                    }
+                    // Prefetch for the thread's NEXT particle, issued here -- after the spring block, whose working set is
+                    // dead by now -- and consumed at the top of the next trip: the contact / shape / apply section plus
+                    // the other three waves of the SIMD cover the L2 latency.  (Issued at the top of the body the 17
+                    // in-flight registers overlapped the spring block's peak pressure and were spilled to scratch.)
+                    {
+                        unsigned in = i_raw + FS_FUSED_THREADS < n ? (unsigned)(i_raw + FS_FUSED_THREADS) : 0u;
+                        if (COMPACT) {
+#pragma unroll
+                            for (int q = 0; q < JW; ++q) { jw_n[q] = g_nbr[(unsigned)q * un + in]; cw_n[q] = g_code[(unsigned)q * un + in]; }
+                        }
+                        cnt_n = g_ncount[in];
+#pragma unroll
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
+                    }
+                    if (xi.w > 0.0f) {
                         const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
                         // candidates in chunks of FS_FUSED_PREFETCH_CAND: the ids of chunk c+1 are requested from the
                         // (slot-major, L2-resident) list before chunk c is processed, so a long list costs one exposed
