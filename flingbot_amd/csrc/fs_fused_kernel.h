@@ -36,7 +36,13 @@
 #define FS_FUSED_OFF_CUR (FS_FUSED_OFF_DICT + 256 * 8)
 #define FS_FUSED_OFF_ITEMS (FS_FUSED_OFF_CUR + FS_FUSED_BUCKETS * 4)
 #define FS_FUSED_OFF_SCAN (FS_FUSED_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
-#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_SCAN + 64)
+// contact set (rebuilt every substep, used by the iterations): ids of up to 1024 particles that have contact candidates,
+// ordered by descending candidate count | their spring accumulators float4[1024] | count histogram / cursors int[128]
+#define FS_FUSED_CSET_CAP 1024
+#define FS_FUSED_OFF_CSET (FS_FUSED_OFF_SCAN + 64)
+#define FS_FUSED_OFF_CACC (FS_FUSED_OFF_CSET + FS_FUSED_CSET_CAP * 2)
+#define FS_FUSED_OFF_CHIST (FS_FUSED_OFF_CACC + FS_FUSED_CSET_CAP * 16)
+#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_CHIST + 512)
 #define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
 
 #define FS_GLOBAL __attribute__((address_space(1)))
@@ -320,6 +326,59 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             for (int i = t; i < n; i += FS_FUSED_THREADS)
                 g_ncount[i] = fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist);
 
+            // ---- contact set.  Candidate counts are very uneven (crumpling sheet: mean 0.8, max ~10 per particle), and a
+            // wave walking its lanes' own lists stays in the ~110-instruction contact body for max(count) rounds with a
+            // few live lanes.  So the particles that have candidates (typically a quarter) are collected, ordered by
+            // descending count, into a compact set; in every iteration their owners only evaluate the springs and park
+            // the accumulator in LDS (pass 1), then thread e finishes particle cset[e] -- contacts, plane, spheres,
+            // applyDeltas -- next to 63 lanes with the same amount of work (pass 2).  The per-particle accumulation
+            // order (springs, contacts ascending, planes, spheres) is unchanged, so results stay bit-identical.
+            unsigned short *cset = (unsigned short *)(smem + FS_FUSED_OFF_CSET);
+            FsVec4 *cacc = (FsVec4 *)(smem + FS_FUSED_OFF_CACC);
+            int *chist = (int *)(smem + FS_FUSED_OFF_CHIST);
+            if (t < 128) chist[t] = 0;
+            __syncthreads();
+            int ccls[FS_FUSED_PPT];
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                const int i = t + k * FS_FUSED_THREADS;
+                int cc = 0;
+                if (i < n && X[i].w > 0.0f) cc = g_ncount[i];
+                ccls[k] = cc > 96 ? 96 : cc;
+                if (ccls[k] > 0) atomicAdd(&chist[ccls[k]], 1);
+            }
+            __syncthreads();
+            if (t == 0) {  // exclusive offsets in descending count order; chist[0] <- total
+                int run = 0;
+                for (int q = 96; q >= 1; --q) { const int hq = chist[q]; chist[q] = run; run += hq; }
+                chist[0] = run;
+            }
+            __syncthreads();
+            unsigned long long slotpack = ~0ull;  // 16-bit set slot of each of the thread's particles, 0xffff = not in the set
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                if (ccls[k] > 0) {
+                    const int pos = atomicAdd(&chist[ccls[k]], 1);
+                    if (pos < FS_FUSED_CSET_CAP) {
+                        cset[pos] = (unsigned short)(t + k * FS_FUSED_THREADS);
+                        slotpack = (slotpack & ~(0xffffull << (16 * k))) | ((unsigned long long)pos << (16 * k));
+                    }
+                }
+            }
+            __syncthreads();
+            const int csize = chist[0] < FS_FUSED_CSET_CAP ? chist[0] : FS_FUSED_CSET_CAP;
+            // the set particle this thread finishes in pass 2, with its candidate count and list head (constant over
+            // the substep's iterations)
+            const int i2 = t < csize ? (int)cset[t] : -1;
+            int cnt2 = 0, cj2[FS_FUSED_PREFETCH_CAND];
+#pragma unroll
+            for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = 0;
+            if (i2 >= 0) {
+                cnt2 = g_ncount[i2];
+#pragma unroll
+                for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = g_nlist[(unsigned)q * un + (unsigned)i2];
+            }
+
             // ---- Jacobi iterations: gather from X, new positions in rotating registers, barrier, publish, barrier
 #pragma unroll 1
             for (int it = 0; it < c.iters; ++it) {
@@ -397,7 +456,10 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
                     }
-                    if (xi.w > 0.0f) {
+                    const unsigned myslot = (unsigned)(slotpack >> (16 * k)) & 0xffffu;
+                    if (xi.w > 0.0f && myslot != 0xffffu && i_raw < n) {
+                        cacc[myslot] = FsVec4{a.d0, a.d1, a.d2, __int_as_float(a.cnt)};  // pass 2 finishes this particle
+                    } else if (xi.w > 0.0f) {
                         const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
                         // candidates in chunks of FS_FUSED_PREFETCH_CAND: the ids of chunk c+1 are requested from the
                         // (slot-major, L2-resident) list before chunk c is processed, so a long list costs one exposed
@@ -436,11 +498,48 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj_n[q];
                 }
                 __syncthreads();
+                // ---- pass 2: finish the contact-set particle of this thread
+                float n2x = 0.0f, n2y = 0.0f, n2z = 0.0f;
+                if (i2 >= 0) {
+                    const FsVec4 xi = X[i2];
+                    const FsVec4 pa = cacc[t];
+                    FsAcc a = {pa.x, pa.y, pa.z, __float_as_int(pa.w)};
+                    const float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z, wi = xi.w;
+                    const float ri0 = xi0 - X0x[i2], ri1 = xi1 - X0y[i2], ri2 = xi2 - X0z[i2];
+                    int cjt[FS_FUSED_PREFETCH_CAND];
+#pragma unroll
+                    for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cj2[q];
+                    for (int s0 = 0; s0 < cnt2; s0 += FS_FUSED_PREFETCH_CAND) {
+                        int cn[FS_FUSED_PREFETCH_CAND];
+#pragma unroll
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) {
+                            const int sn = s0 + FS_FUSED_PREFETCH_CAND + q;
+                            cn[q] = sn < cnt2 ? g_nlist[(unsigned)sn * un + (unsigned)i2] : 0;
+                        }
+#pragma unroll 1
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND && s0 + q < cnt2; ++q) {
+                            const int j = cjt[0];
+#pragma unroll
+                            for (int r = 0; r + 1 < FS_FUSED_PREFETCH_CAND; ++r) cjt[r] = cjt[r + 1];
+                            const FsVec4 xj = X[j];
+                            fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
+                                                xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+                        }
+#pragma unroll
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cn[q];
+                    }
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    n2x = xi0; n2y = xi1; n2z = xi2;
+                    fs_apply(a, c.relax, n2x, n2y, n2z);
+                }
+                __syncthreads();  // every read of the old iterate is done
 #pragma unroll
                 for (int q = 0; q < FS_FUSED_PPT; ++q) {  // particle q of the thread sits in slot PPT-1-q
                     const int i = t + q * FS_FUSED_THREADS;
-                    if (i < n) { FsVec4 &d = X[i]; d.x = rx[FS_FUSED_PPT - 1 - q]; d.y = ry[FS_FUSED_PPT - 1 - q]; d.z = rz[FS_FUSED_PPT - 1 - q]; }
+                    const bool in_set = ((unsigned)(slotpack >> (16 * q)) & 0xffffu) != 0xffffu;
+                    if (i < n && !in_set) { FsVec4 &d = X[i]; d.x = rx[FS_FUSED_PPT - 1 - q]; d.y = ry[FS_FUSED_PPT - 1 - q]; d.z = rz[FS_FUSED_PPT - 1 - q]; }
                 }
+                if (i2 >= 0) { FsVec4 &d = X[i2]; d.x = n2x; d.y = n2y; d.z = n2z; }
                 __syncthreads();
             }
             // ---- finalize: new velocity to global, new substep-start position into X0 (own entries only; every other
