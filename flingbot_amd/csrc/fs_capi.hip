@@ -163,6 +163,7 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         topo->dict = c.take<float>(512);
         topo->code_w = c.take<uint32_t>(size_t(8) * n + 1);
         topo->nbr_w = c.take<uint32_t>(size_t(8) * n + 1);
+        topo->restnear_w = c.take<uint32_t>(size_t(8) * n + 1);
         topo->tris = c.take<int>(size_t(3) * s.t + 1);
         topo->vt_off = c.take<int>(n + 1);
         topo->vt_tri = c.take<int>(size_t(3) * s.t + 1);
@@ -189,6 +190,8 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         up(topo->code_w, s.code_w.data(), size_t(8) * n * 4);
         up(topo->nbr_w, s.nbr_w.data(), size_t(8) * n * 4);
     }
+    topo->restnear_ok = s.restnear_ok;
+    up(topo->restnear_w, s.restnear_w.data(), size_t(8) * n * 4);
     up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
     up(topo->vt_off, s.vt_off.data(), (n + 1) * 4);
     up(topo->vt_tri, s.vt_tri.data(), size_t(3) * s.t * 4);
@@ -257,6 +260,7 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     d.n = scene.n; d.m = scene.m; d.max_deg = scene.max_deg; d.has_scene = 1;
     d.rest = topo->rest; d.adj_off = topo->adj_off; d.adj_j = topo->adj_j; d.adj_len = topo->adj_len; d.adj_k = topo->adj_k;
     d.ell_j = topo->ell_j; d.ell_len = topo->ell_len; d.ell_k = topo->ell_k;
+    d.restnear_w = topo->restnear_w; d.restnear_ok = topo->restnear_ok;
     d.dict_size = topo->dict_size; d.dict = topo->dict; d.code_w = topo->code_w; d.nbr_w = topo->nbr_w;
     d.p = scene.params;
 
@@ -506,6 +510,27 @@ extern "C" int fs_get_params(fs_ctx *ctx, int env, float *o, int n_floats) {
     o[22] = (float)p.numPlanes; o[23] = p.planes[0][0]; o[24] = p.planes[0][1]; o[25] = p.planes[0][2];
     o[26] = p.planes[0][3]; o[27] = (float)p.maxNeighbors; o[28] = (float)p.maxContacts; o[29] = (float)p.relaxationMode;
     return FS_OK;
+}
+extern "C" int fs_set_params(fs_ctx *ctx, int env, const float *o, int n_floats) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !o) return FS_ERR_ARG;
+    CHECK_LEN(n_floats, 32);
+    HIP_TRY(hipSetDevice(ctx->device));
+    FsParams &p = e->dev.p;
+    if (o[0] < 0 || o[0] > 1000 || o[1] < 1 || o[1] > 100 || !(o[2] > 0.0f)) { fs_set_error("bad iteration / substep / dt values"); return FS_ERR_ARG; }
+    if (o[6] != p.radius || o[10] != p.particleCollisionMargin) {
+        fs_set_error("fs_set_params: radius / particleCollisionMargin are baked into the topology (rest-pose filter)");
+        return FS_ERR_ARG;
+    }
+    p.numIterations = (int)o[0]; p.numSubsteps = (int)o[1]; p.dt = o[2];
+    p.gravity[0] = o[3]; p.gravity[1] = o[4]; p.gravity[2] = o[5];
+    p.radius = o[6]; p.solidRestDistance = o[7]; p.collisionDistance = o[8]; p.shapeCollisionMargin = o[9];
+    p.particleCollisionMargin = o[10]; p.dynamicFriction = o[11]; p.staticFriction = o[12]; p.particleFriction = o[13];
+    p.damping = o[14]; p.sleepThreshold = o[15]; p.relaxationFactor = o[16]; p.maxAcceleration = o[17];
+    p.maxSpeed = o[18]; p.restitution = o[19]; p.adhesion = o[20]; p.dissipation = o[21];
+    p.planes[0][0] = o[23]; p.planes[0][1] = o[24]; p.planes[0][2] = o[25]; p.planes[0][3] = o[26];
+    e->host.params = p;
+    return push_env_desc(ctx, env);
 }
 extern "C" int fs_get_scene_bounds(fs_ctx *ctx, int env, float *lower3, float *upper3) {
     FsEnv *e = get_env(ctx, env);

@@ -80,15 +80,17 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
     float inv_len = fs_rsqrt(l2);
     float len = l2 * inv_len;
     float C = len - L;
+    // (bitwise, not short-circuit, logic: short-circuit forms become exec-mask branches)
     const bool tether = k < 0.0f;
-    const bool active = (len > 0.0f) && (!tether || (C > 0.0f));
+    const bool active = (len > 0.0f) & (!tether | (C > 0.0f));
     const float kk = tether ? -k : k;
-    // wi / (wi + wj): exact shortcuts (see fs_mass_ratio); the division runs only if some lane of the wave needs it
+    // wi / (wi + wj): exact shortcuts (see fs_mass_ratio).  The common case -- every lane's neighbour has the lane's own
+    // mass -- is the fall-through path; anything else is moved out of line.
     const float wj = xj.w;
     float ratio = 0.5f;
-    if (__builtin_amdgcn_ballot_w64(wj != wi) != 0ull) {  // some lane has a pinned or differently weighted neighbour
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(wj != wi) != 0ull, 0)) {
         ratio = (wj == wi) ? 0.5f : 1.0f;
-        const bool odd = active && (wj != wi) && (wj != 0.0f);
+        const bool odd = active & (wj != wi) & (wj != 0.0f);
         if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
     }
     // an inactive constraint contributes sc = +0: d - e * 0 == d for every finite e (the accumulators start at +0

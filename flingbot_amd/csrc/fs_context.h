@@ -25,7 +25,8 @@ struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
     float *ell_len = nullptr, *ell_k = nullptr;
     int dict_size = 0;
     float *dict = nullptr;
-    uint32_t *code_w = nullptr, *nbr_w = nullptr;
+    uint32_t *code_w = nullptr, *nbr_w = nullptr, *restnear_w = nullptr;
+    int restnear_ok = 0;
     int *tris = nullptr;  // 3t
     int *vt_off = nullptr, *vt_tri = nullptr;  // vertex -> triangles CSR
     int t = 0;

@@ -182,13 +182,65 @@ __device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, cons
 struct FsFindConsts {  // by value: a reference would force the caller's constants onto the stack
     int n, ncap;
     float rad2, inv_rad;
+    int mode;  // 0: test phases and rest positions per pair (global loads); 1: uniform phase with SelfCollideFilter ->
+               // membership test against the particle's packed rest-near ids; 2: uniform phase, no filter
 };
+struct FsNearWords {  // rest-near ids of one particle, by value (registers)
+    uint32_t w[8];
+};
+#define FS_FUSED_FINDQ 8  // per-thread queue depth (u16 ids) of the two-phase neighbour search, aliases the contact set
+
+// Second half of the search for one candidate j that passed the distance and true-cell tests: phase / rest-pose
+// filter, sorted insertion.
+__device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, int j, int &cnt, int &phi, FsVec4 &ri,
+                                                bool &have_meta, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
+                                                const FsNearWords &near) {
+    const int n = c.n;
+    if (c.mode == 0) {  // general: phases and rest positions from global memory, per pair
+        if (!have_meta) {
+            phi = phase[i];
+            ri = fs_ld4(rest, i);
+            have_meta = true;
+        }
+        const FsVec4 rj = fs_ld4(rest, j);
+        if (!fs_pair_allowed(phi, phase[j], ri, rj, c.rad2)) return;
+    } else if (c.mode == 1) {  // one phase for the whole cloth: the filter is a set-membership test on packed ids
+        const uint32_t jj = (uint32_t)j | ((uint32_t)j << 16);
+        uint32_t hit = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t x = near.w[q] ^ jj;               // a zero 16-bit half <=> that slot holds j
+            hit |= (x - 0x00010001u) & ~x & 0x80008000u;     // classic "has a zero half-word" test
+        }
+        if (hit) return;
+    }
+    if (cnt == c.ncap) {
+        if (j > nlist[(size_t)(c.ncap - 1) * n + i]) return;
+        cnt = c.ncap - 1;
+    }
+    int s = cnt;
+    while (s > 0) {
+        int prev = nlist[(size_t)(s - 1) * n + i];
+        if (prev < j) break;
+        nlist[(size_t)s * n + i] = prev;
+        --s;
+    }
+    nlist[(size_t)s * n + i] = j;
+    ++cnt;
+}
+
+// Two-phase search.  Lanes hit their few real neighbours at different trips of the candidate loop, so with the accept
+// code inside that loop nearly every trip drags the whole wave through it.  Phase A only filters by distance and true
+// cell and parks the survivors (8-9 for a flat sheet) in a per-thread LDS queue; phase B walks the queue, where all lanes
+// have work at the same time.  The candidate loop is software-pipelined: the id two candidates ahead and the position
+// one candidate ahead are requested from LDS before the current candidate is tested (the chain id -> position ->
+// distance is otherwise two exposed LDS latencies per trip).
 __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, const FsVec4 *X,
                                                        const int *cursor, const unsigned short *items, fs_gci phase,
-                                                       const FsVec4 *rest, fs_gi nlist) {
-    const int n = c.n;
+                                                       const FsVec4 *rest, fs_gi nlist, const FsNearWords near,
+                                                       unsigned short *queue /* [FINDQ][blockDim] + threadIdx */) {
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
-    int cnt = 0, phi = 0;
+    int cnt = 0, phi = 0, qn = 0;
     FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
     bool have_meta = false;
     for (int dz = -1; dz <= 1; ++dz)
@@ -197,39 +249,38 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
                 const int b = fs_fused_bucket(cx + dx, cy + dy, cz + dz);
                 const int beg = (b == 0) ? 0 : cursor[b - 1];
                 const int end = cursor[b];
+                if (beg >= end) continue;
+                // items[] has slack behind the last used entry only up to FS_FUSED_MAX_PARTICLES: clamp the look-ahead
+                int j_cur = items[beg];
+                int j_nxt = items[beg + 1 < FS_FUSED_MAX_PARTICLES ? beg + 1 : beg];
+                FsVec4 x_cur = X[j_cur];
                 for (int q = beg; q < end; ++q) {
-                    const int j = items[q];
+                    const int j = j_cur;
+                    const FsVec4 xj = x_cur;
+                    j_cur = j_nxt;
+                    x_cur = X[j_cur & (FS_FUSED_MAX_PARTICLES - 1)];
+                    j_nxt = items[q + 2 < FS_FUSED_MAX_PARTICLES ? q + 2 : q];
                     if (j == i) continue;
-                    const FsVec4 xj = X[j];
                     float ex = xi.x - xj.x, ey = xi.y - xj.y, ez = xi.z - xj.z;
                     float d2 = ex * ex + ey * ey + ez * ez;
                     if (!(d2 < c.rad2)) continue;
-                    // the bucket may alias a far-away cell: require the true cell to be the visited one
+                    // the bucket may alias another cell: take j only from the visit of its own (true) cell, which also
+                    // guarantees it is queued at most once
                     if ((int)floorf(xj.x * c.inv_rad) != cx + dx || (int)floorf(xj.y * c.inv_rad) != cy + dy ||
                         (int)floorf(xj.z * c.inv_rad) != cz + dz)
                         continue;
-                    if (!have_meta) {
-                        phi = phase[i];
-                        ri = fs_ld4(rest, i);
-                        have_meta = true;
+                    if (qn < FS_FUSED_FINDQ) {
+                        queue[qn * FS_FUSED_THREADS] = (unsigned short)j;
+                        ++qn;
+                    } else {  // queue full (dense crumple): finish this one in place
+                        fs_fused_accept(c, i, j, cnt, phi, ri, have_meta, phase, rest, nlist, near);
                     }
-                    const FsVec4 rj = fs_ld4(rest, j);
-                    if (!fs_pair_allowed(phi, phase[j], ri, rj, c.rad2)) continue;
-                    if (cnt == c.ncap) {
-                        if (j > nlist[(size_t)(c.ncap - 1) * n + i]) continue;
-                        cnt = c.ncap - 1;
-                    }
-                    int s = cnt;
-                    while (s > 0) {
-                        int prev = nlist[(size_t)(s - 1) * n + i];
-                        if (prev < j) break;
-                        nlist[(size_t)s * n + i] = prev;
-                        --s;
-                    }
-                    nlist[(size_t)s * n + i] = j;
-                    ++cnt;
                 }
             }
+    for (int q = 0; q < qn; ++q) {
+        const int j = queue[q * FS_FUSED_THREADS];
+        fs_fused_accept(c, i, j, cnt, phi, ri, have_meta, phase, rest, nlist, near);
+    }
     return cnt;
 }
 
@@ -295,6 +346,26 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
         const fs_gcf g_dict = (fs_gcf)E.dict;
         *(float2 *)(smem + FS_FUSED_OFF_DICT + t * 8) = make_float2(g_dict[2 * t], g_dict[2 * t + 1]);
     }
+    // Is the whole cloth one phase?  Then the per-pair phase / rest-position loads of the neighbour search (dependent
+    // global gathers) collapse into a register test against the packed rest-near ids.
+    const fs_gcu g_near = (fs_gcu)E.restnear_w;
+    int find_mode = 0;
+    {
+        const int ph0 = g_phase[0];
+        int differs = 0;
+        for (int i = t; i < n; i += FS_FUSED_THREADS) differs |= (g_phase[i] != ph0);
+        if (t == 0) wave_tot[0] = 0;
+        __syncthreads();
+        if (differs) atomicOr(&wave_tot[0], 1);
+        __syncthreads();
+        const int mixed = wave_tot[0];
+        __syncthreads();
+        if (!mixed) {
+            if (!(ph0 & FS_PHASE_SELF_COLLIDE)) find_mode = 3;  // same group, no self-collision flag: no pairs at all
+            else if (!(ph0 & FS_PHASE_SELF_COLLIDE_FILTER)) find_mode = 2;
+            else if (E.restnear_ok) find_mode = 1;
+        }
+    }
     // own particles: i = t + k * 1024.  Load positions into X (w = invMass) and X0.
     for (int i = t; i < n; i += FS_FUSED_THREADS) {
         const FsVec4 p = fs_ld4(g_pos, i);
@@ -321,10 +392,16 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             }
             __syncthreads();
             fs_fused_build_grid(c, xp, cursor, items, wave_tot);
-            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad};
+            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode};
 #pragma unroll 1
-            for (int i = t; i < n; i += FS_FUSED_THREADS)
-                g_ncount[i] = fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist);
+            for (int i = t; i < n; i += FS_FUSED_THREADS) {
+                FsNearWords near;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
+                g_ncount[i] = find_mode == 3 ? 0
+                                             : fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist, near,
+                                                                       (unsigned short *)(smem + FS_FUSED_OFF_CSET) + t);
+            }
 
             // ---- contact set.  Candidate counts are very uneven (crumpling sheet: mean 0.8, max ~10 per particle), and a
             // wave walking its lanes' own lists stays in the ~110-instruction contact body for max(count) rounds with a

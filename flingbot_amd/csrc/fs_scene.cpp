@@ -5,6 +5,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <utility>
 
 namespace {
@@ -186,6 +187,54 @@ void build_compact_adjacency(FsHostScene &s) {
     s.dict_size = int(entries.size());
 }
 
+// Rest-near sets with exactly the device's fp32 test: e = rest_i - rest_j, e.x*e.x + e.y*e.y + e.z*e.z < r*r.
+void build_restnear(FsHostScene &s) {
+    const int n = s.n;
+    s.restnear_ok = 0;
+    s.restnear_w.assign(size_t(8) * n, 0xffffffffu);
+    if (n > 65535) return;
+    const float r = s.params.radius + s.params.particleCollisionMargin;
+    const float r2 = r * r;
+    if (!(r > 0.0f)) return;
+    // uniform grid over the rest pose, cell = r
+    std::vector<long long> key(n);
+    std::vector<int> order(n);
+    auto cell = [&](int i, int k) { return (long long)floorf(s.pos[4 * size_t(i) + k] / r); };
+    for (int i = 0; i < n; ++i) {
+        key[i] = ((cell(i, 0) & 0x1fffff) << 42) | ((cell(i, 1) & 0x1fffff) << 21) | (cell(i, 2) & 0x1fffff);
+        order[i] = i;
+    }
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+    std::vector<long long> sorted_keys(n);
+    for (int q = 0; q < n; ++q) sorted_keys[q] = key[order[q]];
+    std::vector<int> found;
+    for (int i = 0; i < n; ++i) {
+        found.clear();
+        const float *ri = &s.pos[4 * size_t(i)];
+        for (long long dx = -1; dx <= 1; ++dx)
+            for (long long dy = -1; dy <= 1; ++dy)
+                for (long long dz = -1; dz <= 1; ++dz) {
+                    const long long k = (((cell(i, 0) + dx) & 0x1fffff) << 42) | (((cell(i, 1) + dy) & 0x1fffff) << 21) |
+                                        ((cell(i, 2) + dz) & 0x1fffff);
+                    auto it = std::lower_bound(sorted_keys.begin(), sorted_keys.end(), k);
+                    for (size_t q = size_t(it - sorted_keys.begin()); q < size_t(n) && sorted_keys[q] == k; ++q) {
+                        const int j = order[q];
+                        if (j == i) continue;
+                        const float *rj = &s.pos[4 * size_t(j)];
+                        const float ex = ri[0] - rj[0], ey = ri[1] - rj[1], ez = ri[2] - rj[2];
+                        const float e2 = ex * ex + ey * ey + ez * ez;
+                        if (e2 < r2) found.push_back(j);
+                    }
+                }
+        if (found.size() > 16) return;  // restnear_ok stays 0
+        for (size_t q = 0; q < found.size(); ++q) {
+            uint32_t &w = s.restnear_w[size_t(q / 2) * n + i];
+            w = (w & ~(0xffffu << (16 * (q % 2)))) | (uint32_t(found[q]) << (16 * (q % 2)));
+        }
+    }
+    s.restnear_ok = 1;
+}
+
 void build_vertex_triangles(FsHostScene &s) {
     s.vt_off.assign(size_t(s.n) + 1, 0);
     for (size_t c = 0; c < s.tris.size(); ++c) s.vt_off[size_t(s.tris[c]) + 1]++;
@@ -288,6 +337,7 @@ std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const 
 
     build_adjacency(s);
     build_compact_adjacency(s);
+    build_restnear(s);
     build_vertex_triangles(s);
     return "";
 }

@@ -42,6 +42,11 @@ struct FsHostScene {
     std::vector<float> dict;        // 2 * 256: (len, k) pairs
     std::vector<uint32_t> code_w;   // [8][n]
     std::vector<uint32_t> nbr_w;    // [8][n]
+    // rest-pose neighbours for the SelfCollideFilter test (NvFlex.h:166,564-565): ids of the particles closer than the
+    // interaction radius in the rest pose, 16 slots of 16 bits packed two per word, [8][n], 0xffff = empty.
+    // restnear_ok = 0 when some particle has more than 16 of them or n > 65535 (the kernels then test rest positions).
+    int restnear_ok = 0;
+    std::vector<uint32_t> restnear_w;
     // vertex -> incident triangles (ascending triangle id), for the vertex-normal gather
     std::vector<int> vt_off, vt_tri;
 };

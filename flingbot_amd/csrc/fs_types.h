@@ -74,5 +74,8 @@ struct FsEnvDev {
     const float *dict;       // [256][2]
     const uint32_t *code_w;  // [8][n]
     const uint32_t *nbr_w;   // [8][n]
+    // rest-pose neighbour ids for the SelfCollideFilter test, packed like nbr_w but holding plain particle ids
+    const uint32_t *restnear_w;  // [8][n], 0xffff = empty
+    int restnear_ok, pad1;
     FsParams p;
 };

@@ -66,6 +66,7 @@ def load_library(build_if_missing=True):
         "fs_get_spring_lengths": (ci, [vp, ci, fp, ci]),
         "fs_get_spring_stiffness": (ci, [vp, ci, fp, ci]),
         "fs_get_params": (ci, [vp, ci, fp, ci]),
+        "fs_set_params": (ci, [vp, ci, fp, ci]),
         "fs_get_scene_bounds": (ci, [vp, ci, fp, fp]),
         "fs_add_sphere": (ci, [vp, ci, cf, fp, fp]),
         "fs_clear_shapes": (ci, [vp, ci]),
@@ -273,6 +274,10 @@ class FlingSim:
 
     def get_params(self, env=0):
         return self._getf("fs_get_params", env, 32)
+
+    def set_params(self, env, table):
+        table = _f(table)
+        self._ck(self.lib.fs_set_params(self.h, env, _fp(table), table.size))
 
     def get_scene_bounds(self, env=0):
         lo, up = np.empty(3, np.float32), np.empty(3, np.float32)

@@ -89,6 +89,9 @@ int fs_get_spring_lengths(fs_ctx *ctx, int env, float *out, int n_floats);
 int fs_get_spring_stiffness(fs_ctx *ctx, int env, float *out, int n_floats);
 /* effective NvFlexParams of the env as a packed float[32] (layout: DESIGN.md "parameter table") */
 int fs_get_params(fs_ctx *ctx, int env, float *out, int n_floats);
+/* overwrite the packed parameter table (same layout as fs_get_params); used for experiments -- FlingBot never changes
+   the solver parameters after set_scene */
+int fs_set_params(fs_ctx *ctx, int env, const float *in, int n_floats);
 /* pyflex.get_scene_lower / get_scene_upper (pyflex.cpp:865-889) */
 int fs_get_scene_bounds(fs_ctx *ctx, int env, float *lower3, float *upper3);
 

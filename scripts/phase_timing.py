@@ -30,3 +30,9 @@ for k in range(12):
     cnt, _ = ctx.get_last_neighbors(0)
     print("C bench scenario steps %3d-%3d: %.3f ms/launch  contacts mean %.2f max %d  maxv %.2f" % (
         10 * k, 10 * k + 10, ms, cnt.mean(), cnt.max(), np.abs(ctx.get_velocities(0)).max()), flush=True)
+# split of one launch into per-substep fixed work (predict, hash, neighbour search, contact set, finalize) and
+# per-iteration work: same crumpled state, iterations 30 vs 2
+for iters in (30, 2):
+    for e in range(E):
+        tab = ctx.get_params(e); tab[0] = iters; ctx.set_params(e, tab)
+    print("D crumpled, %2d iterations: %.3f ms/launch" % (iters, timed(ctx, 5)), flush=True)
