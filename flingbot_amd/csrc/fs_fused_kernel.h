@@ -137,8 +137,11 @@ __device__ __forceinline__ void fs_fused_finalize(const FsFusedConsts &c, FsVec4
 
 // spatial hash of the predicted positions in LDS: histogram -> exclusive scan -> scatter.
 // On return cursor[b] == end of bucket b (start == cursor[b-1]) and items[] holds particle ids grouped by bucket.
+// Also writes XS: the predicted positions in bucket order (SoA, aliasing the X0 region, whose content is parked in
+// global memory during the search), so the candidate scan reads positions sequentially instead of chasing ids.
 __device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, const FsVec4 (&xp)[FS_FUSED_PPT], int *cursor,
-                                                    unsigned short *items, int *wave_tot) {
+                                                    unsigned short *items, int *wave_tot, float *XSx, float *XSy,
+                                                    float *XSz) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int bucket[FS_FUSED_PPT];
 #pragma unroll
@@ -173,6 +176,7 @@ __device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, cons
         if (i < c.n) {
             int slot = atomicAdd(&cursor[bucket[k]], 1);
             items[slot] = (unsigned short)i;
+            XSx[slot] = xp[k].x; XSy[slot] = xp[k].y; XSz[slot] = xp[k].z;
         }
     }
     __syncthreads();
@@ -238,7 +242,9 @@ __device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, in
 __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, const FsVec4 *X,
                                                        const int *cursor, const unsigned short *items, fs_gci phase,
                                                        const FsVec4 *rest, fs_gi nlist, const FsNearWords near,
-                                                       unsigned short *queue /* [FINDQ][blockDim] + threadIdx */) {
+                                                       unsigned short *queue /* [FINDQ][blockDim] + threadIdx */,
+                                                       const float *XSx) {
+    const float *XSy = XSx + FS_FUSED_MAX_PARTICLES, *XSz = XSy + FS_FUSED_MAX_PARTICLES;
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
     int cnt = 0, phi = 0, qn = 0;
     FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -249,26 +255,19 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
                 const int b = fs_fused_bucket(cx + dx, cy + dy, cz + dz);
                 const int beg = (b == 0) ? 0 : cursor[b - 1];
                 const int end = cursor[b];
-                if (beg >= end) continue;
-                // items[] has slack behind the last used entry only up to FS_FUSED_MAX_PARTICLES: clamp the look-ahead
-                int j_cur = items[beg];
-                int j_nxt = items[beg + 1 < FS_FUSED_MAX_PARTICLES ? beg + 1 : beg];
-                FsVec4 x_cur = X[j_cur];
                 for (int q = beg; q < end; ++q) {
-                    const int j = j_cur;
-                    const FsVec4 xj = x_cur;
-                    j_cur = j_nxt;
-                    x_cur = X[j_cur & (FS_FUSED_MAX_PARTICLES - 1)];
-                    j_nxt = items[q + 2 < FS_FUSED_MAX_PARTICLES ? q + 2 : q];
-                    if (j == i) continue;
-                    float ex = xi.x - xj.x, ey = xi.y - xj.y, ez = xi.z - xj.z;
+                    // bucket-ordered copy of the predicted positions: sequential LDS reads, no id -> position chase
+                    const float xjx = XSx[q], xjy = XSy[q], xjz = XSz[q];
+                    float ex = xi.x - xjx, ey = xi.y - xjy, ez = xi.z - xjz;
                     float d2 = ex * ex + ey * ey + ez * ez;
                     if (!(d2 < c.rad2)) continue;
                     // the bucket may alias another cell: take j only from the visit of its own (true) cell, which also
                     // guarantees it is queued at most once
-                    if ((int)floorf(xj.x * c.inv_rad) != cx + dx || (int)floorf(xj.y * c.inv_rad) != cy + dy ||
-                        (int)floorf(xj.z * c.inv_rad) != cz + dz)
+                    if ((int)floorf(xjx * c.inv_rad) != cx + dx || (int)floorf(xjy * c.inv_rad) != cy + dy ||
+                        (int)floorf(xjz * c.inv_rad) != cz + dz)
                         continue;
+                    const int j = items[q];
+                    if (j == i) continue;
                     if (qn < FS_FUSED_FINDQ) {
                         queue[qn * FS_FUSED_THREADS] = (unsigned short)j;
                         ++qn;
@@ -388,10 +387,11 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     const FsVec4 p0 = FsVec4{X0x[i], X0y[i], X0z[i], X[i].w};
                     xp[k] = fs_fused_predict(c, p0, fs_ld4(g_vel, i));
                     X[i] = xp[k];
-                }
+                    fs_st4(E.x0, i, p0);  // X0 is parked in global memory: its LDS holds the bucket-ordered positions
+                }                         // (XS) until the search is over
             }
             __syncthreads();
-            fs_fused_build_grid(c, xp, cursor, items, wave_tot);
+            fs_fused_build_grid(c, xp, cursor, items, wave_tot, X0x, X0y, X0z);
             const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode};
 #pragma unroll 1
             for (int i = t; i < n; i += FS_FUSED_THREADS) {
@@ -400,7 +400,12 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
                 g_ncount[i] = find_mode == 3 ? 0
                                              : fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist, near,
-                                                                       (unsigned short *)(smem + FS_FUSED_OFF_CSET) + t);
+                                                                       (unsigned short *)(smem + FS_FUSED_OFF_CSET) + t, X0x);
+            }
+            __syncthreads();  // every wave is done with XS and the hash
+            for (int i = t; i < n; i += FS_FUSED_THREADS) {  // bring X0 back
+                const FsVec4 p0 = fs_ld4(E.x0, i);
+                X0x[i] = p0.x; X0y[i] = p0.y; X0z[i] = p0.z;
             }
 
             // ---- contact set.  Candidate counts are very uneven (crumpling sheet: mean 0.8, max ~10 per particle), and a
