@@ -64,7 +64,16 @@ __device__ __forceinline__ void fs_st4(FsVec4 *p, size_t i, const FsVec4 v) {
     ((FS_GLOBAL fs_f4 *)p)[i] = fs_f4{v.x, v.y, v.z, v.w};
 }
 
-__device__ __forceinline__ int fs_fused_bucket(int cx, int cy, int cz) { return fs_cell_hash(cx, cy, cz, 12); }
+// Cell -> bucket of the LDS hash.  The row (cy, cz) is hashed, x is added on top: the three cells cx-1..cx+1 a search
+// visits per row are ADJACENT buckets, i.e. one contiguous run of the bucket-ordered arrays (9 runs per particle instead
+// of 27 cells; longer runs also even out the per-lane trip counts of a wave).
+__device__ __forceinline__ int fs_fused_row(int cy, int cz) {
+    const unsigned h = (unsigned)cy * 0x85EBCA77u + (unsigned)cz * 0xC2B2AE3Du;
+    return (int)((h ^ (h >> 15)) * 0x2C1B3C6Du >> 20);  // 12 bits = log2(FS_FUSED_BUCKETS)
+}
+__device__ __forceinline__ int fs_fused_bucket(int cx, int cy, int cz) {
+    return (fs_fused_row(cy, cz) + cx) & (FS_FUSED_BUCKETS - 1);
+}
 
 // Scalars of one episode, read once (uniform => SGPRs) so the hot loops never reload them through the descriptor.
 struct FsFusedConsts {
@@ -192,14 +201,65 @@ struct FsFindConsts {  // by value: a reference would force the caller's constan
 struct FsNearWords {  // rest-near ids of one particle, by value (registers)
     uint32_t w[8];
 };
-#define FS_FUSED_FINDQ 8  // per-thread queue depth (u16 ids) of the two-phase neighbour search, aliases the contact set
+ #ifdef FS_TIMING
+__device__ unsigned long long fs_dbg_cnt[8];
+#define FS_DBG_COUNT(k, v)                                                                                   \
+    if (blockIdx.x == 0) {                                                                                   \
+        const int l_ = threadIdx.x & 63;                                                                     \
+        if (__builtin_amdgcn_readfirstlane(l_) == l_) atomicAdd(&fs_dbg_cnt[k], (unsigned long long)(v));   \
+    }
+#define FS_DBG_LANE(k, v) \
+    if (blockIdx.x == 0) atomicAdd(&fs_dbg_cnt[k], (unsigned long long)(v));
+#else
+#define FS_DBG_COUNT(k, v)
+#define FS_DBG_LANE(k, v)
+#endif
+#ifdef FS_TIMING_COUNTS  // trip / candidate counters inside the search loops (their atomics distort the timers)
+#define FS_CNT_WAVE(k, v) FS_DBG_COUNT(k, v)
+#define FS_CNT_LANE(k, v) FS_DBG_LANE(k, v)
+#else
+#define FS_CNT_WAVE(k, v)
+#define FS_CNT_LANE(k, v)
+#endif
+#define FS_FUSED_FINDQ 32  // per-thread queue depth (u16 entries) of the two-phase neighbour search; the queue aliases X,
+                           // which is dead during the search (the predicted positions sit in XS and in their owners' registers)
 
-// Second half of the search for one candidate j that passed the distance and true-cell tests: phase / rest-pose
-// filter, sorted insertion.
-__device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, int j, int &cnt, int &phi, FsVec4 &ri,
+// The neighbour list of the particle being searched, while it is built: the FOUR smallest accepted ids live in
+// registers (ascending, FS_NB_EMPTY padded), only what does not fit there goes to the global list (from slot 4 on, every
+// element larger than the four staged ones).  A crumpling sheet has < 1 real contact per particle on average, so the
+// dependent global read-modify-write chains of an in-memory insertion sort are gone from the common path; the staged
+// ids are stored once at the end.
+#define FS_NB_EMPTY 0x7fffffff
+struct FsNbList {
+    int a0, a1, a2, a3;  // ascending; FS_NB_EMPTY = free
+    int gcnt;            // elements in the global part (slots 4 .. 4 + gcnt - 1)
+};
+
+// sorted insertion into the global part: ascending ids, at most `gcap` kept; an id already present is not inserted again
+__device__ __forceinline__ void fs_fused_global_insert(int n, int i, int j, int gcap, int &gcnt, fs_gi nlist) {
+    if (gcap <= 0) return;
+    fs_gi list = nlist + (size_t)4 * n + i;
+    int s = gcnt, prev = -1;
+    while (s > 0) {
+        prev = list[(size_t)(s - 1) * n];
+        if (prev <= j) break;
+        --s;
+    }
+    if (s > 0 && prev == j) return;
+    if (gcnt == gcap) {
+        if (s == gcap) return;
+        gcnt = gcap - 1;
+    }
+    for (int u = gcnt; u > s; --u) list[(size_t)u * n] = list[(size_t)(u - 1) * n];
+    list[(size_t)s * n] = j;
+    ++gcnt;
+}
+
+// Second half of the search for one candidate j that passed the distance test: phase / rest-pose filter, then sorted,
+// duplicate-free insertion (a particle can be met twice: its bucket may lie in two of the visited runs when rows alias).
+__device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, int j, FsNbList &L, int &phi, FsVec4 &ri,
                                                 bool &have_meta, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
                                                 const FsNearWords &near) {
-    const int n = c.n;
     if (c.mode == 0) {  // general: phases and rest positions from global memory, per pair
         if (!have_meta) {
             phi = phase[i];
@@ -218,69 +278,125 @@ __device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, in
         }
         if (hit) return;
     }
-    if (cnt == c.ncap) {
-        if (j > nlist[(size_t)(c.ncap - 1) * n + i]) return;
-        cnt = c.ncap - 1;
+    if ((j == L.a0) | (j == L.a1) | (j == L.a2) | (j == L.a3)) return;
+    const int gcap = c.ncap - 4;
+    if (j > L.a3) {  // staged part full and j beyond it (L.a3 == FS_NB_EMPTY otherwise)
+        fs_fused_global_insert(c.n, i, j, gcap, L.gcnt, nlist);
+        return;
     }
-    int s = cnt;
-    while (s > 0) {
-        int prev = nlist[(size_t)(s - 1) * n + i];
-        if (prev < j) break;
-        nlist[(size_t)s * n + i] = prev;
-        --s;
-    }
-    nlist[(size_t)s * n + i] = j;
-    ++cnt;
+    int t = j, lo;
+    lo = min(L.a0, t); t = max(L.a0, t); L.a0 = lo;
+    lo = min(L.a1, t); t = max(L.a1, t); L.a1 = lo;
+    lo = min(L.a2, t); t = max(L.a2, t); L.a2 = lo;
+    lo = min(L.a3, t); t = max(L.a3, t); L.a3 = lo;
+    if (t != FS_NB_EMPTY) fs_fused_global_insert(c.n, i, t, gcap, L.gcnt, nlist);  // displaced: larger than all staged
+}
+
+// stores the staged ids; returns the list length
+__device__ __forceinline__ int fs_fused_nb_finish(const FsFindConsts &c, int i, const FsNbList &L, fs_gi nlist) {
+    const int st = (L.a0 != FS_NB_EMPTY) + (L.a1 != FS_NB_EMPTY) + (L.a2 != FS_NB_EMPTY) + (L.a3 != FS_NB_EMPTY);
+    const size_t n = (size_t)c.n;
+    if (st > 0) nlist[i] = L.a0;
+    if (st > 1) nlist[n + i] = L.a1;
+    if (st > 2) nlist[2 * n + i] = L.a2;
+    if (st > 3) nlist[3 * n + i] = L.a3;
+    const int total = st + L.gcnt;
+    return total < c.ncap ? total : c.ncap;
 }
 
 // Two-phase search.  Lanes hit their few real neighbours at different trips of the candidate loop, so with the accept
-// code inside that loop nearly every trip drags the whole wave through it.  Phase A only filters by distance and true
-// cell and parks the survivors (8-9 for a flat sheet) in a per-thread LDS queue; phase B walks the queue, where all lanes
-// have work at the same time.  The candidate loop is software-pipelined: the id two candidates ahead and the position
-// one candidate ahead are requested from LDS before the current candidate is tested (the chain id -> position ->
-// distance is otherwise two exposed LDS latencies per trip).
-__device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, const FsVec4 *X,
-                                                       const int *cursor, const unsigned short *items, fs_gci phase,
-                                                       const FsVec4 *rest, fs_gi nlist, const FsNearWords near,
-                                                       unsigned short *queue /* [FINDQ][blockDim] + threadIdx */,
-                                                       const float *XSx) {
-    const float *XSy = XSx + FS_FUSED_MAX_PARTICLES, *XSz = XSy + FS_FUSED_MAX_PARTICLES;
+// code inside that loop nearly every trip drags the whole wave through it (a wave of 64 lanes has a distance hit in
+// almost every trip: the 8 mesh neighbours of every cloth particle are always in range).
+//   Phase A scans the runs FOUR candidates per trip from the bucket-ordered position copy XS (three aligned 16-byte
+//   LDS reads) and does nothing but the distance test; a trip with hits parks ONE packed entry (run slot | 4-bit hit
+//   mask) in a per-thread LDS queue.
+//   Phase B walks the queue, where all lanes have work at the same time: id lookup, self / rest-pose filter, sorted
+//   insertion.
+typedef __attribute__((address_space(3))) const int *fs_lci;
+typedef __attribute__((address_space(3))) const float *fs_lcf;
+typedef __attribute__((address_space(3))) const fs_f4 *fs_lcf4;
+typedef __attribute__((address_space(3))) const unsigned short *fs_lcus;
+typedef __attribute__((address_space(3))) unsigned short *fs_lus;
+
+__device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int &qn, FsNbList &L, int &phi, FsVec4 &ri,
+                                               bool &have_meta, fs_lcus items, fs_lus queue, fs_gci phase,
+                                               const FsVec4 *rest, fs_gi nlist, const FsNearWords &near) {
+    for (int e = 0; e < qn; ++e) {
+        FS_CNT_WAVE(4, 1)  // wave-level phase-B trips
+        const unsigned u = queue[e * FS_FUSED_THREADS];
+        unsigned m = u & 15u;
+        const int qb = (int)(u >> 4) << 2;
+        while (m) {
+            FS_CNT_WAVE(5, 1)  // wave-level phase-B candidate trips
+            const int j = items[qb + __builtin_ctz(m)];
+            m &= m - 1u;
+            if (j == i) continue;
+            FS_CNT_LANE(3, 1)  // lane-level survivors
+            fs_fused_accept(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
+        }
+    }
+    qn = 0;
+}
+
+__device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, fs_lci cursor,
+                                                       fs_lcus items, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
+                                                       const FsNearWords near,
+                                                       fs_lus queue /* [FINDQ][blockDim] + threadIdx */, fs_lcf XSx) {
+    fs_lcf XSy = XSx + FS_FUSED_MAX_PARTICLES, XSz = XSy + FS_FUSED_MAX_PARTICLES;
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
-    int cnt = 0, phi = 0, qn = 0;
+    int phi = 0, qn = 0;
+    FsNbList L = {FS_NB_EMPTY, FS_NB_EMPTY, FS_NB_EMPTY, FS_NB_EMPTY, 0};
     FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
     bool have_meta = false;
+#ifdef FS_TIMING
+    const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int b = fs_fused_bucket(cx + dx, cy + dy, cz + dz);
-                const int beg = (b == 0) ? 0 : cursor[b - 1];
-                const int end = cursor[b];
-                for (int q = beg; q < end; ++q) {
-                    // bucket-ordered copy of the predicted positions: sequential LDS reads, no id -> position chase
-                    const float xjx = XSx[q], xjy = XSy[q], xjz = XSz[q];
-                    float ex = xi.x - xjx, ey = xi.y - xjy, ez = xi.z - xjz;
-                    float d2 = ex * ex + ey * ey + ez * ez;
-                    if (!(d2 < c.rad2)) continue;
-                    // the bucket may alias another cell: take j only from the visit of its own (true) cell, which also
-                    // guarantees it is queued at most once
-                    if ((int)floorf(xjx * c.inv_rad) != cx + dx || (int)floorf(xjy * c.inv_rad) != cy + dy ||
-                        (int)floorf(xjz * c.inv_rad) != cz + dz)
-                        continue;
-                    const int j = items[q];
-                    if (j == i) continue;
-                    if (qn < FS_FUSED_FINDQ) {
-                        queue[qn * FS_FUSED_THREADS] = (unsigned short)j;
+        for (int dy = -1; dy <= 1; ++dy) {
+            // buckets b0, b0+1, b0+2 (mod BUCKETS) hold the cells (cx-1..cx+1, cy+dy, cz+dz): one run, or two when the
+            // triple wraps around the end of the table.  Whatever else hashes into the run is rejected by distance.
+            const int b0 = (fs_fused_row(cy + dy, cz + dz) + cx - 1) & (FS_FUSED_BUCKETS - 1);
+            const int wrap = b0 + 2 - (FS_FUSED_BUCKETS - 1);  // > 0: that many buckets continue at bucket 0
+            for (int seg = 0; seg < 2; ++seg) {
+                int beg, end;
+                if (seg == 0) {
+                    beg = (b0 == 0) ? 0 : cursor[b0 - 1];
+                    end = cursor[wrap > 0 ? FS_FUSED_BUCKETS - 1 : b0 + 2];
+                } else {
+                    if (wrap <= 0) break;
+                    beg = 0;
+                    end = cursor[wrap - 1];
+                }
+                FS_CNT_WAVE(0, 1)          // wave-level run visits
+                FS_CNT_LANE(2, end - beg)  // lane-level candidates
+                for (int q = beg & ~3; q < end; q += 4) {
+                    FS_CNT_WAVE(1, 1)      // wave-level candidate trips
+                    const fs_f4 ax = *(fs_lcf4)(XSx + q), ay = *(fs_lcf4)(XSy + q), az = *(fs_lcf4)(XSz + q);
+                    const fs_f4 ex = xi.x - ax, ey = xi.y - ay, ez = xi.z - az;
+                    const fs_f4 d2 = ex * ex + ey * ey + ez * ez;
+                    unsigned m = (unsigned)(d2.x < c.rad2) | ((unsigned)(d2.y < c.rad2) << 1) |
+                                 ((unsigned)(d2.z < c.rad2) << 2) | ((unsigned)(d2.w < c.rad2) << 3);
+                    // slots of this group that belong to the run: [beg - q, end - q) clipped to [0, 4)
+                    const int lo = beg - q > 0 ? beg - q : 0, hi = end - q < 4 ? end - q : 4;
+                    m &= ((1u << (hi - lo)) - 1u) << lo;
+                    if (m) {
+                        if (qn == FS_FUSED_FINDQ)  // queue full (dense crumple): work it off first
+                            fs_fused_drain(c, i, qn, L, phi, ri, have_meta, items, queue, phase, rest, nlist, near);
+                        queue[qn * FS_FUSED_THREADS] = (unsigned short)(((unsigned)q << 2) | m);
                         ++qn;
-                    } else {  // queue full (dense crumple): finish this one in place
-                        fs_fused_accept(c, i, j, cnt, phi, ri, have_meta, phase, rest, nlist, near);
                     }
                 }
             }
-    for (int q = 0; q < qn; ++q) {
-        const int j = queue[q * FS_FUSED_THREADS];
-        fs_fused_accept(c, i, j, cnt, phi, ri, have_meta, phase, rest, nlist, near);
-    }
-    return cnt;
+        }
+#ifdef FS_TIMING
+    const unsigned long long tf1 = __builtin_amdgcn_s_memtime();
+    FS_DBG_COUNT(6, tf1 - tf0)
+#endif
+    fs_fused_drain(c, i, qn, L, phi, ri, have_meta, items, queue, phase, rest, nlist, near);
+#ifdef FS_TIMING
+    FS_DBG_COUNT(7, __builtin_amdgcn_s_memtime() - tf1)
+#endif
+    return fs_fused_nb_finish(c, i, L, nlist);
 }
 
 // planes + kinematic spheres for one particle
@@ -324,6 +440,18 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     unsigned short *items = (unsigned short *)(smem + FS_FUSED_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FS_FUSED_OFF_SCAN);
 
+#ifdef FS_TIMING  // developer build: per-section shader-clock totals of block 0's waves, printed at the end
+    unsigned long long ts_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#define FS_TS(k)                                                     \
+    {                                                                \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        ts_acc[k] += now - ts_last;                                  \
+        ts_last = now;                                               \
+    }
+#else
+#define FS_TS(k)
+#endif
     const int e = ids[blockIdx.x];
     const FsEnvDev &E = envs[e];
     const FsShapesDev &sh = shapes[e];
@@ -372,6 +500,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
         X0x[i] = p.x; X0y[i] = p.y; X0z[i] = p.z;
     }
 
+    FS_TS(0)
 #pragma unroll 1
     for (int frame = 0; frame < n_steps; ++frame) {
 #pragma unroll 1
@@ -386,26 +515,39 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 if (i < n) {
                     const FsVec4 p0 = FsVec4{X0x[i], X0y[i], X0z[i], X[i].w};
                     xp[k] = fs_fused_predict(c, p0, fs_ld4(g_vel, i));
-                    X[i] = xp[k];
                     fs_st4(E.x0, i, p0);  // X0 is parked in global memory: its LDS holds the bucket-ordered positions
                 }                         // (XS) until the search is over
             }
             __syncthreads();
             fs_fused_build_grid(c, xp, cursor, items, wave_tot, X0x, X0y, X0z);
+            FS_TS(1)
             const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode};
+            // Particles are searched in BUCKET order (lane <-> slot of the sorted copy): the lanes of one cell walk the
+            // same 27 buckets with the same trip counts and read the same LDS words (broadcast, no bank conflicts);
+            // in id order every lane of a wave walked different buckets and the scan was LDS-conflict bound.
 #pragma unroll 1
-            for (int i = t; i < n; i += FS_FUSED_THREADS) {
+            for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
+                const int i = items[qs];
                 FsNearWords near;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
+                const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
                 g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors(fc, i, X[i], X, cursor, items, g_phase, g_rest, g_nlist, near,
-                                                                       (unsigned short *)(smem + FS_FUSED_OFF_CSET) + t, X0x);
+                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lci)cursor, (fs_lcus)items, g_phase,
+                                                                       g_rest, g_nlist, near,
+                                                                       (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
             }
+            FS_TS(2)
             __syncthreads();  // every wave is done with XS and the hash
-            for (int i = t; i < n; i += FS_FUSED_THREADS) {  // bring X0 back
-                const FsVec4 p0 = fs_ld4(E.x0, i);
-                X0x[i] = p0.x; X0y[i] = p0.y; X0z[i] = p0.z;
+            FS_TS(3)
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {  // the predicted positions become the first iterate; bring X0 back
+                const int i = t + k * FS_FUSED_THREADS;
+                if (i < n) {
+                    X[i] = xp[k];
+                    const FsVec4 p0 = fs_ld4(E.x0, i);
+                    X0x[i] = p0.x; X0y[i] = p0.y; X0z[i] = p0.z;
+                }
             }
 
             // ---- contact set.  Candidate counts are very uneven (crumpling sheet: mean 0.8, max ~10 per particle), and a
@@ -461,6 +603,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = g_nlist[(unsigned)q * un + (unsigned)i2];
             }
 
+            FS_TS(4)
             // ---- Jacobi iterations: gather from X, new positions in rotating registers, barrier, publish, barrier
 #pragma unroll 1
             for (int it = 0; it < c.iters; ++it) {
@@ -524,6 +667,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                             }
                         }
                     }
+                    FS_TS(5)
                     // Prefetch for the thread's NEXT particle, issued here -- after the spring block, whose working set is
                     // dead by now -- and consumed at the top of the next trip: the contact / shape / apply section plus
                     // the other three waves of the SIMD cover the L2 latency.  (Issued at the top of the body the 17
@@ -578,8 +722,10 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     cnt = cnt_n;
 #pragma unroll
                     for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj_n[q];
+                    FS_TS(6)
                 }
                 __syncthreads();
+                FS_TS(7)
                 // ---- pass 2: finish the contact-set particle of this thread
                 float n2x = 0.0f, n2y = 0.0f, n2z = 0.0f;
                 if (i2 >= 0) {
@@ -614,7 +760,9 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fs_apply(a, c.relax, n2x, n2y, n2z);
                 }
+                FS_TS(8)
                 __syncthreads();  // every read of the old iterate is done
+                FS_TS(9)
 #pragma unroll
                 for (int q = 0; q < FS_FUSED_PPT; ++q) {  // particle q of the thread sits in slot PPT-1-q
                     const int i = t + q * FS_FUSED_THREADS;
@@ -623,6 +771,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 }
                 if (i2 >= 0) { FsVec4 &d = X[i2]; d.x = n2x; d.y = n2y; d.z = n2z; }
                 __syncthreads();
+                FS_TS(10)
             }
             // ---- finalize: new velocity to global, new substep-start position into X0 (own entries only; every other
             //      thread is past the last iteration barrier and reads X0 again only after the next predict barrier)
@@ -637,4 +786,14 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
         }
     }
     for (int i = t; i < n; i += FS_FUSED_THREADS) fs_st4(g_pos, i, FsVec4{X0x[i], X0y[i], X0z[i], X[i].w});
+#ifdef FS_TIMING
+    FS_TS(11)
+    if (blockIdx.x == 0 && t == 0)
+        printf("DBG cellvisits(wave) %llu trips(wave) %llu candidates(lane) %llu survivors(lane) %llu phaseB trips(wave) %llu phaseB candidate trips(wave) %llu cyclesA %llu cyclesB %llu\n",
+               fs_dbg_cnt[0], fs_dbg_cnt[1], fs_dbg_cnt[2], fs_dbg_cnt[3], fs_dbg_cnt[4], fs_dbg_cnt[5], fs_dbg_cnt[6], fs_dbg_cnt[7]);
+    if (blockIdx.x == 0 && (t & 63) == 0)
+        printf("TS wave %2d: init %llu grid %llu find %llu findwait %llu cset %llu springs %llu rest %llu bar1 %llu pass2 %llu bar2 %llu publish %llu final %llu\n",
+               t >> 6, ts_acc[0], ts_acc[1], ts_acc[2], ts_acc[3], ts_acc[4], ts_acc[5], ts_acc[6], ts_acc[7], ts_acc[8],
+               ts_acc[9], ts_acc[10], ts_acc[11]);
+#endif
 }
