@@ -321,19 +321,24 @@ typedef __attribute__((address_space(3))) unsigned short *fs_lus;
 __device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int &qn, FsNbList &L, int &phi, FsVec4 &ri,
                                                bool &have_meta, fs_lcus items, fs_lus queue, fs_gci phase,
                                                const FsVec4 *rest, fs_gi nlist, const FsNearWords &near) {
-    for (int e = 0; e < qn; ++e) {
-        FS_CNT_WAVE(4, 1)  // wave-level phase-B trips
-        const unsigned u = queue[e * FS_FUSED_THREADS];
-        unsigned m = u & 15u;
-        const int qb = (int)(u >> 4) << 2;
-        while (m) {
-            FS_CNT_WAVE(5, 1)  // wave-level phase-B candidate trips
-            const int j = items[qb + __builtin_ctz(m)];
-            m &= m - 1u;
-            if (j == i) continue;
-            FS_CNT_LANE(3, 1)  // lane-level survivors
-            fs_fused_accept(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
+    // one survivor per lane and trip: the next packed entry is fetched in the trip that finds the current one used up,
+    // so the trip count is the largest SURVIVOR count of the wave, not (most entries) x (most hits per entry)
+    int e = 0, qb = 0;
+    unsigned m = 0u;
+    for (;;) {
+        if (!m) {
+            if (e == qn) break;
+            const unsigned u = queue[e * FS_FUSED_THREADS];
+            ++e;
+            m = u & 15u;
+            qb = (int)(u >> 4) << 2;
         }
+        FS_CNT_WAVE(5, 1)  // wave-level phase-B candidate trips
+        const int j = items[qb + __builtin_ctz(m)];
+        m &= m - 1u;
+        if (j == i) continue;
+        FS_CNT_LANE(3, 1)  // lane-level survivors
+        fs_fused_accept(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
     }
     qn = 0;
 }
