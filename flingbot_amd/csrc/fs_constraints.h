@@ -4,7 +4,8 @@
 // position delta to an accumulator and bumps a counter; the particle then moves by relaxationFactor * delta / count.
 // Accumulation order per particle is fixed (springs by ascending spring id, particle contacts by ascending
 // neighbour id, planes, spheres) and the build uses -ffp-contract=off, so results do not depend on the launch
-// geometry and are reproducible bit for bit.
+// geometry and are reproducible bit for bit.  Fused multiply-adds appear exactly where the specification (and the CPU
+// oracle, with fmaf) spells them out: FS_FMA / fs_dot3 below -- the compiler never contracts on its own.
 //
 // Semantics: distance constraints NvFlex.h:656-667, solidRestDistance :101, particleFriction :107, inelastic
 // particle contacts :108, collisionDistance :145, dynamic/static friction :105-106, planes :149, shapes :941-987.
@@ -20,16 +21,22 @@ struct FsAcc {
     int cnt;
 };
 
-// Reciprocal square root for every length inside the constraint sweeps: integer seed + three Newton steps, a fixed
-// sequence of IEEE fp32 multiplies / subtracts (max error 2.5 ulp).  Being a pure function of add/mul it gives the
-// same bits on the CPU oracle and on the GPU, and replaces the ~30 instruction correctly-rounded sqrt + divide
-// sequences (two quarter-rate ops among them) by 15 full-rate VALU ops.
+#define FS_FMA(a, b, c) __builtin_fmaf((a), (b), (c))  // one rounding, v_fma_f32; the oracle uses fmaf()
+// a . b = fma(az, bz, fma(ay, by, ax * bx))
+__device__ __forceinline__ float fs_dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return FS_FMA(az, bz, FS_FMA(ay, by, ax * bx));
+}
+
+// Reciprocal square root for every length inside the constraint sweeps: integer seed + three Newton steps
+// y <- y * fma(-(x/2 * y), y, 3/2), a fixed sequence of IEEE fp32 operations (max error ~2 ulp).  Being a pure function
+// of mul / fma it gives the same bits on the CPU oracle and on the GPU, and replaces the ~30 instruction
+// correctly-rounded sqrt + divide sequences (two quarter-rate ops among them) by 12 full-rate VALU ops.
 __device__ __forceinline__ float fs_rsqrt(float x) {
     float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
     const float xh = 0.5f * x;
-    y = y * (1.5f - (xh * y) * y);
-    y = y * (1.5f - (xh * y) * y);
-    y = y * (1.5f - (xh * y) * y);
+    y = y * FS_FMA(-(xh * y), y, 1.5f);
+    y = y * FS_FMA(-(xh * y), y, 1.5f);
+    y = y * FS_FMA(-(xh * y), y, 1.5f);
     return y;
 }
 
@@ -53,7 +60,7 @@ __device__ __forceinline__ float fs_mass_ratio(float wi, float wj) {
 __device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float xi2, float wi, const FsVec4 xj, float L,
                                           float k) {
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
-    float l2 = ex * ex + ey * ey + ez * ez;
+    float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float inv_len = fs_rsqrt(l2);
     float len = l2 * inv_len;
     if (!(len > 0.0f)) return;
@@ -64,9 +71,9 @@ __device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float 
     }
     float ratio = fs_mass_ratio(wi, xj.w);
     float sc = (k * ratio) * (C * inv_len);
-    a.d0 = a.d0 - ex * sc;
-    a.d1 = a.d1 - ey * sc;
-    a.d2 = a.d2 - ez * sc;
+    a.d0 = FS_FMA(-ex, sc, a.d0);
+    a.d1 = FS_FMA(-ey, sc, a.d1);
+    a.d2 = FS_FMA(-ez, sc, a.d2);
     a.cnt++;
 }
 
@@ -76,7 +83,7 @@ __device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float 
 __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, float xi2, float wi, const FsVec4 xj, float L,
                                              float k) {
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
-    float l2 = ex * ex + ey * ey + ez * ez;
+    float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float inv_len = fs_rsqrt(l2);
     float len = l2 * inv_len;
     float C = len - L;
@@ -93,12 +100,12 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
         const bool odd = active & (wj != wi) & (wj != 0.0f);
         if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
     }
-    // an inactive constraint contributes sc = +0: d - e * 0 == d for every finite e (the accumulators start at +0
+    // an inactive constraint contributes sc = +0: fma(-e, 0, d) == d for every finite e (the accumulators start at +0
     // and can never become -0), so one select on the scale replaces three on the accumulators
     float sc = active ? (kk * ratio) * (C * inv_len) : 0.0f;
-    a.d0 = a.d0 - ex * sc;
-    a.d1 = a.d1 - ey * sc;
-    a.d2 = a.d2 - ez * sc;
+    a.d0 = FS_FMA(-ex, sc, a.d0);
+    a.d1 = FS_FMA(-ey, sc, a.d1);
+    a.d2 = FS_FMA(-ez, sc, a.d2);
     a.cnt += active ? 1 : 0;
 }
 
@@ -107,7 +114,7 @@ __device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float x
                                                     float ri1, float ri2, const FsVec4 xj, float rj0, float rj1,
                                                     float rj2, float restd, float restd2, float mu) {
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
-    float l2 = ex * ex + ey * ey + ez * ez;
+    float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     if (!(l2 < restd2)) return;
     float inv = fs_rsqrt(l2);
     float dist = l2 * inv;
@@ -123,14 +130,14 @@ __device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float x
     float c0 = nx * cn, c1 = ny * cn, c2 = nz * cn;
     if (mu > 0.0f) {
         float rx = ri0 - rj0, ry = ri1 - rj1, rz = ri2 - rj2;
-        float rn = rx * nx + ry * ny + rz * nz;
-        float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
-        float tl2 = tx * tx + ty * ty + tz * tz;
+        float rn = fs_dot3(rx, ry, rz, nx, ny, nz);
+        float tx = FS_FMA(-nx, rn, rx), ty = FS_FMA(-ny, rn, ry), tz = FS_FMA(-nz, rn, rz);
+        float tl2 = fs_dot3(tx, ty, tz, tx, ty, tz);
         if (tl2 > 0.0f) {
             float inv_tl = fs_rsqrt(tl2);
             float tl = tl2 * inv_tl;
             float fs = fs_friction_scale(tl, inv_tl, pen, mu, mu) * ratio;
-            c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+            c0 = FS_FMA(-tx, fs, c0); c1 = FS_FMA(-ty, fs, c1); c2 = FS_FMA(-tz, fs, c2);
         }
     }
     a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
@@ -140,18 +147,18 @@ __device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float x
 __device__ __forceinline__ void fs_plane_contact(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
                                                  float ri2, float p0, float p1, float p2, float p3, float cd, float mu_s,
                                                  float mu_k) {
-    float sdist = p0 * xi0 + p1 * xi1 + p2 * xi2 + p3;
+    float sdist = fs_dot3(p0, p1, p2, xi0, xi1, xi2) + p3;
     if (!(sdist < cd)) return;
     float pen = cd - sdist;
     float c0 = p0 * pen, c1 = p1 * pen, c2 = p2 * pen;
-    float rn = ri0 * p0 + ri1 * p1 + ri2 * p2;
-    float tx = ri0 - p0 * rn, ty = ri1 - p1 * rn, tz = ri2 - p2 * rn;
-    float tl2 = tx * tx + ty * ty + tz * tz;
+    float rn = fs_dot3(ri0, ri1, ri2, p0, p1, p2);
+    float tx = FS_FMA(-p0, rn, ri0), ty = FS_FMA(-p1, rn, ri1), tz = FS_FMA(-p2, rn, ri2);
+    float tl2 = fs_dot3(tx, ty, tz, tx, ty, tz);
     if (tl2 > 0.0f) {
         float inv_tl = fs_rsqrt(tl2);
         float tl = tl2 * inv_tl;
         float fs = fs_friction_scale(tl, inv_tl, pen, mu_s, mu_k);
-        c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+        c0 = FS_FMA(-tx, fs, c0); c1 = FS_FMA(-ty, fs, c1); c2 = FS_FMA(-tz, fs, c2);
     }
     a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
     a.cnt++;
@@ -162,7 +169,7 @@ __device__ __forceinline__ void fs_sphere_contact(FsAcc &a, float xi0, float xi1
                                                   float ri2, float c0_, float c1_, float c2_, float r, float s0,
                                                   float s1, float s2, float cd, float mu_s, float mu_k) {
     float ex = xi0 - c0_, ey = xi1 - c1_, ez = xi2 - c2_;
-    float l2 = ex * ex + ey * ey + ez * ez;
+    float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float lim = r + cd;
     if (!(l2 < lim * lim)) return;
     float inv = fs_rsqrt(l2);
@@ -176,14 +183,14 @@ __device__ __forceinline__ void fs_sphere_contact(FsAcc &a, float xi0, float xi1
     float pen = lim - dist;
     float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
     float rx = ri0 - s0, ry = ri1 - s1, rz = ri2 - s2;
-    float rn = rx * nx + ry * ny + rz * nz;
-    float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
-    float tl2 = tx * tx + ty * ty + tz * tz;
+    float rn = fs_dot3(rx, ry, rz, nx, ny, nz);
+    float tx = FS_FMA(-nx, rn, rx), ty = FS_FMA(-ny, rn, ry), tz = FS_FMA(-nz, rn, rz);
+    float tl2 = fs_dot3(tx, ty, tz, tx, ty, tz);
     if (tl2 > 0.0f) {
         float inv_tl = fs_rsqrt(tl2);
         float tl = tl2 * inv_tl;
         float fs = fs_friction_scale(tl, inv_tl, pen, mu_s, mu_k);
-        c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+        c0 = FS_FMA(-tx, fs, c0); c1 = FS_FMA(-ty, fs, c1); c2 = FS_FMA(-tz, fs, c2);
     }
     a.d0 = a.d0 + c0; a.d1 = a.d1 + c1; a.d2 = a.d2 + c2;
     a.cnt++;
@@ -219,7 +226,7 @@ __device__ __forceinline__ void fs_shape_contacts(FsAcc &a, float xi0, float xi1
 __device__ __forceinline__ void fs_apply(const FsAcc &a, float relax, float &x0, float &x1, float &x2) {
     if (a.cnt > 0) {
         float sc = relax / (float)a.cnt;
-        x0 = x0 + a.d0 * sc; x1 = x1 + a.d1 * sc; x2 = x2 + a.d2 * sc;
+        x0 = FS_FMA(a.d0, sc, x0); x1 = FS_FMA(a.d1, sc, x1); x2 = FS_FMA(a.d2, sc, x2);
     }
 }
 

@@ -12,8 +12,21 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
 def oracle_lib_path():
-    return os.path.join(_HERE, "liboracle.so")
+    """liboracle_fma.so (fmaf inlined as the hardware instruction) when this CPU has FMA, else the libm-fmaf build.
+    Both give the same bits."""
+    return os.path.join(_HERE, "liboracle_fma.so" if _cpu_has_fma() else "liboracle.so")
 
 
 def build_oracle(force=False):
@@ -22,7 +35,7 @@ def build_oracle(force=False):
     lib = oracle_lib_path()
     stale = force or not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so", "liboracle_fma.so"])
     if os.path.isdir("/root/reference/PyFlex/core") and os.path.exists(os.path.join(_HERE, "ref_camera_probe.cpp")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "_ref/camera_ref"])
     return lib

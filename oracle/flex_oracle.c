@@ -393,9 +393,10 @@ static void find_neighbors(orc_sim *s) {
 }
 
 /* Reciprocal square root used for every length inside the constraint sweeps: classic integer seed + three Newton
-   steps, i.e. a fixed sequence of IEEE fp32 multiplies / subtracts (max error 2.5 ulp).  [I] The closed-source
-   reference certainly uses a hardware approximation here; spelling the approximation out in basic IEEE operations
-   makes the result a pure function of add/mul, identical on the CPU and on the GPU without libm or divide sequences. */
+   steps y <- y * fma(-(x/2 * y), y, 3/2), i.e. a fixed sequence of IEEE fp32 multiplies / fused multiply-adds (max
+   error ~2 ulp).  [I] The closed-source reference certainly uses a hardware approximation here; spelling the
+   approximation out in basic IEEE operations makes the result a pure function of mul/fma, identical on the CPU and on
+   the GPU without libm square roots or divide sequences. */
 #include <stdint.h>
 static inline float orc_rsqrt(float x) {
     union { float f; uint32_t u; } v;
@@ -403,10 +404,16 @@ static inline float orc_rsqrt(float x) {
     v.u = 0x5f3759dfu - (v.u >> 1);
     float y = v.f;
     const float xh = 0.5f * x;
-    y = y * (1.5f - (xh * y) * y);
-    y = y * (1.5f - (xh * y) * y);
-    y = y * (1.5f - (xh * y) * y);
+    y = y * fmaf(-(xh * y), y, 1.5f);
+    y = y * fmaf(-(xh * y), y, 1.5f);
+    y = y * fmaf(-(xh * y), y, 1.5f);
     return y;
+}
+
+/* a . b with two fused multiply-adds -- the constraint sweeps use fmaf exactly where the specification says so (the
+   build keeps -ffp-contract=off, so nothing else is ever fused); the HIP kernels use v_fma_f32 at the same places. */
+static inline float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return fmaf(az, bz, fmaf(ay, by, ax * bx));
 }
 
 /* friction on a contact: t = tangential relative displacement since substep start (length tl = tl2 * inv_tl),
@@ -473,7 +480,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 int j = (s->sidx[2 * e] == i) ? s->sidx[2 * e + 1] : s->sidx[2 * e];
                 const float wj = xp[4 * j + 3];
                 float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
-                float l2 = ex * ex + ey * ey + ez * ez;
+                float l2 = dot3(ex, ey, ez, ex, ey, ez);
                 float inv_len = orc_rsqrt(l2);
                 float len = l2 * inv_len;
                 if (!(len > 0.0f)) continue;
@@ -482,7 +489,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 if (k < 0.0f) { if (!(C > 0.0f)) continue; k = -k; } /* tether: unilateral */
                 float ratio = wi / (wi + wj);
                 float sc_ = (k * ratio) * (C * inv_len);
-                d0 = d0 - ex * sc_; d1 = d1 - ey * sc_; d2 = d2 - ez * sc_;
+                d0 = fmaf(-ex, sc_, d0); d1 = fmaf(-ey, sc_, d1); d2 = fmaf(-ez, sc_, d2);
                 cnt++;
             }
             /* 4b. particle-particle contacts (NvFlex.h:101 solidRestDistance, :107 particleFriction, :108 inelastic) */
@@ -491,7 +498,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 int j = s->nlist[(size_t)ORC_MAX_NEIGHBORS * i + a];
                 const float wj = xp[4 * j + 3];
                 float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
-                float l2 = ex * ex + ey * ey + ez * ez;
+                float l2 = dot3(ex, ey, ez, ex, ey, ez);
                 if (!(l2 < restd2)) continue;
                 float inv = orc_rsqrt(l2);
                 float dist = l2 * inv;
@@ -506,14 +513,14 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                     float rx = ri0 - (xp[4 * j] - x0[4 * j]);
                     float ry = ri1 - (xp[4 * j + 1] - x0[4 * j + 1]);
                     float rz = ri2 - (xp[4 * j + 2] - x0[4 * j + 2]);
-                    float rn = rx * nx + ry * ny + rz * nz;
-                    float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
-                    float tl2 = tx * tx + ty * ty + tz * tz;
+                    float rn = dot3(rx, ry, rz, nx, ny, nz);
+                    float tx = fmaf(-nx, rn, rx), ty = fmaf(-ny, rn, ry), tz = fmaf(-nz, rn, rz);
+                    float tl2 = dot3(tx, ty, tz, tx, ty, tz);
                     if (tl2 > 0.0f) {
                         float inv_tl = orc_rsqrt(tl2);
                         float tl = tl2 * inv_tl;
                         float fs = friction_scale(tl, inv_tl, pen, p->particleFriction, p->particleFriction) * ratio;
-                        c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+                        c0 = fmaf(-tx, fs, c0); c1 = fmaf(-ty, fs, c1); c2 = fmaf(-tz, fs, c2);
                     }
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
@@ -522,18 +529,18 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
             /* 4c. planes (NvFlex.h:145 collisionDistance, :149 plane form, :105-106 friction) */
             for (int q = 0; q < p->numPlanes; ++q) {
                 const float *pl = p->planes[q];
-                float sdist = pl[0] * xi0 + pl[1] * xi1 + pl[2] * xi2 + pl[3];
+                float sdist = dot3(pl[0], pl[1], pl[2], xi0, xi1, xi2) + pl[3];
                 if (!(sdist < cd)) continue;
                 float pen = cd - sdist;
                 float c0 = pl[0] * pen, c1 = pl[1] * pen, c2 = pl[2] * pen;
-                float rn = ri0 * pl[0] + ri1 * pl[1] + ri2 * pl[2];
-                float tx = ri0 - pl[0] * rn, ty = ri1 - pl[1] * rn, tz = ri2 - pl[2] * rn;
-                float tl2 = tx * tx + ty * ty + tz * tz;
+                float rn = dot3(ri0, ri1, ri2, pl[0], pl[1], pl[2]);
+                float tx = fmaf(-pl[0], rn, ri0), ty = fmaf(-pl[1], rn, ri1), tz = fmaf(-pl[2], rn, ri2);
+                float tl2 = dot3(tx, ty, tz, tx, ty, tz);
                 if (tl2 > 0.0f) {
                     float inv_tl = orc_rsqrt(tl2);
                     float tl = tl2 * inv_tl;
                     float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
-                    c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+                    c0 = fmaf(-tx, fs, c0); c1 = fmaf(-ty, fs, c1); c2 = fmaf(-tz, fs, c2);
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
                 cnt++;
@@ -541,7 +548,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
             /* 4d. kinematic spheres (NvFlex.h:941-987), all channels set so every particle collides (NvFlex.h:163,965) */
             for (int q = 0; q < s->ns; ++q) {
                 float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
-                float l2 = ex * ex + ey * ey + ez * ez;
+                float l2 = dot3(ex, ey, ez, ex, ey, ez);
                 float lim = s->sh_radius[q] + cd;
                 if (!(l2 < lim * lim)) continue;
                 float inv = orc_rsqrt(l2);
@@ -552,14 +559,14 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float pen = lim - dist;
                 float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
                 float rx = ri0 - sd[q][0], ry = ri1 - sd[q][1], rz = ri2 - sd[q][2];
-                float rn = rx * nx + ry * ny + rz * nz;
-                float tx = rx - nx * rn, ty = ry - ny * rn, tz = rz - nz * rn;
-                float tl2 = tx * tx + ty * ty + tz * tz;
+                float rn = dot3(rx, ry, rz, nx, ny, nz);
+                float tx = fmaf(-nx, rn, rx), ty = fmaf(-ny, rn, ry), tz = fmaf(-nz, rn, rz);
+                float tl2 = dot3(tx, ty, tz, tx, ty, tz);
                 if (tl2 > 0.0f) {
                     float inv_tl = orc_rsqrt(tl2);
                     float tl = tl2 * inv_tl;
                     float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
-                    c0 = c0 - tx * fs; c1 = c1 - ty * fs; c2 = c2 - tz * fs;
+                    c0 = fmaf(-tx, fs, c0); c1 = fmaf(-ty, fs, c1); c2 = fmaf(-tz, fs, c2);
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
                 cnt++;
@@ -567,7 +574,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
             /* 4e. applyDeltas, eNvFlexRelaxationLocal: delta / constraint count * relaxationFactor */
             if (cnt > 0) {
                 float sc_ = p->relaxationFactor / (float)cnt;
-                xn[4 * i] = xi0 + d0 * sc_; xn[4 * i + 1] = xi1 + d1 * sc_; xn[4 * i + 2] = xi2 + d2 * sc_;
+                xn[4 * i] = fmaf(d0, sc_, xi0); xn[4 * i + 1] = fmaf(d1, sc_, xi1); xn[4 * i + 2] = fmaf(d2, sc_, xi2);
             } else { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; }
             xn[4 * i + 3] = wi;
         }
