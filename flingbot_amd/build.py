@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libflingsim.so")
 ARCH = "gfx950"
 
 LIB_SOURCES = ["fs_capi.hip", "fs_solver.hip", "fs_render.hip", "fs_picker.hip", "fs_hostapi.hip", "fs_scene.cpp"]
-HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", f"--offload-arch={ARCH}", "-Wall",
+HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", f"--offload-arch={ARCH}", "-Wall",
              "-Wno-unused-function", "-Wno-unused-result"]
 
 
@@ -31,6 +31,7 @@ def _newer(target, deps):
 def _all_sources():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps.append(os.path.join(ROOT, "include", "flingsim.h"))
+    deps.append(os.path.abspath(__file__))  # the compile flags live here
     return deps
 
 

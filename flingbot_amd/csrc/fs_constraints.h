@@ -109,6 +109,25 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
     a.cnt += active ? 1 : 0;
 }
 
+// fs_spring_bf for the case that covers a free cloth: the neighbour has the particle's own mass (ratio == 0.5 exactly)
+// and the cloth has no tethers (every k > 0); kh = 0.5 * k (exact: a power-of-two scaling).  Performs exactly the
+// operations of fs_spring on an active constraint, in the same order -- (k * 0.5) * (C * inv_len) -- minus the tests
+// whose outcome is known.
+__device__ __forceinline__ void fs_spring_fast(FsAcc &a, float xi0, float xi1, float xi2, const FsVec4 xj, float L,
+                                               float kh) {
+    float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
+    float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
+    float inv_len = fs_rsqrt(l2);
+    float len = l2 * inv_len;
+    float C = len - L;
+    const bool active = len > 0.0f;
+    float sc = active ? kh * (C * inv_len) : 0.0f;
+    a.d0 = FS_FMA(-ex, sc, a.d0);
+    a.d1 = FS_FMA(-ey, sc, a.d1);
+    a.d2 = FS_FMA(-ez, sc, a.d2);
+    a.cnt += active ? 1 : 0;
+}
+
 // particle-particle contact; (ri*) = xi - x0_i, rj = xj - x0_j (displacement since substep start)
 __device__ __forceinline__ void fs_particle_contact(FsAcc &a, float xi0, float xi1, float xi2, float wi, float ri0,
                                                     float ri1, float ri2, const FsVec4 xj, float rj0, float rj1,

@@ -30,10 +30,12 @@
 //   DICT float2[256]    distinct (rest length, stiffness) pairs of the cloth                    2 KiB
 //   HASH cursor int[4096] | items u16[4096] | scan int[16]   (neighbour search only)           24 KiB
 // The next iterate needs no LDS: each thread carries its four new positions in a rotating set of registers.
-#define FS_FUSED_OFF_X 0
+// (DICT and X sit below 64 KiB so their bases fold into the 16-bit offset field of the ds_read instructions; the gather
+// addresses are then just the 16-bit halves of the packed adjacency words)
+#define FS_FUSED_OFF_DICT 0
+#define FS_FUSED_OFF_X (FS_FUSED_OFF_DICT + 256 * 8)
 #define FS_FUSED_OFF_X0 (FS_FUSED_OFF_X + FS_FUSED_MAX_PARTICLES * 16)
-#define FS_FUSED_OFF_DICT (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
-#define FS_FUSED_OFF_CUR (FS_FUSED_OFF_DICT + 256 * 8)
+#define FS_FUSED_OFF_CUR (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
 #define FS_FUSED_OFF_ITEMS (FS_FUSED_OFF_CUR + FS_FUSED_BUCKETS * 4)
 #define FS_FUSED_OFF_SCAN (FS_FUSED_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
 // contact set (rebuilt every substep, used by the iterations): ids of up to 1024 particles that have contact candidates,
@@ -423,6 +425,35 @@ __device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedC
     }
 }
 
+// The spring sweep of one particle over the packed adjacency: one spring per scheduling region; the LDS gather and
+// dictionary fetch of spring s+1 are issued in front of the arithmetic of spring s.
+//   FAST: the wave's neighbours all carry their particle's own mass and the cloth has no tethers -> fs_spring_fast on
+//         the pre-halved stiffness; otherwise fs_spring_bf on the stiffness times `kscale` (2 when the LDS dictionary
+//         holds halves, else 1 -- both exact).
+template <int SLOTS, bool FAST>
+__device__ __forceinline__ void fs_fused_spring_block(FsAcc &a, const char *smem, const uint32_t (&jw)[SLOTS / 2 > 0 ? SLOTS / 2 : 1],
+                                                      const uint32_t (&cw)[SLOTS / 2 > 0 ? SLOTS / 2 : 1], float xi0, float xi1,
+                                                      float xi2, float wi, float kscale) {
+    FsVec4 xj = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + (jw[0] & 0xffffu));
+    float2 lk = *(const float2 *)(smem + FS_FUSED_OFF_DICT + (cw[0] & 0xffffu));
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        FsVec4 xj_next = xj;
+        float2 lk_next = lk;
+        if (s + 1 < SLOTS) {
+            const uint32_t joff = (jw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
+            const uint32_t coff = (cw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
+            xj_next = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + joff);
+            lk_next = *(const float2 *)(smem + FS_FUSED_OFF_DICT + coff);
+        }
+        if (FAST) fs_spring_fast(a, xi0, xi1, xi2, xj, lk.x, lk.y);
+        else fs_spring_bf(a, xi0, xi1, xi2, wi, xj, lk.x, lk.y * kscale);
+        __builtin_amdgcn_sched_barrier(0);
+        xj = xj_next;
+        lk = lk_next;
+    }
+}
+
 // SLOTS > 0: packed (dictionary-coded) adjacency with that many slots (12 or 16); SLOTS == 0: plain ELL adjacency.
 //
 // Register discipline (1024 threads => 128 VGPRs, and every attempt to keep per-particle state of the thread's four
@@ -474,23 +505,31 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     const fs_gcu g_nbr = (fs_gcu)E.nbr_w, g_code = (fs_gcu)E.code_w;
     const int max_deg = E.max_deg;
 
+    // Spring dictionary -> LDS.  When no entry is a tether (k < 0) and every stiffness halves exactly, LDS holds
+    // (L, k / 2) and the waves whose particles see only neighbours of their own mass take the short spring form.
+    float2 dict_e = make_float2(0.0f, 0.0f);
+    bool dict_bad = false;
     if (COMPACT && t < 256) {
         const fs_gcf g_dict = (fs_gcf)E.dict;
-        *(float2 *)(smem + FS_FUSED_OFF_DICT + t * 8) = make_float2(g_dict[2 * t], g_dict[2 * t + 1]);
+        dict_e = make_float2(g_dict[2 * t], g_dict[2 * t + 1]);
+        dict_bad = t < E.dict_size && (dict_e.y < 0.0f || (dict_e.y * 0.5f) * 2.0f != dict_e.y);
     }
     // Is the whole cloth one phase?  Then the per-pair phase / rest-position loads of the neighbour search (dependent
     // global gathers) collapse into a register test against the packed rest-near ids.
     const fs_gcu g_near = (fs_gcu)E.restnear_w;
     int find_mode = 0;
+    bool dict_halved = false;
     {
         const int ph0 = g_phase[0];
         int differs = 0;
         for (int i = t; i < n; i += FS_FUSED_THREADS) differs |= (g_phase[i] != ph0);
-        if (t == 0) wave_tot[0] = 0;
+        if (t == 0) { wave_tot[0] = 0; wave_tot[1] = 0; }
         __syncthreads();
         if (differs) atomicOr(&wave_tot[0], 1);
+        if (dict_bad) atomicOr(&wave_tot[1], 1);
         __syncthreads();
         const int mixed = wave_tot[0];
+        dict_halved = COMPACT && wave_tot[1] == 0;
         __syncthreads();
         if (!mixed) {
             if (!(ph0 & FS_PHASE_SELF_COLLIDE)) find_mode = 3;  // same group, no self-collision flag: no pairs at all
@@ -498,11 +537,37 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             else if (E.restnear_ok) find_mode = 1;
         }
     }
+    if (COMPACT && t < 256)
+        *(float2 *)(smem + FS_FUSED_OFF_DICT + t * 8) = make_float2(dict_e.x, dict_halved ? dict_e.y * 0.5f : dict_e.y);
+    const float kscale = dict_halved ? 2.0f : 1.0f;
     // own particles: i = t + k * 1024.  Load positions into X (w = invMass) and X0.
     for (int i = t; i < n; i += FS_FUSED_THREADS) {
         const FsVec4 p = fs_ld4(g_pos, i);
         X[i] = p;
         X0x[i] = p.x; X0y[i] = p.y; X0z[i] = p.z;
+    }
+    // bit k: every lane's particle k of this wave has only spring neighbours of its own inverse mass (constant for the
+    // launch: masses change between launches only) -> short spring form
+    unsigned fastmask = 0u;
+    if (COMPACT && dict_halved) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FS_FUSED_PPT; ++k) {
+            const int i = t + k * FS_FUSED_THREADS;
+            bool differs = false;
+            if (i < n) {
+                const float wi = X[i].w;
+                if (wi > 0.0f) {
+#pragma unroll
+                    for (int q = 0; q < JW; ++q) {
+                        const uint32_t w = g_nbr[(unsigned)q * un + (unsigned)i];
+                        differs |= *(const float *)(smem + FS_FUSED_OFF_X + (w & 0xffffu) + 12) != wi;
+                        differs |= *(const float *)(smem + FS_FUSED_OFF_X + (w >> 16) + 12) != wi;
+                    }
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(differs) == 0ull) fastmask |= 1u << k;
+        }
     }
 
     FS_TS(0)
@@ -644,25 +709,10 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     const float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z, wi = xi.w;
                     if (xi.w > 0.0f) {
                         if (COMPACT) {
-                            // one spring per scheduling region; the LDS gather and dictionary fetch of spring s+1 are
-                            // issued in front of the arithmetic of spring s
-                            FsVec4 xj = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + (jw[0] & 0xffffu));
-                            float2 lk = *(const float2 *)(smem + FS_FUSED_OFF_DICT + (cw[0] & 0xffffu));
-#pragma unroll
-                            for (int s = 0; s < SLOTS; ++s) {
-                                FsVec4 xj_next = xj;
-                                float2 lk_next = lk;
-                                if (s + 1 < SLOTS) {
-                                    const uint32_t joff = (jw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
-                                    const uint32_t coff = (cw[(s + 1) >> 1] >> (16 * ((s + 1) & 1))) & 0xffffu;
-                                    xj_next = *(const FsVec4 *)(smem + FS_FUSED_OFF_X + joff);
-                                    lk_next = *(const float2 *)(smem + FS_FUSED_OFF_DICT + coff);
-                                }
-                                fs_spring_bf(a, xi0, xi1, xi2, wi, xj, lk.x, lk.y);
-                                __builtin_amdgcn_sched_barrier(0);
-                                xj = xj_next;
-                                lk = lk_next;
-                            }
+                            if ((fastmask >> k) & 1u)
+                                fs_fused_spring_block<SLOTS, true>(a, smem, jw, cw, xi0, xi1, xi2, wi, 1.0f);
+                            else
+                                fs_fused_spring_block<SLOTS, false>(a, smem, jw, cw, xi0, xi1, xi2, wi, kscale);
                         } else {
                             for (int s = 0; s < max_deg; ++s) {
                                 const int j = g_ell_j[(unsigned)s * un + (unsigned)i];
