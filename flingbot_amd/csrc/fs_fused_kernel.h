@@ -463,7 +463,7 @@ __device__ __forceinline__ void fs_fused_spring_block(FsAcc &a, const char *smem
 // packed adjacency (2 x SLOTS/2 dwords per particle, shared by all episodes of the same cloth, L2/L1 resident) and the
 // head of the contact-candidate list are fetched one particle ahead of their use.
 template <int SLOTS>
-__global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvDev *envs, const FsShapesDev *shapes,
+__global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvDev *__restrict__ envs, const FsShapesDev *__restrict__ shapes,
                                                                     const int *ids, int n_steps) {
     constexpr bool COMPACT = SLOTS > 0;
     constexpr int JW = COMPACT ? SLOTS / 2 : 1;
