@@ -742,27 +742,28 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                         cacc[myslot] = FsVec4{a.d0, a.d1, a.d2, __int_as_float(a.cnt)};  // pass 2 finishes this particle
                     } else if (xi.w > 0.0f) {
                         const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
-                        // candidates in chunks of FS_FUSED_PREFETCH_CAND: the ids of chunk c+1 are requested from the
-                        // (slot-major, L2-resident) list before chunk c is processed, so a long list costs one exposed
-                        // memory latency at most instead of one per candidate
-                        for (int s0 = 0; s0 < cnt; s0 += FS_FUSED_PREFETCH_CAND) {
-                            int cn[FS_FUSED_PREFETCH_CAND];
-#pragma unroll
-                            for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) {
-                                const int sn = s0 + FS_FUSED_PREFETCH_CAND + q;
-                                cn[q] = sn < cnt ? g_nlist[(unsigned)sn * un + (unsigned)i] : 0;
-                            }
+                        // A particle handled here has few candidates (the set takes the heavy ones first): the first
+                        // FS_FUSED_PREFETCH_CAND ids are already in registers.  No load may sit on this path -- the
+                        // compiler guards a conditionally loaded id with s_waitcnt vmcnt(0), which would also wait for the
+                        // next-particle prefetch issued just above, every trip -- so the tail beyond the registers has
+                        // its own, rarely entered loop.
 #pragma unroll 1
-                            for (int q = 0; q < FS_FUSED_PREFETCH_CAND && s0 + q < cnt; ++q) {  // one copy of the body
-                                const int j = cj[0];
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND && q < cnt; ++q) {
+                            const int j = cj[0];
 #pragma unroll
-                                for (int r = 0; r + 1 < FS_FUSED_PREFETCH_CAND; ++r) cj[r] = cj[r + 1];
+                            for (int r = 0; r + 1 < FS_FUSED_PREFETCH_CAND; ++r) cj[r] = cj[r + 1];
+                            const FsVec4 xj = X[j];
+                            fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
+                                                xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+                        }
+                        if (cnt > FS_FUSED_PREFETCH_CAND) {
+#pragma unroll 1
+                            for (int sq = FS_FUSED_PREFETCH_CAND; sq < cnt; ++sq) {
+                                const int j = g_nlist[(unsigned)sq * un + (unsigned)i];
                                 const FsVec4 xj = X[j];
                                 fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
                                                     xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
                             }
-#pragma unroll
-                            for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cn[q];
                         }
                         fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
                         fs_apply(a, c.relax, nx, ny, nz);
