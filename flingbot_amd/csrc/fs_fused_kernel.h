@@ -25,10 +25,12 @@
 #define FS_FUSED_SLOTS 16      // compact adjacency slots per particle
 
 // LDS carve (bytes):
-//   X    float4[4096]   current Jacobi iterate (xyz + invMass)                               64 KiB
-//   X0   float[3][4096] substep-start position (own displacement + neighbours' for friction)  48 KiB
 //   DICT float2[256]    distinct (rest length, stiffness) pairs of the cloth                    2 KiB
+//   X    float4[4096]   current Jacobi iterate (xyz + invMass); search queues while the search runs   64 KiB
+//   X0   float[3][4096] substep-start position (own displacement + neighbours' for friction);
+//                       bucket-ordered predicted positions XS while the search runs                  48 KiB
 //   HASH cursor int[4096] | items u16[4096] | scan int[16]   (neighbour search only)           24 KiB
+//   contact set: cset u16[1024] | cacc float4[1024] | chist int[128]                           18.5 KiB
 // The next iterate needs no LDS: each thread carries its four new positions in a rotating set of registers.
 // (DICT and X sit below 64 KiB so their bases fold into the 16-bit offset field of the ds_read instructions; the gather
 // addresses are then just the 16-bit halves of the packed adjacency words)
