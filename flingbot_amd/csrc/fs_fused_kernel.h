@@ -491,6 +491,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #define FS_TS(k)
 #endif
     const int e = ids[blockIdx.x];
+    if (e < 0) return;  // slot retired by a device-side loop (fs_wait_until_stable)
     const FsEnvDev &E = envs[e];
     const FsShapesDev &sh = shapes[e];
     const FsFusedConsts c = fs_fused_consts(E, sh);

@@ -1,0 +1,229 @@
+// fs_loops.hip -- device-side feedback loops and reductions of the reference's manipulation primitives (SURVEY.md 8f
+// row f1): wait_until_stable (environment/flex_utils.py:430-441), the height / velocity tests of lift_cloth and
+// is_cloth_grasped (environment/simEnv.py:186-200, 809-813) and stretch_cloth's probe (simEnv.py:155-168).
+// The reference downloads all positions / velocities through pyflex and reduces them with numpy once per simulation
+// step or loop trip; here one small kernel per call produces the few numbers the host logic needs, and
+// wait_until_stable runs its whole data-dependent loop without the host: a check kernel retires finished episodes from
+// the launch list (id -> -1), which every solver kernel skips.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/flingsim.h"
+#include "fs_context.h"
+
+#define HIP_TRY(call)                                     \
+    do {                                                  \
+        if (!fs_hip_ok((call), #call)) return FS_ERR_HIP; \
+    } while (0)
+
+// max over particles of max(|vx|, |vy|, |vz|); block-wide, result valid in thread 0
+__device__ __forceinline__ float fs_block_max(float v, float *red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// One block per launch-list slot: the wait_until_stable test, BEFORE the step (flex_utils.py:434-437).
+__global__ __launch_bounds__(256) void fs_k_stable_check(const FsEnvDev *envs, int *ids, double tol, int *steps, int *stable,
+                                                         int *remaining) {
+    __shared__ float red[256];
+    const int slot = blockIdx.x;
+    const int e = ids[slot];
+    if (e < 0) return;
+    const FsEnvDev &E = envs[e];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < E.n; i += blockDim.x) {
+        const FsVec4 v = E.vel[i];
+        m = fmaxf(m, fmaxf(fabsf(v.x), fmaxf(fabsf(v.y), fabsf(v.z))));
+    }
+    m = fs_block_max(m, red);
+    if (threadIdx.x == 0) {
+        if ((double)m < tol) {
+            stable[slot] = 1;
+            ids[slot] = -1;
+            atomicSub(remaining, 1);
+        } else {
+            steps[slot] += 1;  // the step that follows
+        }
+    }
+}
+
+extern "C" int fs_wait_until_stable(fs_ctx *ctx, int n, const int *envs, int max_steps, double tolerance, int *steps_out,
+                                    int *stable_out) {
+    if (!ctx || !envs || !steps_out || !stable_out || n <= 0 || n > ctx->n_envs || max_steps < 0) {
+        fs_set_error("fs_wait_until_stable: bad arguments");
+        return FS_ERR_ARG;
+    }
+    std::vector<int> ids(envs, envs + n);
+    for (int e : ids)
+        if (e < 0 || e >= ctx->n_envs || !ctx->envs[e].has_scene) {
+            fs_set_error("fs_wait_until_stable: bad episode id / no scene");
+            return FS_ERR_ARG;
+        }
+    int *d_buf = nullptr;  // ids[n] | steps[n] | stable[n] | remaining
+    HIP_TRY(hipMalloc((void **)&d_buf, sizeof(int) * (3 * n + 1)));
+    int *d_ids = d_buf, *d_steps = d_buf + n, *d_stable = d_buf + 2 * n, *d_remaining = d_buf + 3 * n;
+    std::vector<int> init(3 * n + 1, 0);
+    for (int k = 0; k < n; ++k) init[k] = ids[k];
+    init[3 * n] = n;
+    int rc = FS_OK;
+    hipError_t herr = hipMemcpyAsync(d_buf, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);  // `init` is pageable
+    if (!fs_hip_ok(herr, "fs_wait_until_stable upload")) rc = FS_ERR_HIP;
+    int *h_remaining = (int *)fs_stage(ctx, sizeof(int));
+    for (int s = 0; s < max_steps && rc == FS_OK; ++s) {
+        hipLaunchKernelGGL(fs_k_stable_check, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->d_envs, d_ids, tolerance,
+                           d_steps, d_stable, d_remaining);
+        rc = fs_step_ids(ctx, ids, 1, d_ids);
+        if (rc == FS_OK && (s & 15) == 15) {  // every 16 steps: has everybody finished?
+            if (!fs_hip_ok(hipMemcpyAsync(h_remaining, d_remaining, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), "poll") ||
+                !fs_hip_ok(hipStreamSynchronize(ctx->stream), "poll sync"))
+                rc = FS_ERR_HIP;
+            else if (*h_remaining == 0)
+                break;
+        }
+    }
+    if (rc == FS_OK) {
+        std::vector<int> out(2 * n);
+        herr = hipMemcpyAsync(out.data(), d_steps, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, ctx->stream);
+        if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
+        if (!fs_hip_ok(herr, "fs_wait_until_stable download")) rc = FS_ERR_HIP;
+        for (int k = 0; k < n && rc == FS_OK; ++k) { steps_out[k] = out[k]; stable_out[k] = out[n + k]; }
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(d_buf);
+    return rc;
+}
+
+// ---- reductions ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fs_k_cloth_stats(const FsEnvDev *envs, const int *ids, float *out) {
+    __shared__ float red[256];
+    const FsEnvDev &E = envs[ids[blockIdx.x]];
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f, vm = 0.0f;
+    for (int i = threadIdx.x; i < E.n; i += blockDim.x) {
+        const float y = E.pos[i].y;
+        lo = fminf(lo, y);
+        hi = fmaxf(hi, y);
+        const FsVec4 v = E.vel[i];
+        vm = fmaxf(vm, fmaxf(fabsf(v.x), fmaxf(fabsf(v.y), fabsf(v.z))));
+    }
+    const float nlo = fs_block_max(-lo, red);
+    __syncthreads();
+    const float mhi = fs_block_max(hi, red);
+    __syncthreads();
+    const float mv = fs_block_max(vm, red);
+    if (threadIdx.x == 0) {
+        out[3 * blockIdx.x] = -nlo;
+        out[3 * blockIdx.x + 1] = mhi;
+        out[3 * blockIdx.x + 2] = mv;
+    }
+}
+
+static int upload_list(fs_ctx *ctx, int n, const int *envs, int **d_ids) {
+    if (!ctx || !envs || n <= 0 || n > ctx->n_envs) {
+        fs_set_error("bad episode list");
+        return FS_ERR_ARG;
+    }
+    for (int k = 0; k < n; ++k)
+        if (envs[k] < 0 || envs[k] >= ctx->n_envs || !ctx->envs[envs[k]].has_scene) {
+            fs_set_error("bad episode id / no scene");
+            return FS_ERR_ARG;
+        }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // h_ids may still be read by an earlier copy
+    for (int k = 0; k < n; ++k) ctx->h_ids[k] = envs[k];
+    HIP_TRY(hipMemcpyAsync(ctx->d_ids, ctx->h_ids, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+    *d_ids = ctx->d_ids;
+    return FS_OK;
+}
+
+extern "C" int fs_cloth_stats(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats) {
+    if (!out || n_floats < 3 * n) {
+        fs_set_error("fs_cloth_stats: output too small");
+        return FS_ERR_ARG;
+    }
+    int *d_ids = nullptr;
+    int rc = upload_list(ctx, n, envs, &d_ids);
+    if (rc != FS_OK) return rc;
+    float *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_out, sizeof(float) * 3 * n));
+    hipLaunchKernelGGL(fs_k_cloth_stats, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->d_envs, d_ids, d_out);
+    hipError_t herr = hipMemcpyAsync(out, d_out, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_out);
+    return fs_hip_ok(herr, "fs_cloth_stats") ? FS_OK : FS_ERR_HIP;
+}
+
+// stretch_cloth's probe.  All arithmetic in float32, as numpy does on the float32 arrays pyflex returns.
+__global__ __launch_bounds__(256) void fs_k_stretch_probe(const FsEnvDev *envs, const int *ids, const float *mid_xz,
+                                                          const float *height_thr, int *single_out, float *nearest_out) {
+    __shared__ float best_d[256];
+    __shared__ int best_i[256];
+    __shared__ int any_neg[256], any_pos[256];  // a high particle with x >= 0 / x <= 0 exists
+    const int slot = blockIdx.x, t = threadIdx.x;
+    const FsEnvDev &E = envs[ids[slot]];
+    const float mx = mid_xz[2 * slot], mz = mid_xz[2 * slot + 1], thr = height_thr[slot];
+    float bd = 3.402823466e+38f;
+    int bi = 0x7fffffff, not_all_neg = 0, not_all_pos = 0;
+    for (int i = t; i < E.n; i += blockDim.x) {
+        const FsVec4 p = E.pos[i];
+        if (p.y > thr) {
+            if (!(p.x < 0.0f)) not_all_neg = 1;
+            if (!(p.x > 0.0f)) not_all_pos = 1;
+        }
+        const float dx = p.x - mx, dz = p.z - mz;
+        const float d = sqrtf(dx * dx + dz * dz);  // np.linalg.norm of the float32 2-vector
+        if (d < bd) { bd = d; bi = i; }            // ascending i within a thread: the first minimum is kept
+    }
+    best_d[t] = bd; best_i[t] = bi; any_neg[t] = not_all_neg; any_pos[t] = not_all_pos;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            if (best_d[t + s] < best_d[t] || (best_d[t + s] == best_d[t] && best_i[t + s] < best_i[t])) {
+                best_d[t] = best_d[t + s];
+                best_i[t] = best_i[t + s];
+            }
+            any_neg[t] |= any_neg[t + s];
+            any_pos[t] |= any_pos[t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        single_out[slot] = (!any_neg[0] || !any_pos[0]) ? 1 : 0;  // (x < 0).all() or (x > 0).all()
+        const FsVec4 p = E.pos[best_i[0] < E.n ? best_i[0] : 0];
+        nearest_out[3 * slot] = p.x; nearest_out[3 * slot + 1] = p.y; nearest_out[3 * slot + 2] = p.z;
+    }
+}
+
+extern "C" int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float *midpoint_xz, const float *height_thr,
+                                int *single_grasp_out, float *nearest_out) {
+    if (!midpoint_xz || !height_thr || !single_grasp_out || !nearest_out) {
+        fs_set_error("fs_stretch_probe: null argument");
+        return FS_ERR_ARG;
+    }
+    int *d_ids = nullptr;
+    int rc = upload_list(ctx, n, envs, &d_ids);
+    if (rc != FS_OK) return rc;
+    float *d_buf = nullptr;  // mid[2n] | thr[n] | nearest[3n] | single[n] (ints)
+    HIP_TRY(hipMalloc((void **)&d_buf, sizeof(float) * 7 * n));
+    float *d_mid = d_buf, *d_thr = d_buf + 2 * n, *d_near = d_buf + 3 * n;
+    int *d_single = (int *)(d_buf + 6 * n);
+    hipError_t herr = hipMemcpyAsync(d_mid, midpoint_xz, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipMemcpyAsync(d_thr, height_thr, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);  // the sources are pageable
+    if (herr == hipSuccess) {
+        hipLaunchKernelGGL(fs_k_stretch_probe, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->d_envs, d_ids, d_mid, d_thr,
+                           d_single, d_near);
+        herr = hipMemcpyAsync(nearest_out, d_near, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (herr == hipSuccess) herr = hipMemcpyAsync(single_grasp_out, d_single, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_buf);
+    return fs_hip_ok(herr, "fs_stretch_probe") ? FS_OK : FS_ERR_HIP;
+}

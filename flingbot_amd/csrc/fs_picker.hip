@@ -162,9 +162,12 @@ struct Plan {  // host-side trajectory of one episode for one movep call
 
 inline double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
-// simEnv.py:739-769 + flex_utils.py:223-252 on the kinematic picker state only (float64 math, float32 state)
+// simEnv.py:739-769 + flex_utils.py:223-252 on the kinematic picker state only (float64 math, float32 state).
+// f32_targets: the caller's targets are a float32 numpy array in the reference (stretch_cloth builds them from the
+// float32 picker positions, simEnv.py:146-156,180-182), so movep's own arithmetic -- delta, its norm, the step toward the
+// target -- happens in float32 there; PickerPickPlace.step below always works in float64.
 Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *grasp, double speed, int limit,
-                int min_steps, double eps) {
+                int min_steps, double eps, bool f32_targets) {
     Plan plan;
     const int S = shapes.count;
     float cur[FS_MAX_SHAPES][3];
@@ -173,6 +176,16 @@ Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *gra
         double end[FS_MAX_SHAPES][3];
         bool all_close = true;
         for (int k = 0; k < S; ++k) {
+            if (f32_targets) {
+                float d[3];
+                for (int c = 0; c < 3; ++c) d[c] = (float)targets[3 * k + c] - cur[k][c];
+                const float dist = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                if (!((double)dist < eps)) all_close = false;
+                for (int c = 0; c < 3; ++c)
+                    end[k][c] = (double)dist < speed ? (double)(float)targets[3 * k + c]
+                                                     : (double)(cur[k][c] + (d[c] / dist) * (float)speed);
+                continue;
+            }
             double d[3];
             for (int c = 0; c < 3; ++c) d[c] = targets[3 * k + c] - (double)cur[k][c];
             const double dist = norm3(d);
@@ -229,8 +242,8 @@ Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *gra
 // movep for a batch of episodes: targets double[n][S][3], grasp int[n][S] (S = shapes of the episode, identical
 // for every episode of the batch), iterations_out int[n].  Returns FS_ERR_LIMIT if any episode ran into `limit`
 // (MoveJointsException in the reference); the trajectories are executed up to the limit in that case.
-extern "C" int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed,
-                              int limit, int min_steps, double eps, int *iterations_out) {
+static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed,
+                            int limit, int min_steps, double eps, int *iterations_out, bool f32_targets) {
     if (!ctx || n <= 0 || !envs || !targets || !grasp) { fs_set_error("fs_movep: bad arguments"); return FS_ERR_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     int S = -1;
@@ -242,7 +255,8 @@ extern "C" int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double 
         if (!e->picker_ready) { fs_set_error("fs_movep: call fs_picker_reset first"); return FS_ERR_STATE; }
         if (S < 0) S = e->shapes.count;
         if (e->shapes.count != S || S <= 0) { fs_set_error("fs_movep: episodes need the same (non-zero) picker count"); return FS_ERR_STATE; }
-        plans[a] = plan_movep(e->shapes, targets + (size_t)a * S * 3, grasp + (size_t)a * S, speed, limit, min_steps, eps);
+        plans[a] = plan_movep(e->shapes, targets + (size_t)a * S * 3, grasp + (size_t)a * S, speed, limit, min_steps, eps,
+                              f32_targets);
         if (iterations_out) iterations_out[a] = plans[a].iterations;
         if (plans[a].cmds.size() > max_steps) max_steps = plans[a].cmds.size();
     }
@@ -304,6 +318,22 @@ extern "C" int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double 
     }
     if (any_limit) { fs_set_error("fs_movep: step limit reached (MoveJointsException)"); return FS_ERR_LIMIT; }
     return FS_OK;
+}
+
+extern "C" int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed,
+                              int limit, int min_steps, double eps, int *iterations_out) {
+    return movep_batch_impl(ctx, n, envs, targets, grasp, speed, limit, min_steps, eps, iterations_out, false);
+}
+
+extern "C" int fs_movep_batch_f32(fs_ctx *ctx, int n, const int *envs, const float *targets, const int *grasp, double speed,
+                                  int limit, int min_steps, double eps, int *iterations_out) {
+    if (!ctx || n <= 0 || !envs || !targets) { fs_set_error("fs_movep: bad arguments"); return FS_ERR_ARG; }
+    FsEnv *e0 = picker_env(ctx, envs[0]);
+    if (!e0) return FS_ERR_ARG;
+    const size_t count = (size_t)n * (size_t)e0->shapes.count * 3;
+    std::vector<double> wide(count);
+    for (size_t k = 0; k < count; ++k) wide[k] = (double)targets[k];
+    return movep_batch_impl(ctx, n, envs, wide.data(), grasp, speed, limit, min_steps, eps, iterations_out, true);
 }
 
 extern "C" int fs_movep(fs_ctx *ctx, int env, const double *targets, const int *grasp, double speed, int limit,

@@ -11,6 +11,7 @@
 
 // ---- predict + cell histogram.  reference: gravity NvFlex.h:99, damping :117, invMass == 0 -> kinematic :545
 __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *ids) {
+    if (ids[blockIdx.y] < 0) return;  // retired slot
     const FsEnvDev &E = envs[ids[blockIdx.y]];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, co
 
 // ---- exclusive scan of the bucket histogram (one workgroup per episode); leaves count/fill zeroed for the next use
 __global__ __launch_bounds__(1024) void fs_k_grid_scan(const FsEnvDev *envs, const int *ids) {
+    if (ids[blockIdx.x] < 0) return;  // retired slot
     const FsEnvDev &E = envs[ids[blockIdx.x]];
     __shared__ int wave_tot[16];
     constexpr int PER = FS_GRID_BUCKETS / 1024;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(1024) void fs_k_grid_scan(const FsEnvDev *envs, con
 
 // ---- scatter particle ids into buckets.  After this kernel cell_fill[b] == end of bucket b.
 __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *envs, const int *ids) {
+    if (ids[blockIdx.y] < 0) return;  // retired slot
     const FsEnvDev &E = envs[ids[blockIdx.y]];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 // ---- particle-contact candidates: ascending neighbour id, the (up to) 96 smallest ids.
 // A bucket spans [end[b] - size, end[b]); sizes are recovered from consecutive ends (end[b-1] == start[b]).
 __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids) {
+    if (ids[blockIdx.y] < 0) return;  // retired slot
     const FsEnvDev &E = envs[ids[blockIdx.y]];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
                                                         int sub, int flip) {
     const int e = ids[blockIdx.y];
+    if (e < 0) return;  // retired slot
     const FsEnvDev &E = envs[e];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, co
 
 // ---- finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping (:110)
 __global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, const int *ids, int flip) {
+    if (ids[blockIdx.y] < 0) return;  // retired slot
     const FsEnvDev &E = envs[ids[blockIdx.y]];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
     if (i >= E.n) return;

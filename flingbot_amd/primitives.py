@@ -1,0 +1,192 @@
+"""Batched fling primitive on the device-resident simulator.
+
+Host-side mirror of the reference's manipulation code for MANY episodes at once -- same control flow, same numpy
+expressions (and therefore the same float32 / float64 roundings) per episode:
+
+    SimEnv.pick_and_fling_primitive   environment/simEnv.py:283-318
+    SimEnv.stretch_cloth              environment/simEnv.py:140-184
+    SimEnv.lift_cloth                 environment/simEnv.py:186-200
+    SimEnv.fling_primitive            environment/simEnv.py:262-281
+    SimEnv.is_cloth_grasped           environment/simEnv.py:809-813
+    SimEnv.reset_end_effectors / set_grasp / movep   :739-780
+
+Everything that touches particle data runs on the GPU: `movep` is `fs_movep_batch` (every simulation step of every
+episode without a host round trip), the loops' tests read device reductions (`fs_cloth_stats`, `fs_stretch_probe`)
+instead of downloading 64 KiB of positions per episode and trip.  Episodes are independent, so advancing them stage by
+stage in lock step gives each one exactly the trajectory the reference's sequential code gives it.
+"""
+import numpy as np
+
+from .sim import FlingSim
+
+
+class FlingPrimitives:
+    def __init__(self, sim: FlingSim, envs, grasp_height=0.02, fling_speed=6e-3, fixed_fling_height=-1):
+        self.sim = sim
+        self.envs = np.asarray(envs, np.int32).reshape(-1)
+        self.grasp_height = grasp_height
+        self.fling_speed = fling_speed
+        self.fixed_fling_height = fixed_fling_height
+        self.grasp_states = {int(e): [False, False] for e in self.envs}
+        self.terminate = {int(e): False for e in self.envs}
+        self.sim_steps = 0  # simulation steps issued by this object (all episodes)
+
+    # ---- SimEnv.movep for a subset of the episodes, each with its own targets
+    def movep(self, envs, targets, speed=None, min_steps=None, limit=1000):
+        envs = [int(e) for e in envs]
+        if not envs:
+            return
+        speed = 0.1 if speed is None else speed  # dump_visualizations is off in batch mode (simEnv.py:740-744)
+        grasp = [self.grasp_states[e] for e in envs]
+        iters = self.sim.movep(envs, np.array(targets), grasp, speed=speed, limit=limit, min_steps=min_steps)
+        self.sim_steps += int(np.sum(iters))
+
+    def set_grasp(self, envs, grasp):
+        for e in envs:
+            self.grasp_states[int(e)] = [bool(grasp)] * 2 if isinstance(grasp, (bool, np.bool_)) else [bool(g) for g in grasp]
+
+    def picker_positions(self, e):
+        """Picker._get_pos()[0]: float32 [2,3] (flex_utils.py:104-112)."""
+        return np.array(self.sim.get_shape_states(e)).reshape(-1, 14)[:, :3]
+
+    def is_cloth_grasped(self, envs):
+        st = self.sim.cloth_stats(envs)
+        return st[:, 1] > 0.2  # heights.max() > 0.2, float32 vs python float as numpy compares them
+
+    # ---- simEnv.py:140-184, one state machine per episode, advanced together
+    def stretch_cloth(self, envs, grasp_dist, fling_height=0.7, max_grasp_dist=0.7, increment_step=0.02):
+        envs = [int(e) for e in envs]
+        result = {}
+        st = {}
+        first_targets = []
+        for e, gd in zip(envs, grasp_dist):
+            left, right = self.picker_positions(e)
+            left[1] = fling_height
+            right[1] = fling_height
+            midpoint = (left + right) / 2
+            direction = left - right
+            direction = direction / np.linalg.norm(direction)
+            st[e] = dict(grasp_dist=gd, midpoint=midpoint, direction=direction, stable_steps=0, cloth_midpoint=1e2)
+            first_targets.append([left, right])
+        self.movep(envs, first_targets, speed=5e-4, min_steps=20)
+        active = list(envs)
+        while active:
+            mids = [st[e]["midpoint"][[0, 2]] for e in active]
+            thr = [np.float32(fling_height - 0.1)] * len(active)
+            single, nearest = self.sim.stretch_probe(active, mids, thr)
+            nxt, targets = [], []
+            for k, e in enumerate(active):
+                s = st[e]
+                if single[k]:  # single grasp
+                    result[e] = s["grasp_dist"]
+                    continue
+                new_cloth_midpoint = nearest[k]
+                stable = np.linalg.norm(new_cloth_midpoint - s["cloth_midpoint"]) < 1.5e-2
+                s["stable_steps"] = s["stable_steps"] + 1 if stable else 0
+                if s["stable_steps"] > 2:
+                    result[e] = s["grasp_dist"]
+                    continue
+                s["cloth_midpoint"] = new_cloth_midpoint
+                s["grasp_dist"] += increment_step
+                left = s["midpoint"] + s["direction"] * s["grasp_dist"] / 2
+                right = s["midpoint"] - s["direction"] * s["grasp_dist"] / 2
+                nxt.append(e)
+                targets.append([left, right])
+            self.movep(nxt, targets, speed=5e-4)
+            active = []
+            for e in nxt:
+                if st[e]["grasp_dist"] > max_grasp_dist:
+                    result[e] = max_grasp_dist
+                else:
+                    active.append(e)
+        return [result[e] for e in envs]
+
+    # ---- simEnv.py:186-200
+    def lift_cloth(self, envs, grasp_dist, fling_height=0.7, increment_step=0.05, max_height=0.7):
+        envs = [int(e) for e in envs]
+        height = {e: fling_height for e in envs}
+        dist = dict(zip(envs, grasp_dist))
+        result = {}
+        active = list(envs)
+        while active:
+            stats = self.sim.cloth_stats(active)
+            nxt, targets = [], []
+            for k, e in enumerate(active):
+                if stats[k, 0] > 0.02:  # heights.min() > 0.02
+                    result[e] = height[e]
+                    continue
+                height[e] += increment_step
+                nxt.append(e)
+                targets.append([[dist[e] / 2, height[e], -0.3], [-dist[e] / 2, height[e], -0.3]])
+            self.movep(nxt, targets, speed=1e-3)
+            active = []
+            for e in nxt:
+                if height[e] >= max_height:
+                    result[e] = height[e]
+                else:
+                    active.append(e)
+        return [result[e] for e in envs]
+
+    # ---- simEnv.py:262-281
+    def fling_primitive(self, envs, dist, fling_height, fling_speed):
+        envs = [int(e) for e in envs]
+        gh2 = self.grasp_height * 2
+
+        def tg(y, z):
+            return [[[d / 2, h if y is None else y, z], [-d / 2, h if y is None else y, z]] for d, h in zip(dist, fling_height)]
+
+        self.movep(envs, tg(None, -0.2), speed=fling_speed)
+        self.movep(envs, tg(None, 0.2), speed=fling_speed)
+        self.movep(envs, tg(None, 0.2), speed=1e-2, min_steps=4)
+        self.movep(envs, tg(gh2, -0.2), speed=1e-2)      # lower
+        self.movep(envs, tg(gh2, -0.25), speed=5e-3)
+        self.set_grasp(envs, False)                        # release
+        self.reset_end_effectors(envs)
+
+    def reset_end_effectors(self, envs):
+        envs = [int(e) for e in envs]
+        self.movep(envs, [[[0.5, 0.5, -0.5], [-0.5, 0.5, -0.5]]] * len(envs), speed=5e-3)
+
+    # ---- simEnv.py:283-318
+    def pick_and_fling(self, p1, p2, p1_grasp_cloth, p2_grasp_cloth):
+        """p1, p2: [n,3] grasp positions per episode (y is overwritten by grasp_height), *_grasp_cloth: bool[n].
+        Returns a list of dicts per episode: {'dist', 'fling_height', 'terminated', 'skipped'}."""
+        envs = [int(e) for e in self.envs]
+        p1 = np.array(p1, np.float64).reshape(len(envs), 3)
+        p2 = np.array(p2, np.float64).reshape(len(envs), 3)
+        out = {e: dict(dist=None, fling_height=None, terminated=False, skipped=False) for e in envs}
+        run = []
+        for k, e in enumerate(envs):
+            if not (p1_grasp_cloth[k] or p2_grasp_cloth[k]):
+                out[e]["skipped"] = True  # both points not on cloth
+            else:
+                run.append(k)
+        if run:
+            idx = {envs[k]: k for k in run}
+            act = [envs[k] for k in run]
+            p1[:, 1] = self.grasp_height
+            p2[:, 1] = self.grasp_height
+            dist = {e: np.linalg.norm(np.array(p1[idx[e]]) - np.array(p2[idx[e]])) for e in act}
+            self.movep(act, [[p1[idx[e]], p2[idx[e]]] for e in act])
+            for e in act:  # only grasp points on cloth
+                self.grasp_states[e] = [bool(p1_grasp_cloth[idx[e]]), bool(p2_grasp_cloth[idx[e]])]
+            # lift to prefling
+            self.movep(act, [[[dist[e] / 2, 0.3, -0.3], [-dist[e] / 2, 0.3, -0.3]] for e in act], speed=5e-3)
+            grasped = self.is_cloth_grasped(act)
+            keep = []
+            for e, g in zip(act, grasped):
+                if not g:
+                    self.terminate[e] = True
+                    out[e]["terminated"] = True
+                else:
+                    keep.append(e)
+            if keep:
+                d = self.stretch_cloth(keep, [dist[e] for e in keep], fling_height=0.3)
+                if self.fixed_fling_height == -1:
+                    h = self.lift_cloth(keep, d, fling_height=0.3)
+                else:
+                    h = [self.fixed_fling_height] * len(keep)
+                self.fling_primitive(keep, d, h, self.fling_speed)
+                for e, dd, hh in zip(keep, d, h):
+                    out[e]["dist"], out[e]["fling_height"] = dd, hh
+        return [out[e] for e in envs]

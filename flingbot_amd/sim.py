@@ -81,6 +81,10 @@ def load_library(build_if_missing=True):
         "fs_picker_get_picked": (ci, [vp, ci, ip, ci]),
         "fs_movep": (ci, [vp, ci, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
+        "fs_movep_batch_f32": (ci, [vp, ci, ip, fp, ip, C.c_double, ci, ci, C.c_double, ip]),
+        "fs_wait_until_stable": (ci, [vp, ci, ip, ci, C.c_double, ip, ip]),
+        "fs_cloth_stats": (ci, [vp, ci, ip, fp, ci]),
+        "fs_stretch_probe": (ci, [vp, ci, ip, fp, fp, ip, fp]),
         "fs_timer_start": (ci, [vp]),
         "fs_timer_stop": (ci, [vp, fp]),
         "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
@@ -181,20 +185,54 @@ class FlingSim:
         return out
 
     def movep(self, envs, targets, grasp, speed=0.1, limit=1000, min_steps=None, eps=1e-4):
-        """SimEnv.movep for one episode (envs = int) or a batch (envs = sequence).  targets [n,S,3] float64, grasp [n,S].
+        """SimEnv.movep for one episode (envs = int) or a batch (envs = sequence).  targets [n,S,3], grasp [n,S].
+        A float32 `targets` array keeps movep's arithmetic in float32, exactly as numpy does in the reference when
+        stretch_cloth passes float32 picker positions; anything else is float64 (python lists of floats).
         Returns the iteration counts; raises MoveLimitError like the reference's MoveJointsException."""
         single = np.isscalar(envs)
         ids = _i([envs] if single else envs)
-        tg = np.ascontiguousarray(np.asarray(targets, np.float64).reshape(ids.size, -1, 3))
+        arr = np.asarray(targets)
         gr = _i(np.asarray(grasp).astype(np.int32).reshape(ids.size, -1))
         iters = np.zeros(ids.size, np.int32)
-        rc = self.lib.fs_movep_batch(self.h, ids.size, _ip(ids), tg.ctypes.data_as(C.POINTER(C.c_double)), _ip(gr),
-                                     float(speed), int(limit), -1 if min_steps is None else int(min_steps), float(eps),
-                                     _ip(iters))
+        ms = -1 if min_steps is None else int(min_steps)
+        if arr.dtype == np.float32:
+            tg = np.ascontiguousarray(arr.reshape(ids.size, -1, 3))
+            rc = self.lib.fs_movep_batch_f32(self.h, ids.size, _ip(ids), _fp(tg), _ip(gr), float(speed), int(limit), ms,
+                                             float(eps), _ip(iters))
+        else:
+            tg = np.ascontiguousarray(arr.astype(np.float64).reshape(ids.size, -1, 3))
+            rc = self.lib.fs_movep_batch(self.h, ids.size, _ip(ids), tg.ctypes.data_as(C.POINTER(C.c_double)), _ip(gr),
+                                         float(speed), int(limit), ms, float(eps), _ip(iters))
         if rc == -4:
             raise MoveLimitError(self.lib.fs_last_error().decode())
         self._ck(rc)
         return int(iters[0]) if single else iters
+
+    def wait_until_stable(self, envs, max_steps=300, tolerance=1e-2):
+        """flex_utils.wait_until_stable (flex_utils.py:430-441) for one episode or a batch, looped on the device.
+        Returns (stable, steps): the reference's return value and the number of simulation steps taken, per episode."""
+        single = np.isscalar(envs)
+        ids = _i([envs] if single else envs)
+        steps, stable = np.zeros(ids.size, np.int32), np.zeros(ids.size, np.int32)
+        self._ck(self.lib.fs_wait_until_stable(self.h, ids.size, _ip(ids), int(max_steps), float(tolerance), _ip(steps),
+                                               _ip(stable)))
+        return (bool(stable[0]), int(steps[0])) if single else (stable.astype(bool), steps)
+
+    def cloth_stats(self, envs):
+        """[n,3] float32: min height, max height, max |velocity component| per episode (device reductions)."""
+        ids = _i([envs] if np.isscalar(envs) else envs)
+        out = np.empty((ids.size, 3), np.float32)
+        self._ck(self.lib.fs_cloth_stats(self.h, ids.size, _ip(ids), _fp(out), out.size))
+        return out
+
+    def stretch_probe(self, envs, midpoints_xz, height_thr):
+        """stretch_cloth's probe (simEnv.py:155-168) per episode: (single_grasp bool[n], nearest float32[n,3])."""
+        ids = _i([envs] if np.isscalar(envs) else envs)
+        mid = np.ascontiguousarray(np.asarray(midpoints_xz, np.float32).reshape(ids.size, 2))
+        thr = np.ascontiguousarray(np.asarray(height_thr, np.float32).reshape(ids.size))
+        single, near = np.zeros(ids.size, np.int32), np.empty((ids.size, 3), np.float32)
+        self._ck(self.lib.fs_stretch_probe(self.h, ids.size, _ip(ids), _fp(mid), _fp(thr), _ip(single), _fp(near)))
+        return single.astype(bool), near
 
     def timer_start(self):
         self._ck(self.lib.fs_timer_start(self.h))

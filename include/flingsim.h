@@ -135,6 +135,30 @@ int fs_movep(fs_ctx *ctx, int env, const double *targets, const int *grasp, doub
 /* the same for n episodes at once: targets double[n][S][3], grasp int[n][S], iterations_out int[n] */
 int fs_movep_batch(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed, int limit,
                    int min_steps, double eps, int *iterations_out);
+/* the same when the reference's `pos` argument is a float32 numpy array (stretch_cloth builds its targets from the
+   float32 picker positions, simEnv.py:146-156,180-182): movep's own arithmetic then runs in float32 */
+int fs_movep_batch_f32(fs_ctx *ctx, int n, const int *envs, const float *targets, const int *grasp, double speed,
+                       int limit, int min_steps, double eps, int *iterations_out);
+
+/* ---- device-side feedback loops and reductions -------------------------------------------------
+   The reference's primitives download whole particle arrays to take one number from them, every simulation step or
+   every loop trip; these entry points compute the same numbers on the device.                                        */
+/* flex_utils.py:430-441 wait_until_stable for n episodes at once: before EVERY step the episode's max |velocity
+   component| (float32, compared in double like `np.abs(v).max() < tolerance`) is tested; an episode that passes stops
+   stepping.  At most max_steps steps.  steps_out[k] = simulation steps taken, stable_out[k] = 1 when the test passed
+   (the function's return value), 0 when max_steps ran out.  No host round trip per step. */
+int fs_wait_until_stable(fs_ctx *ctx, int n, const int *envs, int max_steps, double tolerance, int *steps_out,
+                         int *stable_out);
+/* out[3k..3k+2] = { min height y, max height y, max |velocity component| } of episode envs[k]
+   (simEnv.py:186-200 lift_cloth `heights.min()`, :809-813 is_cloth_grasped `heights.max()`, flex_utils.py:435) */
+int fs_cloth_stats(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats);
+/* stretch_cloth's probe (simEnv.py:155-168) for episode envs[k]:
+     single_grasp_out[k] = 1 when every particle with y > height_thr[k] has x < 0, or every one has x > 0 (also when there
+                           is none), evaluated in float32 like the numpy expression;
+     nearest_out[3k..]   = position of the particle whose float32 distance to midpoint_xz[2k..2k+1] in the x-z plane,
+                           sqrt(dx*dx + dz*dz), is smallest (lowest index on ties = Python's stable sort). */
+int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float *midpoint_xz, const float *height_thr,
+                     int *single_grasp_out, float *nearest_out);
 
 /* ---- host-only entry points (no HIP device needed) ------------------------------------------------------------
    Scene builder exposed on its own so host logic can be checked without a GPU: same arguments as fs_set_scene. */

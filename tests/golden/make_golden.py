@@ -207,8 +207,160 @@ def picker_vectors():
     print("picker:", len(log["pos"]), "sim steps, iters", log["iters"], "picked", log["picked"][-1])
 
 
+def fling_vectors():
+    """The reference's SimEnv.pick_and_fling_primitive (with stretch_cloth, lift_cloth, fling_primitive, movep,
+    is_cloth_grasped, reset_end_effectors: environment/simEnv.py:140-318,739-813) followed by
+    flex_utils.wait_until_stable (flex_utils.py:430-441), executed by the reference's own code on a `pyflex` stub that is
+    backed by the CPU oracle.  SimEnv is instantiated without __init__ (which needs ray / HDF5 task files); every module
+    the import chain wants but this image lacks is replaced by an empty stub."""
+    sys.path.insert(0, ROOT)
+    from oracle import OracleSim
+
+    if not hasattr(np, "alltrue"):
+        np.alltrue = np.all
+    import torch  # noqa: F401  (before the stubs: its import machinery inspects sys.modules)
+    import scipy.ndimage  # noqa: F401
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, name): return _Any()
+
+    def anystub(name):
+        m = types.ModuleType(name)
+
+        def _ga(attr):
+            if attr.startswith("__"):
+                raise AttributeError(attr)
+            return _Any()
+        m.__getattr__ = _ga
+        m.__path__ = []
+        m.__file__ = "<stub %s>" % name
+        sys.modules[name] = m
+        return m
+
+    for name in ("h5py", "filelock", "imageio", "trimesh", "OpenEXR", "Imath", "cv2", "PIL", "skimage", "skimage.morphology",
+                 "matplotlib", "matplotlib.pyplot", "ray", "pyflex"):
+        if name not in ("pyflex",):
+            try:
+                __import__(name)
+                continue
+            except Exception:
+                pass
+        anystub(name)
+    sys.modules["ray"].remote = lambda f: f
+    orc_box = {}
+    pf = sys.modules["pyflex"]
+    for name in ("get_positions", "set_positions", "get_velocities", "set_velocities", "get_shape_states",
+                 "set_shape_states", "add_sphere", "get_phases", "set_phases"):
+        setattr(pf, name, (lambda nm: lambda *a, **k: getattr(orc_box["o"], nm)(*a, **k))(name))
+    counter = {"steps": 0}
+
+    def _step(*a, **k):
+        counter["steps"] += 1
+        orc_box["o"].step(1)
+    pf.step = _step
+    for m in [k for k in sys.modules if k == "environment" or k.startswith("environment.") or k in ("flex_utils", "nets")]:
+        del sys.modules[m]
+    sys.path.insert(0, REF)
+    from environment import simEnv as ref_simenv
+    from environment import flex_utils as ref_fu
+    SimEnv = ref_simenv.SimEnv
+
+    sp = np.array([0, 0.2, 0, 32, 32, 0.9, 0.9, 0.9, 2, 0, 2, 0, np.pi / 2, -np.pi / 2, 0, 720, 720, 0.3, 0])
+    dim = 32
+    xs = (np.arange(dim) - (dim - 1) / 2) * 0.00625
+    xx, zz = np.meshgrid(xs, xs)
+    cases = [  # (p1, p2, p1_grasp, p2_grasp): corners of the sheet / one-handed / a grasp that misses the cloth
+        ([xs[0], 0.0, xs[0]], [xs[-1], 0.0, xs[0]], True, True),
+        ([xs[2], 0.0, xs[5]], [xs[-8], 0.0, xs[-3]], True, False),
+        ([xs[0] - 0.05, 0.0, xs[0] - 0.05], [xs[-1] + 0.05, 0.0, xs[0] - 0.05], True, True),
+        ([xs[4], 0.0, xs[0]], [xs[-5], 0.0, xs[0]], False, False),
+    ]
+    rec = {k: [] for k in ("dist", "height", "terminate", "steps_fling", "stable", "steps_stable", "pos_fling", "pos_final",
+                           "shapes_final", "stretch_ret", "lift_ret")}
+    init_pos = None
+    for p1, p2, g1, g2 in cases:
+        orc = OracleSim()
+        orc_box["o"] = orc
+        orc.set_scene(sp)
+        orc.step(1)
+        n = orc.n
+        w = orc.get_positions().reshape(-1, 4)[0, 3]
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3] = xx.ravel(), 0.0125, zz.ravel(), w
+        init_pos = pos
+        orc.set_positions(pos.ravel())
+        orc.set_velocities(np.zeros(3 * n, np.float32))
+        env = SimEnv.__new__(SimEnv)
+        env.gui = False
+        env.gui_step = 0
+        env.dump_visualizations = False
+        env.default_speed = 1e-2
+        env.grasp_height = 0.02
+        env.fling_speed = 6e-3
+        env.fixed_fling_height = -1
+        env.particle_radius = 0.00625
+        env.terminate = False
+        env.grasp_states = [False, False]
+        env.env_video_frames = {}
+        env.action_tool = ref_fu.PickerPickPlace(num_picker=2, particle_radius=0.00625, picker_radius=0.02,
+                                                 picker_low=(-5, 0, -5), picker_high=(5, 5, 5))
+        env.action_tool.reset([0.0, 0.1, 0.0])
+        rets = {"stretch": None, "lift": None}
+        o_stretch, o_lift = SimEnv.stretch_cloth, SimEnv.lift_cloth
+
+        def stretch(self, *a, _o=o_stretch, **k):
+            rets["stretch"] = _o(self, *a, **k)
+            return rets["stretch"]
+
+        def lift(self, *a, _o=o_lift, **k):
+            rets["lift"] = _o(self, *a, **k)
+            return rets["lift"]
+        SimEnv.stretch_cloth, SimEnv.lift_cloth = stretch, lift
+        counter["steps"] = 0
+        try:
+            env.pick_and_fling_primitive(np.array(p1, np.float64), np.array(p2, np.float64), g1, g2)
+        finally:
+            SimEnv.stretch_cloth, SimEnv.lift_cloth = o_stretch, o_lift
+        rec["terminate"].append(bool(env.terminate))
+        rec["stretch_ret"].append(np.nan if rets["stretch"] is None else float(rets["stretch"]))
+        rec["lift_ret"].append(np.nan if rets["lift"] is None else float(rets["lift"]))
+        rec["steps_fling"].append(counter["steps"])
+        rec["pos_fling"].append(orc.get_positions().copy())
+        counter["steps"] = 0
+        stable = ref_fu.wait_until_stable(max_steps=150, tolerance=1e-2, step_sim_fn=env.step_simulation)
+        rec["stable"].append(bool(stable))
+        rec["steps_stable"].append(counter["steps"])
+        # wait_until_stable with something to wait for: the cloth as it lies, lifted by 0.25 and dropped
+        lifted = orc.get_positions().reshape(-1, 4).copy()
+        lifted[:, 1] += np.float32(0.25)
+        orc.set_positions(lifted.ravel())
+        vel = np.zeros((n, 3), np.float32)
+        vel[:, 1] = -0.5  # moving: the test that precedes every step must fail at first
+        orc.set_velocities(vel.ravel())
+        counter["steps"] = 0
+        stable2 = ref_fu.wait_until_stable(max_steps=60 + 30 * len(rec["stable"]), tolerance=2e-2,
+                                           step_sim_fn=env.step_simulation)
+        rec.setdefault("stable_drop", []).append(bool(stable2))
+        rec.setdefault("steps_drop", []).append(counter["steps"])
+        rec["pos_final"].append(orc.get_positions().copy())
+        rec["shapes_final"].append(orc.get_shape_states().copy())
+        print("fling case", len(rec["stable"]), "terminate", env.terminate, "stretch", rets["stretch"], "lift", rets["lift"],
+              "steps", rec["steps_fling"][-1], "stable", stable, "| drop: stable", stable2, "after", counter["steps"])
+    np.savez_compressed(os.path.join(HERE, "fling_golden.npz"), scene_params=sp, init_pos=init_pos,
+                        p1=np.array([c[0] for c in cases]), p2=np.array([c[1] for c in cases]),
+                        g1=np.array([c[2] for c in cases]), g2=np.array([c[3] for c in cases]),
+                        terminate=np.array(rec["terminate"]), stretch_ret=np.array(rec["stretch_ret"]),
+                        lift_ret=np.array(rec["lift_ret"]), steps_fling=np.array(rec["steps_fling"]),
+                        stable=np.array(rec["stable"]), steps_stable=np.array(rec["steps_stable"]),
+                        stable_drop=np.array(rec["stable_drop"]), steps_drop=np.array(rec["steps_drop"]),
+                        pos_fling=np.array(rec["pos_fling"]), pos_final=np.array(rec["pos_final"]),
+                        shapes_final=np.array(rec["shapes_final"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker"]
+    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling"]
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:
@@ -219,3 +371,5 @@ if __name__ == "__main__":
         envutils_vectors()
     if "picker" in which:
         picker_vectors()
+    if "fling" in which:
+        fling_vectors()

@@ -379,3 +379,23 @@ def test_picker_restatement_matches_reference_classes():
     assert np.array_equal(np.array(poss[::10]).view(np.uint32), g["pos_every_10"].view(np.uint32))
     assert np.array_equal(poss[-1].view(np.uint32), g["pos_last"].view(np.uint32))
     assert g["picked"][-1].tolist() == [0, -1] and g["picked"][5].tolist() == [0, 23]
+
+
+def test_fling_primitive_host_logic_reproduces_reference_golden():
+    """flingbot_amd.primitives.FlingPrimitives is pure host logic over a simulator interface: on the CPU oracle (with the
+    numpy restatement of the picker) it retraces the trajectories the REFERENCE's SimEnv methods produced
+    (tests/golden/fling_golden.npz), bit for bit."""
+    from fling_helpers import OracleBatch, load_fling_golden
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+    cases = [0, 1, 2, 3]  # two-handed (full stretch loop), one-handed (single-grasp exit), missed grasp (terminate), no grasp
+    sim = OracleBatch(len(cases), g["scene_params"], g["init_pos"])
+    prim = FlingPrimitives(sim, range(len(cases)))
+    out = prim.pick_and_fling(g["p1"][cases], g["p2"][cases], g["g1"][cases], g["g2"][cases])
+    for k, c in enumerate(cases):
+        assert out[k]["terminated"] == bool(g["terminate"][c])
+        if not np.isnan(g["stretch_ret"][c]):
+            assert out[k]["dist"] == g["stretch_ret"][c] and out[k]["fling_height"] == g["lift_ret"][c]
+        assert np.array_equal(sim.get_positions(k).view(np.uint32), g["pos_fling"][c].view(np.uint32)), c
+    assert out[3]["skipped"]
