@@ -178,10 +178,65 @@ def transform_async(*args, **kwargs):
     return transform(*args, **kwargs)
 
 
+def rotation_matrices(rotations, size):
+    """Matrix rows and offset of scipy.ndimage.rotate(angle, reshape=False) for a size x size plane (scipy
+    _interpolation.py: c, s = cosdg, sindg; [[c, s], [-s, c]]; offset = centre - matrix @ centre)."""
+    from scipy import special
+    mats, offs = [], []
+    for ang in rotations:
+        c, s_ = special.cosdg(ang), special.sindg(ang)
+        m = np.array([[c, s_], [-s_, c]])
+        centre = (np.array([size, size]) - 1) / 2
+        mats.append(m.ravel())
+        offs.append(centre - m @ centre)
+    return np.ascontiguousarray(mats, np.float64), np.ascontiguousarray(offs, np.float64)
+
+
+_prep_work = {}
+
+
+def prepare_image_device(img, transformations, dim: int):
+    """prepare_image (nets.py:177-193) for an observation that already lives on the GPU: one spline prefilter of the
+    observation + one gather kernel for all transforms (libflingsim fs_prepare_image, csrc/fs_image.hip) instead of
+    len(transformations) full-size scipy rotations on the host.  Returns a float32 CUDA tensor [T, C, dim, dim]."""
+    import ctypes as C
+    from .sim import load_library
+
+    lib = load_library()
+    assert img.is_cuda and img.dim() == 3 and img.shape[-1] == img.shape[-2], "expects a CUDA (C, S, S) observation"
+    img = img.contiguous().float()
+    ch, size = int(img.shape[0]), int(img.shape[-1])
+    rots = [float(t[0]) for t in transformations]
+    scales = np.ascontiguousarray([float(t[1]) for t in transformations], np.float64)
+    mats, offs = rotation_matrices(rots, size)
+    n = len(rots)
+    key = (img.device.index, ch, size, n)
+    nbytes = int(lib.fs_prepare_image_work_bytes(ch, size, n))
+    work = _prep_work.get(key)
+    if work is None or work.numel() < nbytes:
+        work = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        _prep_work[key] = work
+    out = torch.empty((n, ch, dim, dim), dtype=torch.float32, device=img.device)
+    dp = C.POINTER(C.c_double)
+    with torch.cuda.device(img.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.fs_prepare_image(C.c_void_p(img.data_ptr()), ch, size, n, mats.ctypes.data_as(dp), offs.ctypes.data_as(dp),
+                                  scales.ctypes.data_as(dp), int(dim), C.c_void_p(out.data_ptr()),
+                                  C.c_void_p(work.data_ptr()), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError("fs_prepare_image: " + lib.fs_last_error().decode())
+    return out
+
+
 def prepare_image(img, transformations, dim: int, parallelize=False, log=False):
     if log:
         start = time()
         print('preparing images')
+    if torch.is_tensor(img) and img.is_cuda:  # device-resident observation: the HIP path (no host copy, no scipy)
+        retval = prepare_image_device(img, transformations, dim)
+        if log:
+            print(f'prepare_image took {float(time() - start):.02f}s')
+        return retval
     imgs = [transform(img, *t, dim=dim) for t in transformations]
     retval = torch.stack(imgs).float()
     if log:

@@ -85,6 +85,9 @@ def load_library(build_if_missing=True):
         "fs_wait_until_stable": (ci, [vp, ci, ip, ci, C.c_double, ip, ip]),
         "fs_cloth_stats": (ci, [vp, ci, ip, fp, ci]),
         "fs_stretch_probe": (ci, [vp, ci, ip, fp, fp, ip, fp]),
+        "fs_prepare_image_work_bytes": (C.c_size_t, [ci, ci, ci]),
+        "fs_prepare_image": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), ci,
+                                  vp, vp, vp]),
         "fs_timer_start": (ci, [vp]),
         "fs_timer_stop": (ci, [vp, fp]),
         "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),

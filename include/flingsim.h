@@ -16,6 +16,8 @@
 #ifndef FLINGSIM_H
 #define FLINGSIM_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -159,6 +161,21 @@ int fs_cloth_stats(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats
                            sqrt(dx*dx + dz*dz), is smallest (lowest index on ties = Python's stable sort). */
 int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float *midpoint_xz, const float *height_thr,
                      int *single_grasp_out, float *nearest_out);
+
+/* ---- observation transforms on the device ---------------------------------------------------
+   learning/nets.py:155-193 prepare_image: n_transforms rotated / scaled / resized copies of one observation.
+     d_img   device float32 [channels][size][size]                  (the tensor preprocess_obs returns)
+     matrix  host double [n][4], offset host double [n][2]          rotation matrix rows and offset exactly as
+             scipy.ndimage.rotate(reshape=False) derives them from the angle (c, s = cosdg, sindg; [[c, s], [-s, c]];
+             offset = centre - matrix @ centre) -- computed by the caller so special angles stay exact
+     scale   host double [n]                                        <1 centre crop, >1 replicate pad to int(scale*size)
+     d_out   device float32 [n][channels][dim][dim]
+     d_work  device scratch of fs_prepare_image_work_bytes() bytes; stream: hipStream_t the work is enqueued on
+   Cubic-spline rotation (mode='nearest', float64 like scipy) evaluated only at the pixels the nearest-neighbour resize
+   keeps. */
+size_t fs_prepare_image_work_bytes(int channels, int size, int n_transforms);
+int fs_prepare_image(const float *d_img, int channels, int size, int n_transforms, const double *matrix,
+                     const double *offset, const double *scale, int dim, float *d_out, void *d_work, void *stream);
 
 /* ---- host-only entry points (no HIP device needed) ------------------------------------------------------------
    Scene builder exposed on its own so host logic can be checked without a GPU: same arguments as fs_set_scene. */
