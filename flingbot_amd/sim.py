@@ -88,6 +88,10 @@ def load_library(build_if_missing=True):
         "fs_prepare_image_work_bytes": (C.c_size_t, [ci, ci, ci]),
         "fs_prepare_image": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), ci,
                                   vp, vp, vp]),
+        "fs_select_action_work_bytes": (C.c_size_t, [ci]),
+        "fs_select_action": (ci, [vp, ci, ip, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci, C.c_double,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                                  C.c_double, C.POINTER(C.c_longlong), fp, vp, vp]),
         "fs_timer_start": (ci, [vp]),
         "fs_timer_stop": (ci, [vp, fp]),
         "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),

@@ -177,6 +177,30 @@ size_t fs_prepare_image_work_bytes(int channels, int size, int n_transforms);
 int fs_prepare_image(const float *d_img, int channels, int size, int n_transforms, const double *matrix,
                      const double *offset, const double *scale, int dim, float *d_out, void *d_work, void *stream);
 
+/* ---- action selection on the device ----------------------------------------------------------
+   SimEnv.get_max_value_valid_action (environment/simEnv.py:560-661): the best-valued VALID action over all primitives,
+   transforms and pixels.  A candidate (primitive p, transform t, pixel (y, z)) is valid when its two reach points lie
+   in the obs_dim image (get_action_params :517-537), map into the pretransform image (pixels_to_3d_positions,
+   environment/utils.py:237-276, with `transform_mats[t]` = get_transform_matrix(depth_dim, obs_dim, -rotation, scale)
+   row-major), unproject through `d_depth` (pixel_to_3d :214-234) and satisfy check_action_reachability (:539-558;
+   stretchdrag also at the end of its drag :624-642).
+     d_values  device float32 [n_primitives][n_transforms][obs_dim][obs_dim] (stacked value maps)
+     best_index_out  flattened index into values[:, :, g:-g, g:-g] (g = pix_grasp_dist) of the winner -- the entry the
+                     reference's descending walk stops at (ties: lowest flattened index) -- or -1 when nothing is valid
+     d_work    device scratch of fs_select_action_work_bytes(n_transforms) bytes; stream: hipStream_t */
+#define FS_ACTION_FLING 0
+#define FS_ACTION_STRETCHDRAG 1
+#define FS_ACTION_DRAG 2
+#define FS_ACTION_PLACE 3
+#define FS_ACTION_MAX_PRIMITIVES 8
+size_t fs_select_action_work_bytes(int n_transforms);
+int fs_select_action(const float *d_values, int n_primitives, const int *primitive_kinds, int n_transforms, int obs_dim,
+                     int pix_grasp_dist, int pix_drag_dist, int pix_place_dist, const double *transform_mats,
+                     const float *d_depth, int depth_dim, double focal_length, const double *pose_matrix,
+                     const double *left_arm_base, const double *right_arm_base, double reach_distance_limit,
+                     double stretchdrag_dist, double grasp_height, long long *best_index_out, float *best_value_out,
+                     void *d_work, void *stream);
+
 /* ---- host-only entry points (no HIP device needed) ------------------------------------------------------------
    Scene builder exposed on its own so host logic can be checked without a GPU: same arguments as fs_set_scene. */
 typedef struct fs_host_scene fs_host_scene;

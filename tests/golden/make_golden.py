@@ -359,8 +359,105 @@ def fling_vectors():
                         shapes_final=np.array(rec["shapes_final"]))
 
 
+def action_vectors():
+    """The reference's SimEnv.get_max_value_valid_action (environment/simEnv.py:560-661, with check_action :202-260,
+    get_action_params :517-537, check_action_reachability :542-558 and environment/utils.py pixels_to_3d_positions /
+    get_transform_matrix / pixel_to_3d / compute_pose) on synthetic value maps and depth images.  SimEnv is instantiated
+    without __init__; conservative_grasp_radius = 0 (the cloth-mask circles need cv2, absent here, and do not take part in
+    the selection); visualisation / logging hooks are no-ops."""
+    import torch
+    import scipy.ndimage  # noqa: F401
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, name): return _Any()
+
+    def anystub(name):
+        m = types.ModuleType(name)
+
+        def _ga(attr):
+            if attr.startswith("__"):
+                raise AttributeError(attr)
+            return _Any()
+        m.__getattr__ = _ga
+        m.__path__ = []
+        m.__file__ = "<stub %s>" % name
+        sys.modules[name] = m
+        return m
+
+    for name in ("h5py", "filelock", "imageio", "trimesh", "OpenEXR", "Imath", "cv2", "PIL", "skimage", "skimage.morphology",
+                 "matplotlib", "matplotlib.pyplot", "ray", "pyflex"):
+        if name != "pyflex":
+            try:
+                __import__(name)
+                continue
+            except Exception:
+                pass
+        anystub(name)
+    sys.modules["ray"].remote = lambda f: f
+    for m in [k for k in sys.modules if k == "environment" or k.startswith("environment.") or k in ("flex_utils", "nets")]:
+        del sys.modules[m]
+    sys.path.insert(0, REF)
+    from environment import simEnv as ref_simenv
+    ref_simenv.visualize_action = lambda **k: None
+    SimEnv = ref_simenv.SimEnv
+
+    rng = np.random.default_rng(7)
+    cases = []
+    # (primitives, obs_dim D, pretransform S, pix distances, reach limit, scales)
+    setups = [(["fling"], 32, 100, (8, 8, 5), 0.8, [0.75, 1.0, 1.5, 2.0]),
+              (["fling", "drag", "place"], 24, 72, (4, 6, 3), 0.7, [1.0, 1.25, 2.5]),
+              (["stretchdrag", "fling"], 24, 60, (5, 5, 5), 0.75, [1.0, 2.0]),
+              (["fling"], 32, 100, (8, 8, 5), 0.45, [1.0, 2.75])]
+    out = {}
+    for ci, (prims, D, S, (gd, dd, pd), reach, scales) in enumerate(setups):
+        env = SimEnv.__new__(SimEnv)
+        num_rot = 6
+        env.rotations = [(2 * i / (num_rot - 1) - 1) * 90 for i in range(num_rot)]
+        if "fling" not in prims:
+            env.rotations = [(2 * i / num_rot - 1) * 180 for i in range(num_rot)]
+        env.adaptive_scale_factors = np.array(scales)
+        env.obs_dim = D
+        env.pix_grasp_dist, env.pix_drag_dist, env.pix_place_dist = gd, dd, pd
+        env.conservative_grasp_radius = 0
+        env.left_arm_base = np.array([0.765, 0, 0])
+        env.right_arm_base = np.array([-0.765, 0, 0])
+        env.reach_distance_limit = reach
+        env.stretchdrag_dist = 0.3
+        env.grasp_height = 0.02
+        env.log_step_stats = lambda kw: None
+        T = num_rot * len(scales)
+        # depth: plane at 2.0 (camera height) with a cloth blob closer to the camera
+        yy, xx = np.mgrid[0:S, 0:S]
+        depth = np.full((S, S), 2.0, np.float32)
+        blob = ((xx - S * 0.55) ** 2 + (yy - S * 0.45) ** 2) < (S * 0.3) ** 2
+        depth[blob] = (1.98 - 0.05 * rng.random(blob.sum())).astype(np.float32)
+        env.pretransform_depth = depth
+        env.pretransform_rgb = np.zeros((S, S, 3), np.float32)
+        env.transformed_obs = torch.zeros(T, 4, D, D)
+        value_maps = {p: torch.tensor(rng.random((T, D, D)).astype(np.float32)) for p in prims}
+        if ci == 1:  # ties: quantised values, the first in flattened order must win
+            value_maps = {p: torch.round(v * 6) / 6 for p, v in value_maps.items()}
+        action, params = env.get_max_value_valid_action(value_maps)
+        out[f"c{ci}_prims"] = np.array(prims)
+        out[f"c{ci}_cfg"] = np.array([D, S, gd, dd, pd, num_rot], np.int64)
+        out[f"c{ci}_reach"] = np.array([reach, 0.3, 0.02])
+        out[f"c{ci}_scales"] = np.array(scales)
+        out[f"c{ci}_rotations"] = np.array(env.rotations)
+        out[f"c{ci}_depth"] = depth
+        out[f"c{ci}_values"] = np.stack([value_maps[p].numpy() for p in prims])
+        out[f"c{ci}_action"] = np.array("" if action is None else action)
+        if action is not None:
+            out[f"c{ci}_p1"] = np.array(params["p1"], np.float64)
+            out[f"c{ci}_p2"] = np.array(params["p2"], np.float64)
+            out[f"c{ci}_g"] = np.array([params["p1_grasp_cloth"], params["p2_grasp_cloth"]])
+        print("action case", ci, "->", action, None if params is None else (params["p1"], params["p2"]))
+    np.savez_compressed(os.path.join(HERE, "action_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling"]
+    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling", "action"]
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:
@@ -373,3 +470,5 @@ if __name__ == "__main__":
         picker_vectors()
     if "fling" in which:
         fling_vectors()
+    if "action" in which:
+        action_vectors()

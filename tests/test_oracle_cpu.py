@@ -399,3 +399,24 @@ def test_fling_primitive_host_logic_reproduces_reference_golden():
             assert out[k]["dist"] == g["stretch_ret"][c] and out[k]["fling_height"] == g["lift_ret"][c]
         assert np.array_equal(sim.get_positions(k).view(np.uint32), g["pos_fling"][c].view(np.uint32)), c
     assert out[3]["skipped"]
+
+
+def test_action_selection_restatement_matches_reference_golden():
+    """oracle/action.py against tests/golden/action_golden.npz -- SimEnv.get_max_value_valid_action of the REFERENCE run
+    on synthetic value maps and depth images (fling only / three primitives with tied values / stretchdrag / nothing
+    reachable)."""
+    from oracle import action as oa
+
+    g = np.load(os.path.join(GOLD, "action_golden.npz"))
+    for ci in range(4):
+        D, S, gd, dd, pd, _ = g[f"c{ci}_cfg"].tolist()
+        reach, sdist, gh = g[f"c{ci}_reach"].tolist()
+        cfg = dict(obs_dim=D, pix_grasp_dist=gd, pix_drag_dist=dd, pix_place_dist=pd, scales=g[f"c{ci}_scales"],
+                   rotations=g[f"c{ci}_rotations"].tolist(), depth=g[f"c{ci}_depth"], reach_distance_limit=reach,
+                   stretchdrag_dist=sdist, grasp_height=gh, left_arm_base=np.array([0.765, 0, 0]),
+                   right_arm_base=np.array([-0.765, 0, 0]))
+        action, res, _ = oa.get_max_value_valid_action(g[f"c{ci}_values"], g[f"c{ci}_prims"].tolist(), cfg)
+        want = str(g[f"c{ci}_action"])
+        assert (action or "") == want, ci
+        if want:
+            assert np.array_equal(res["p1"], g[f"c{ci}_p1"]) and np.array_equal(res["p2"], g[f"c{ci}_p2"]), ci
