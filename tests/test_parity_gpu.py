@@ -171,3 +171,52 @@ def test_mesh_path_bit_exact(gpu_required):
     hip.step(30)
     orc.step(30)
     _assert_state_equal(hip, orc, "mesh")
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_dense_ball_neighbor_cap_and_queue_overflow(gpu_required, solver):
+    """1024 particles squeezed into a 4 cm cube: ~90 particles within the search radius of each one, so neighbour lists
+    run into the 96-entry cap, the fused search overflows its per-thread hit queue and the register-staged list spills
+    into the in-memory insertion path.  Lists and the following steps must still equal the oracle's."""
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    p = cloth_params(32, 32, pos=(0.0, 0.3, 0.0))
+    rng = np.random.RandomState(5)
+    for s in (hip, orc):
+        s.set_scene(p)
+    pos = orc.get_positions().reshape(-1, 4).copy()
+    pos[:, :3] = (rng.rand(pos.shape[0], 3) * 0.04).astype(np.float32) + np.array([0.0, 0.3, 0.0], np.float32)
+    for s in (hip, orc):
+        s.set_positions(pos.ravel())
+        s.set_velocities(np.zeros(3 * pos.shape[0], np.float32))
+        s.step(1)
+    ch, lh = ctx.get_last_neighbors(0)
+    co, lo = orc.get_last_neighbors()
+    assert co.max() >= 90 and (co > 32).mean() > 0.5, "the case must be dense"
+    assert np.array_equal(ch, co)
+    mask = np.arange(96)[None, :] < co[:, None]  # entries beyond the count are unspecified
+    assert np.array_equal(np.where(mask, lh, -1), np.where(mask, lo, -1))
+    _assert_state_equal(hip, orc, "dense ball, step 1")
+    hip.step(2)
+    orc.step(2)
+    _assert_state_equal(hip, orc, "dense ball, step 3")
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_tether_springs_take_the_general_spring_path(gpu_required, solver):
+    """Negative stiffness = tether (unilateral, NvFlex.h:660): the fused kernel then keeps the full stiffness dictionary
+    and every wave runs the general spring form instead of the pre-halved fast one."""
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    p = cloth_params(32, 32, pos=(0.0, -0.05, 0.0), stiff=(0.9, -0.6, 0.9))
+    rng = np.random.RandomState(2)
+    for s in (hip, orc):
+        s.set_scene(p)
+    pos = orc.get_positions().reshape(-1, 4).copy()
+    pos[:, 1] += (rng.rand(pos.shape[0]) * 0.02).astype(np.float32)
+    for s in (hip, orc):
+        s.set_positions(pos.ravel())
+    assert (orc.get_spring_stiffness() < 0).any()
+    hip.step(25)
+    orc.step(25)
+    _assert_state_equal(hip, orc, "tethers")
