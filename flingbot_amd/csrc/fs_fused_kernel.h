@@ -47,7 +47,9 @@
 #define FS_FUSED_OFF_CACC (FS_FUSED_OFF_CSET + FS_FUSED_CSET_CAP * 2)
 #define FS_FUSED_OFF_CHIST (FS_FUSED_OFF_CACC + FS_FUSED_CSET_CAP * 16)
 #define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_CHIST + 512)
+#ifndef FS_FUSED_PREFETCH_CAND
 #define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
+#endif
 
 #define FS_GLOBAL __attribute__((address_space(1)))
 typedef FS_GLOBAL const int *fs_gci;
