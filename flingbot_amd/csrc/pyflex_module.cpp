@@ -229,4 +229,33 @@ PYBIND11_MODULE(pyflex, m) {
     m.def("get_scene_lower", []() { return bounds(false); });
     m.def("add_rigid_body", &pyflex_add_rigid_body);
     m.def("set_shape_color", &pyflex_set_shape_color, "Set the color of the shape");
+
+    // ---- additive names: the reference's host loops around step(), run on the device ----------
+    m.def("picker_reset", [](double picker_threshold, double particle_radius) {
+        if (fs_picker_reset(ctx(), 0, picker_threshold, particle_radius) != FS_OK) fail("pyflex.picker_reset");
+    }, py::arg("picker_threshold") = 0.005, py::arg("particle_radius") = 0.00625,
+          "Picker.reset bookkeeping (flex_utils.py:85,99-101) for the spheres added with add_sphere");
+    m.def("movep", [](py::array targets, py::array_t<int, py::array::c_style | py::array::forcecast> grasp, double speed,
+                      int limit, py::object min_steps, double eps) {
+        int iters = 0, rc;
+        const int ms = min_steps.is_none() ? -1 : min_steps.cast<int>();
+        if (targets.dtype().is(py::dtype::of<float>())) {  // float32 targets: movep's arithmetic stays in float32
+            auto t = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(targets);
+            rc = fs_movep_batch_f32(ctx(), 1, (const int[]){0}, t.data(), grasp.data(), speed, limit, ms, eps, &iters);
+        } else {
+            auto t = py::array_t<double, py::array::c_style | py::array::forcecast>::ensure(targets);
+            rc = fs_movep(ctx(), 0, t.data(), grasp.data(), speed, limit, ms, eps, &iters);
+        }
+        if (rc == FS_ERR_LIMIT) throw std::runtime_error("MoveJointsException: movep limit reached");
+        if (rc != FS_OK) fail("pyflex.movep");
+        return iters;
+    }, py::arg("targets"), py::arg("grasp"), py::arg("speed") = 0.1, py::arg("limit") = 1000,
+          py::arg("min_steps") = py::none(), py::arg("eps") = 1e-4,
+          "SimEnv.movep (simEnv.py:739-769): every simulation step on the device; returns the loop iterations");
+    m.def("wait_until_stable", [](int max_steps, double tolerance) {
+        int env = 0, steps = 0, stable = 0;
+        if (fs_wait_until_stable(ctx(), 1, &env, max_steps, tolerance, &steps, &stable) != FS_OK) fail("pyflex.wait_until_stable");
+        return py::make_tuple(stable != 0, steps);
+    }, py::arg("max_steps") = 300, py::arg("tolerance") = 1e-2,
+          "flex_utils.wait_until_stable (flex_utils.py:430-441) looped on the device; returns (stable, steps taken)");
 }

@@ -16,6 +16,7 @@ get_shape_states set_shape_states clear_shapes get_scene_upper get_scene_lower a
 
 
 def _import_pyflex():
+    import torch  # noqa: F401  -- load order: torch's ROCm runtime first, as in every other test of this suite
     from flingbot_amd import build
 
     path = build.build_pyflex()
@@ -31,6 +32,8 @@ def test_module_exports_the_reference_surface():
     pyflex = _import_pyflex()
     assert len(REFERENCE_NAMES) == 40
     for name in REFERENCE_NAMES:
+        assert callable(getattr(pyflex, name, None)), f"pyflex.{name} missing"
+    for name in ("picker_reset", "movep", "wait_until_stable"):  # additive device-side loops
         assert callable(getattr(pyflex, name, None)), f"pyflex.{name} missing"
     # init takes four REQUIRED positionals like the reference (m.def without py::arg, pyflex.cpp:1138)
     with pytest.raises(TypeError):
@@ -103,4 +106,30 @@ def test_reference_call_pattern_matches_oracle(gpu_required):
     assert pyflex.get_rigidOffsets().size == 0 and pyflex.get_n_rigids() == 0
     with pytest.raises(RuntimeError):
         pyflex.add_box(np.ones(3), np.zeros(3), np.array([1, 0, 0, 0.0]), 0)
+    # additive device-side loops: movep + wait_until_stable equal the numpy restatement driving the oracle
+    from oracle.picker import OraclePicker
+
+    tool = OraclePicker(orc)
+    tool.particle_inv_mass = orc.get_positions().reshape(-1, 4)[:, 3].copy()
+    tool.particle_inv_mass[5] = pos[5, 3]  # particle 5 was pinned by hand above; its saved mass is the original one
+    p = np.array(pyflex.get_positions()).reshape(-1, 4)
+    p[5, 3] = pos[5, 3]
+    pyflex.set_positions(p)
+    orc.set_positions(p.astype(np.float32).ravel())
+    pyflex.picker_reset()
+    cur = np.array(pyflex.get_shape_states()).reshape(-1, 14)[:, :3].astype(np.float64)
+    targets = cur + [[0.01, -0.03, 0.02], [-0.02, -0.03, 0.0]]
+    it = pyflex.movep(targets, [1, 0], speed=4e-3)
+    assert it == tool.movep(targets, [True, False], speed=4e-3)
+    stable, steps = pyflex.wait_until_stable(max_steps=25, tolerance=1e-2)
+    done, ok = 0, False
+    for _ in range(25):
+        if np.abs(orc.get_velocities()).max() < 1e-2:
+            ok = True
+            break
+        orc.step()
+        done += 1
+    assert (stable, steps) == (ok, done)
+    assert np.array_equal(pyflex.get_positions().view(np.uint32), orc.get_positions().view(np.uint32))
+    assert np.array_equal(pyflex.get_shape_states().view(np.uint32), orc.get_shape_states().view(np.uint32))
     pyflex.clean()
