@@ -1,0 +1,17 @@
+"""Development helper: step time of cloths that do not fit the fused LDS kernel (N > 4096): streaming back-end."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from conftest import cloth_params
+from flingbot_amd import sim as fsim
+
+for dim, E in ((64, 64), (80, 64), (104, 64), (104, 16), (104, 1)):
+    ctx = fsim.FlingSim(n_envs=E, solver=1 if dim == 64 else 0)
+    for e in range(E):
+        ctx.set_scene(e, cloth_params(dim, dim, pos=(0.0, -0.3, 0.0)))
+    ctx.step(3); ctx.sync()
+    ctx.timer_start(); ctx.step(10); ms = ctx.timer_stop() / 10
+    print("%3dx%-3d cloth, %3d episodes, %s: %.2f ms/step -> %.0f episode-steps/s" % (
+        dim, dim, E, "streaming" if True else "", ms, E / ms * 1e3), flush=True)
+    ctx.close()
