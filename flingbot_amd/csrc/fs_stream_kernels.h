@@ -155,8 +155,30 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, co
         return;
     }
     FsAcc a = {0.0f, 0.0f, 0.0f, 0};
-    for (int q = E.adj_off[i]; q < E.adj_off[i + 1]; ++q)
-        fs_spring(a, xi.x, xi.y, xi.z, xi.w, src[E.adj_j[q]], E.adj_len[q], E.adj_k[q]);
+    // slot-major (ELL) adjacency: the wave's loads of slot s are contiguous (the CSR rows of neighbouring particles are 12
+    // entries apart, i.e. one cache line per lane); slots ascend with the spring id, like the CSR rows.  Four slots per
+    // trip: their index / length / stiffness loads and then their four position gathers are in flight together.
+    const unsigned un = (unsigned)E.n;
+    const int max_deg = E.max_deg;
+    for (int s0 = 0; s0 < max_deg; s0 += 4) {
+        int jj[4];
+        float ll[4], kk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = s0 + q < max_deg;
+            const unsigned at = (unsigned)(s0 + q) * un + (unsigned)i;
+            jj[q] = in ? E.ell_j[at] : -1;
+            ll[q] = in ? E.ell_len[at] : 0.0f;
+            kk[q] = in ? E.ell_k[at] : 0.0f;
+        }
+        FsVec4 xj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xj[q] = src[jj[q] < 0 ? i : jj[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (jj[q] >= 0) fs_spring(a, xi.x, xi.y, xi.z, xi.w, xj[q], ll[q], kk[q]);
+        if (jj[3] < 0) break;  // the padding (-1) is at the tail of every row
+    }
     const FsVec4 x0i = E.x0[i];
     const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
     const int nc = E.ncount[i];
