@@ -200,6 +200,16 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
     return topo;
 }
 
+// summary of an episode's phases for the streaming neighbour search (FsEnvDev::find_mode)
+static int phase_find_mode(const int *phase, int n, int restnear_ok) {
+    if (n <= 0) return 0;
+    for (int i = 1; i < n; ++i)
+        if (phase[i] != phase[0]) return 0;
+    if (!(phase[0] & FS_PHASE_SELF_COLLIDE)) return 3;
+    if (!(phase[0] & FS_PHASE_SELF_COLLIDE_FILTER)) return 2;
+    return restnear_ok ? 1 : 0;
+}
+
 static int push_env_desc(fs_ctx *ctx, int env) {
     HIP_TRY(hipMemcpyAsync(ctx->d_envs + env, &ctx->envs[env].dev, sizeof(FsEnvDev), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -261,6 +271,7 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     d.rest = topo->rest; d.adj_off = topo->adj_off; d.adj_j = topo->adj_j; d.adj_len = topo->adj_len; d.adj_k = topo->adj_k;
     d.ell_j = topo->ell_j; d.ell_len = topo->ell_len; d.ell_k = topo->ell_k;
     d.restnear_w = topo->restnear_w; d.restnear_ok = topo->restnear_ok;
+    d.find_mode = phase_find_mode(scene.phase.data(), scene.n, topo->restnear_ok);
     d.dict_size = topo->dict_size; d.dict = topo->dict; d.code_w = topo->code_w; d.nbr_w = topo->nbr_w;
     d.p = scene.params;
 
@@ -451,7 +462,14 @@ extern "C" int fs_set_phases(fs_ctx *ctx, int env, const int *in, int n_ints) {
     if (!e || !in) return FS_ERR_ARG;
     CHECK_LEN(n_ints, e->host.n);
     HIP_TRY(hipSetDevice(ctx->device));
-    return h2d(ctx, e->dev.phase, in, size_t(4) * e->host.n);
+    int rc = h2d(ctx, e->dev.phase, in, size_t(4) * e->host.n);
+    if (rc != FS_OK) return rc;
+    const int mode = phase_find_mode(in, e->host.n, e->dev.restnear_ok);
+    if (mode != e->dev.find_mode) {
+        e->dev.find_mode = mode;
+        rc = push_env_desc(ctx, env);
+    }
+    return rc;
 }
 extern "C" int fs_get_rest_positions(fs_ctx *ctx, int env, float *out, int n_floats) {
     FsEnv *e = get_env(ctx, env);

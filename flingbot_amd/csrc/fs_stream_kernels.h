@@ -9,6 +9,16 @@
 
 #define FS_TILE 256
 
+// Cell -> bucket of the global hash, like the fused kernel's: the row (cy, cz) is hashed and x added on top, so the three
+// cells cx-1..cx+1 a search visits per row are adjacent buckets = ONE contiguous run of the bucket-ordered arrays.
+__device__ __forceinline__ int fs_stream_bucket(int cx, int cy, int cz) {
+    const unsigned h = (unsigned)cy * 0x85EBCA77u + (unsigned)cz * 0xC2B2AE3Du;
+    return (int)(((h ^ (h >> 15)) * 0x2C1B3C6Du >> 18) + (unsigned)cx) & (FS_GRID_BUCKETS - 1);
+}
+#ifndef FS_STREAM_CHUNK
+#define FS_STREAM_CHUNK 6  // springs whose loads are issued together in fs_k_iterate
+#endif
+
 // ---- predict + cell histogram.  reference: gravity NvFlex.h:99, damping :117, invMass == 0 -> kinematic :545
 __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *ids) {
     if (ids[blockIdx.y] < 0) return;  // retired slot
@@ -32,7 +42,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, co
     }
     E.xa[i] = xp;
     const float inv = 1.0f / (p.radius + p.particleCollisionMargin);
-    int b = fs_bucket((int)floorf(xp.x * inv), (int)floorf(xp.y * inv), (int)floorf(xp.z * inv));
+    int b = fs_stream_bucket((int)floorf(xp.x * inv), (int)floorf(xp.y * inv), (int)floorf(xp.z * inv));
     atomicAdd(&E.cell_count[b], 1);
 }
 
@@ -78,64 +88,108 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
     const FsParams &p = E.p;
     const float inv = 1.0f / (p.radius + p.particleCollisionMargin);
     FsVec4 xp = E.xa[i];
-    int b = fs_bucket((int)floorf(xp.x * inv), (int)floorf(xp.y * inv), (int)floorf(xp.z * inv));
+    int b = fs_stream_bucket((int)floorf(xp.x * inv), (int)floorf(xp.y * inv), (int)floorf(xp.z * inv));
     int slot = atomicAdd(&E.cell_fill[b], 1);
-    E.cell_items[slot] = i;
+    // bucket-ordered copy of the predicted positions with the particle id in w: the search reads candidates sequentially
+    // (xb is free until the first Jacobi iteration writes it)
+    E.xb[slot] = FsVec4{xp.x, xp.y, xp.z, __int_as_float(i)};
 }
 
 // ---- particle-contact candidates: ascending neighbour id, the (up to) 96 smallest ids.
-// A bucket spans [end[b] - size, end[b]); sizes are recovered from consecutive ends (end[b-1] == start[b]).
+// Same two-phase scheme as the fused kernel (fs_fused_kernel.h), on global arrays: threads take the particles in BUCKET
+// order (thread <-> slot of the sorted copy in xb); phase A scans the 9 runs (3 adjacent buckets each) four candidates per
+// trip and parks a packed entry (slot | 4-bit hit mask) per trip with hits in a per-thread LDS queue; phase B walks the
+// queue one survivor per trip: id, self test, phase / rest-pose filter (set membership on the packed rest-near ids when
+// the whole cloth is one phase), sorted duplicate-free insertion with the four smallest ids staged in registers.
+// A bucket spans [end[b-1], end[b]) of the sorted arrays (cell_fill holds the ends after the scatter).
+#define FS_STREAM_FINDQ 32
 __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids) {
     if (ids[blockIdx.y] < 0) return;  // retired slot
     const FsEnvDev &E = envs[ids[blockIdx.y]];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
-    if (i >= E.n) return;
+    __shared__ uint32_t queue_s[FS_STREAM_FINDQ][FS_TILE];
+    const int qs = blockIdx.x * FS_TILE + threadIdx.x;
+    const int n = E.n;
+    if (qs >= n) return;
     const FsParams &p = E.p;
     const float r = p.radius + p.particleCollisionMargin;
-    const float r2 = r * r;
-    const float inv = 1.0f / r;
-    const int n = E.n;
     const int cap = p.maxNeighbors < FS_MAX_NEIGHBORS ? p.maxNeighbors : FS_MAX_NEIGHBORS;
-    const FsVec4 xi = E.xa[i];
-    const int phi = E.phase[i];
-    const FsVec4 ri = E.rest[i];
-    const int cx = (int)floorf(xi.x * inv), cy = (int)floorf(xi.y * inv), cz = (int)floorf(xi.z * inv);
-    int cnt = 0;
+    const FsFindConsts c = {n, cap, r * r, 1.0f / r, E.find_mode};
+    const fs_gcv4 xs = (fs_gcv4)E.xb;
+    const fs_gci fill = (fs_gci)E.cell_fill, phase = (fs_gci)E.phase;
+    const fs_gi nlist = (fs_gi)E.nlist;
+    const FsVec4 xsi = fs_ld4(E.xb, qs);
+    const FsVec4 xi = FsVec4{xsi.x, xsi.y, xsi.z, 0.0f};
+    const int i = __float_as_int(xsi.w);
+    if (c.mode == 3) {  // one phase without the SelfCollide flag: no pairs at all
+        E.ncount[i] = 0;
+        return;
+    }
+    FsNearWords near;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) near.w[q] = c.mode == 1 ? E.restnear_w[(size_t)q * n + i] : 0xffffffffu;
+    const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
+    int phi = 0, qn = 0;
+    FsNbList L = {FS_NB_EMPTY, FS_NB_EMPTY, FS_NB_EMPTY, FS_NB_EMPTY, 0};
+    FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+    bool have_meta = false;
+    uint32_t *queue = &queue_s[0][threadIdx.x];
+
+    auto drain = [&]() {  // phase B over the queued entries
+        int e = 0, qb = 0;
+        unsigned m = 0u;
+        for (;;) {
+            if (!m) {
+                if (e == qn) break;
+                const uint32_t u = queue[e * FS_TILE];
+                ++e;
+                m = u & 15u;
+                qb = (int)(u >> 4);
+            }
+            const int at = qb + __builtin_ctz(m);
+            m &= m - 1u;
+            const int j = __float_as_int(xs[at < n ? at : n - 1].w);
+            if (j == i) continue;
+            fs_fused_accept(c, i, j, L, phi, ri, have_meta, phase, E.rest, nlist, near);
+        }
+        qn = 0;
+    };
+
     for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int b = fs_bucket(cx + dx, cy + dy, cz + dz);
-                const int beg = (b == 0) ? 0 : E.cell_fill[b - 1];
-                const int end = E.cell_fill[b];
-                for (int q = beg; q < end; ++q) {
-                    const int j = E.cell_items[q];
-                    if (j == i) continue;
-                    const FsVec4 xj = E.xa[j];
-                    // the bucket may alias a far-away cell: require the true cell to be the visited one
-                    if ((int)floorf(xj.x * inv) != cx + dx || (int)floorf(xj.y * inv) != cy + dy ||
-                        (int)floorf(xj.z * inv) != cz + dz)
-                        continue;
-                    float ex = xi.x - xj.x, ey = xi.y - xj.y, ez = xi.z - xj.z;
-                    float d2 = ex * ex + ey * ey + ez * ez;
-                    if (!(d2 < r2)) continue;
-                    if (!fs_pair_allowed(phi, E.phase[j], ri, E.rest[j], r2)) continue;
-                    // sorted insert, keep the `cap` smallest ids
-                    if (cnt == cap) {
-                        if (j > E.nlist[(size_t)(cap - 1) * n + i]) continue;
-                        cnt = cap - 1;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int b0 = fs_stream_bucket(cx - 1, cy + dy, cz + dz);
+            const int wrap = b0 + 2 - (FS_GRID_BUCKETS - 1);  // > 0: that many buckets continue at bucket 0
+            for (int seg = 0; seg < 2; ++seg) {
+                int beg, end;
+                if (seg == 0) {
+                    beg = (b0 == 0) ? 0 : fill[b0 - 1];
+                    end = fill[wrap > 0 ? FS_GRID_BUCKETS - 1 : b0 + 2];
+                } else {
+                    if (wrap <= 0) break;
+                    beg = 0;
+                    end = fill[wrap - 1];
+                }
+                for (int q = beg & ~3; q < end; q += 4) {
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int at = q + k < n ? q + k : n - 1;  // (clamped slots are masked out below)
+                        const FsVec4 xj = fs_ld4(E.xb, at);
+                        const float ex = xi.x - xj.x, ey = xi.y - xj.y, ez = xi.z - xj.z;
+                        const float d2 = ex * ex + ey * ey + ez * ez;
+                        m |= (unsigned)(d2 < c.rad2) << k;
                     }
-                    int s = cnt;
-                    while (s > 0) {
-                        int prev = E.nlist[(size_t)(s - 1) * n + i];
-                        if (prev < j) break;
-                        E.nlist[(size_t)s * n + i] = prev;
-                        --s;
+                    const int lo = beg - q > 0 ? beg - q : 0, hi = end - q < 4 ? end - q : 4;
+                    m &= ((1u << (hi - lo)) - 1u) << lo;
+                    if (m) {
+                        if (qn == FS_STREAM_FINDQ) drain();  // queue full (dense crumple): work it off first
+                        queue[qn * FS_TILE] = ((uint32_t)q << 4) | m;
+                        ++qn;
                     }
-                    E.nlist[(size_t)s * n + i] = j;
-                    ++cnt;
                 }
             }
-    E.ncount[i] = cnt;
+        }
+    drain();
+    E.ncount[i] = fs_fused_nb_finish(c, i, L, nlist);
 }
 
 // ---- one Jacobi iteration: solveSprings + solveContacts + applyDeltas for particle i
@@ -156,28 +210,28 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, co
     }
     FsAcc a = {0.0f, 0.0f, 0.0f, 0};
     // slot-major (ELL) adjacency: the wave's loads of slot s are contiguous (the CSR rows of neighbouring particles are 12
-    // entries apart, i.e. one cache line per lane); slots ascend with the spring id, like the CSR rows.  Four slots per
+    // entries apart, i.e. one cache line per lane); slots ascend with the spring id, like the CSR rows.  FS_STREAM_CHUNK slots per
     // trip: their index / length / stiffness loads and then their four position gathers are in flight together.
     const unsigned un = (unsigned)E.n;
     const int max_deg = E.max_deg;
-    for (int s0 = 0; s0 < max_deg; s0 += 4) {
-        int jj[4];
-        float ll[4], kk[4];
+    for (int s0 = 0; s0 < max_deg; s0 += FS_STREAM_CHUNK) {
+        int jj[FS_STREAM_CHUNK];
+        float ll[FS_STREAM_CHUNK], kk[FS_STREAM_CHUNK];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < FS_STREAM_CHUNK; ++q) {
             const bool in = s0 + q < max_deg;
             const unsigned at = (unsigned)(s0 + q) * un + (unsigned)i;
             jj[q] = in ? E.ell_j[at] : -1;
             ll[q] = in ? E.ell_len[at] : 0.0f;
             kk[q] = in ? E.ell_k[at] : 0.0f;
         }
-        FsVec4 xj[4];
+        FsVec4 xj[FS_STREAM_CHUNK];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xj[q] = src[jj[q] < 0 ? i : jj[q]];
+        for (int q = 0; q < FS_STREAM_CHUNK; ++q) xj[q] = src[jj[q] < 0 ? i : jj[q]];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (jj[q] >= 0) fs_spring(a, xi.x, xi.y, xi.z, xi.w, xj[q], ll[q], kk[q]);
-        if (jj[3] < 0) break;  // the padding (-1) is at the tail of every row
+        for (int q = 0; q < FS_STREAM_CHUNK; ++q)
+            fs_spring_bf(a, xi.x, xi.y, xi.z, xi.w, xj[q], ll[q], kk[q]);  // a padded slot gathers the particle itself: length 0, inactive
+        if (jj[FS_STREAM_CHUNK - 1] < 0) break;  // the padding (-1) is at the tail of every row
     }
     const FsVec4 x0i = E.x0[i];
     const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;

@@ -76,6 +76,10 @@ struct FsEnvDev {
     const uint32_t *nbr_w;   // [8][n]
     // rest-pose neighbour ids for the SelfCollideFilter test, packed like nbr_w but holding plain particle ids
     const uint32_t *restnear_w;  // [8][n], 0xffff = empty
-    int restnear_ok, pad1;
+    int restnear_ok;
+    int find_mode;  // host-maintained summary of the phases (fs_set_scene / fs_set_phases), used by the streaming search:
+                    // 0 mixed phases: test every pair; 1 one phase with SelfCollide|SelfCollideFilter and restnear_ok: rest-near
+                    // membership test; 2 one phase, SelfCollide without filter: every pair in range; 3 one phase, no
+                    // SelfCollide: no pairs
     FsParams p;
 };

@@ -6,7 +6,10 @@ import numpy as np
 from conftest import cloth_params
 from flingbot_amd import sim as fsim
 
-for dim, E in ((64, 64), (80, 64), (104, 64), (104, 16), (104, 1)):
+cases = ((64, 64), (80, 64), (104, 64), (104, 16), (104, 1))
+if len(sys.argv) > 2:
+    cases = ((int(sys.argv[1]), int(sys.argv[2])),)
+for dim, E in cases:
     ctx = fsim.FlingSim(n_envs=E, solver=1 if dim == 64 else 0)
     for e in range(E):
         ctx.set_scene(e, cloth_params(dim, dim, pos=(0.0, -0.3, 0.0)))
