@@ -313,9 +313,16 @@ extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
 int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids) {
     int solver = ctx->solver;
     if (solver == FS_SOLVER_AUTO) {
+        // The fused kernel gives one CU to an episode for the whole frame: unbeatable once the launch fills the chip, but a
+        // small launch leaves most CUs idle while the streaming kernels spread every stage over all of them.  Measured
+        // crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py): between 64 and 128 episodes.
         solver = FS_SOLVER_FUSED;
-        for (int id : ids)
+        size_t particles = 0;
+        for (int id : ids) {
             if (!fs_fused_supported(ctx, ctx->envs[id])) solver = FS_SOLVER_STREAM;
+            particles += (size_t)ctx->envs[id].host.n;
+        }
+        if (particles < (size_t)96 * 4096) solver = FS_SOLVER_STREAM;
     } else if (solver == FS_SOLVER_FUSED) {
         for (int id : ids)
             if (!fs_fused_supported(ctx, ctx->envs[id])) {
