@@ -220,3 +220,27 @@ def test_tether_springs_take_the_general_spring_path(gpu_required, solver):
     hip.step(25)
     orc.step(25)
     _assert_state_equal(hip, orc, "tethers")
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_mixed_phases_take_the_general_pair_filter(gpu_required, solver):
+    """Two phase groups in one cloth (NvFlex.h:159-192): the search cannot use the single-phase shortcuts (rest-near id
+    sets) and has to test phases and rest positions pair by pair; set_phases must also refresh the host-side summary the
+    streaming search reads."""
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    for s in (hip, orc):
+        sc.scenario_crumple(s, 32, 32, seed=3, lift_steps=10, settle_steps=0)
+    ph = orc.get_phases().copy()
+    n = ph.shape[0]
+    group1_no_filter = (ph[0] & ~((1 << 20) - 1) & ~(1 << 21)) | 1  # group 1, SelfCollide kept, SelfCollideFilter off
+    ph[n // 2:] = group1_no_filter
+    for s in (hip, orc):
+        s.set_phases(ph)
+        s.step(25)
+    ch, lh = ctx.get_last_neighbors(0)
+    co, lo = orc.get_last_neighbors()
+    assert np.array_equal(ch, co) and co.max() > 0
+    mask = np.arange(96)[None, :] < co[:, None]
+    assert np.array_equal(np.where(mask, lh, -1), np.where(mask, lo, -1))
+    _assert_state_equal(hip, orc, "mixed phases")
