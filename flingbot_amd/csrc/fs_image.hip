@@ -26,20 +26,65 @@
 // initialisation (what scipy applies for mode 'nearest' after padding).
 __device__ __forceinline__ void fs_spline_line(double *c, int n, int stride) {
     const double z = -0.26794919243112270647;  // sqrt(3) - 2
-    for (int i = 0; i < n; ++i) c[(size_t)i * stride] *= 6.0;
-    {   // _init_causal_mirror
+    // The recursions are sequential, the memory accesses are not: every pass moves FS_SPLINE_CHUNK samples between
+    // memory and registers at a time, so a thread has that many loads in flight instead of one dependent load per step.
+    constexpr int CH = 8;
+    double c0;
+    {   // gain + _init_causal_mirror: c0 = sum_i z^i c[i] (mirror tail weighted by z^(n-1))
         const double z_n_1 = pow(z, (double)(n - 1));
         double z_i = z;
-        double c0 = c[0] + z_n_1 * c[(size_t)(n - 1) * stride];
-        for (int i = 1; i < n - 1; ++i) {
-            c0 += z_i * (c[(size_t)i * stride] + z_n_1 * c[(size_t)(n - 1 - i) * stride]);
-            z_i *= z;
+        c0 = 6.0 * c[0] + z_n_1 * (6.0 * c[(size_t)(n - 1) * stride]);
+        for (int i0 = 1; i0 < n - 1; i0 += CH) {
+            double a[CH], b[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = i0 + k;
+                a[k] = i < n - 1 ? c[(size_t)i * stride] : 0.0;
+                b[k] = i < n - 1 ? c[(size_t)(n - 1 - i) * stride] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (i0 + k < n - 1) {
+                    c0 += z_i * (6.0 * a[k] + z_n_1 * (6.0 * b[k]));
+                    z_i *= z;
+                }
         }
-        c[0] = c0 / (1.0 - z_n_1 * z_n_1);
+        c0 /= 1.0 - z_n_1 * z_n_1;
     }
-    for (int i = 1; i < n; ++i) c[(size_t)i * stride] += z * c[(size_t)(i - 1) * stride];
-    c[(size_t)(n - 1) * stride] = (z * c[(size_t)(n - 2) * stride] + c[(size_t)(n - 1) * stride]) * z / (z * z - 1.0);
-    for (int i = n - 2; i >= 0; --i) c[(size_t)i * stride] = z * (c[(size_t)(i + 1) * stride] - c[(size_t)i * stride]);
+    // causal pass (with the gain folded in): c[i] = 6 c[i] + z c[i-1]
+    double prev = c0;
+    c[0] = c0;
+    for (int i0 = 1; i0 < n; i0 += CH) {
+        double a[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) a[k] = i0 + k < n ? c[(size_t)(i0 + k) * stride] : 0.0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (i0 + k < n) {
+                prev = 6.0 * a[k] + z * prev;
+                a[k] = prev;
+            }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (i0 + k < n) c[(size_t)(i0 + k) * stride] = a[k];
+    }
+    // _init_anticausal_mirror, then the anticausal pass c[i] = z (c[i+1] - c[i])
+    double nxt = (z * c[(size_t)(n - 2) * stride] + prev) * z / (z * z - 1.0);
+    c[(size_t)(n - 1) * stride] = nxt;
+    for (int i0 = n - 2; i0 >= 0; i0 -= CH) {
+        double a[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) a[k] = i0 - k >= 0 ? c[(size_t)(i0 - k) * stride] : 0.0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (i0 - k >= 0) {
+                nxt = z * (nxt - a[k]);
+                a[k] = nxt;
+            }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (i0 - k >= 0) c[(size_t)(i0 - k) * stride] = a[k];
+    }
 }
 
 // coef[c][a0][a1], a0 = x (+pad), a1 = y (+pad): edge-padded copy of A[x][y][c] = img[c][y][x]
