@@ -71,6 +71,19 @@ def cpu_baseline(warmup, budget_s=15.0):
     from oracle import OracleSim
 
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:  # a container's CPU quota (cgroup v2 cpu.max / v1 cfs) can be far below the visible CPU count
+        quota = None
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        if quota is not None:
+            cores = max(1, min(cores, int(quota + 0.5)))
+    except (OSError, ValueError):
+        pass
     sims = []
     for k in range(cores):
         o = OracleSim()

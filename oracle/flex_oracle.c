@@ -313,7 +313,8 @@ int orc_set_scene(orc_sim *s, const float *ptr, const float *verts, int n_vert_f
 
 static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
 
-static const int *g_sort_keys; /* qsort context: 3 ints per particle */
+static __thread const int *g_sort_keys; /* qsort context: 3 ints per particle (thread-local: independent simulations
+                                              may run on different threads, e.g. bench.py's CPU baseline) */
 static int cmp_cell(const void *a, const void *b) {
     const int *ka = g_sort_keys + 3 * (*(const int *)a), *kb = g_sort_keys + 3 * (*(const int *)b);
     for (int k = 0; k < 3; ++k)
