@@ -203,7 +203,6 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "fs_k_fused_step" if args.solver == 2 else "fs_k_iterate (+stage kernels)",
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_STEP * E},
-            "single_episode_steps_per_s": 1e3 / kern_ms,
             "mean_coverage": float(cov_all.mean().item()),
         }
         if world == 1 and not args.no_cpu_baseline:
