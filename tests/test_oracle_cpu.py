@@ -420,3 +420,27 @@ def test_action_selection_restatement_matches_reference_golden():
         assert (action or "") == want, ci
         if want:
             assert np.array_equal(res["p1"], g[f"c{ci}_p1"]) and np.array_equal(res["p2"], g[f"c{ci}_p2"]), ci
+
+
+def test_action_selector_host_evaluation_matches_reference_golden():
+    """The product's host-side re-evaluation of the winning candidate (flingbot_amd/action.py, the reference's numpy
+    expressions) returns the reference's own p1 / p2 for the golden winners; no GPU involved."""
+    from flingbot_amd.action import ActionSelector
+    from oracle import action as oa
+
+    g = np.load(os.path.join(GOLD, "action_golden.npz"))
+    for ci in range(3):
+        D, S, gd, dd, pd, _ = g[f"c{ci}_cfg"].tolist()
+        reach, sdist, gh = g[f"c{ci}_reach"].tolist()
+        prims = g[f"c{ci}_prims"].tolist()
+        rotations = g[f"c{ci}_rotations"].tolist()
+        cfg = dict(obs_dim=D, pix_grasp_dist=gd, pix_drag_dist=dd, pix_place_dist=pd, scales=g[f"c{ci}_scales"],
+                   rotations=rotations, depth=g[f"c{ci}_depth"], reach_distance_limit=reach, stretchdrag_dist=sdist,
+                   grasp_height=gh, left_arm_base=np.array([0.765, 0, 0]), right_arm_base=np.array([-0.765, 0, 0]))
+        action, _, k = oa.get_max_value_valid_action(g[f"c{ci}_values"], prims, cfg)
+        P, T = g[f"c{ci}_values"].shape[:2]
+        pidx, x, yy, zz = np.unravel_index(k, (P, T, D - 2 * gd, D - 2 * gd))
+        sel = ActionSelector(prims, rotations, D, gd, dd, pd, reach, stretchdrag_dist=sdist, grasp_height=gh)
+        res = sel._candidate(prims[pidx], int(x), int(yy) + gd, int(zz) + gd, g[f"c{ci}_scales"], g[f"c{ci}_depth"])
+        assert res is not None and prims[pidx] == str(g[f"c{ci}_action"])
+        assert np.array_equal(res["p1"], g[f"c{ci}_p1"]) and np.array_equal(res["p2"], g[f"c{ci}_p2"]), ci
