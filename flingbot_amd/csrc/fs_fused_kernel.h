@@ -1,17 +1,19 @@
 // fs_fused_kernel.h -- fused LDS-resident solver: ONE workgroup advances ONE cloth episode by whole frames.
 //
-// MI355X mapping: a 64x64 cloth is 4096 particles; its predicted positions (float4, 64 KiB), substep-start
-// positions (3 x 16 KiB) and the spatial-hash bins (24 KiB) all fit the 160 KiB LDS of one CU, so the 4 substeps x
-// 30 Jacobi iterations of a frame (reference softgym_cloth.h:154-155) run without touching HBM for particle state:
-// 1024 threads (16 waves, 4 per SIMD), 4 particles per thread held in registers across the frame, neighbour
-// positions gathered from LDS with ds_read_b128.  Grid = #episodes: 256 CUs advance 256 episodes concurrently.
+// MI355X mapping: a 64x64 cloth is 4096 particles; its current iterate (float4, 64 KiB), substep-start positions
+// (3 x 16 KiB) and the spatial-hash bins (24 KiB) all fit the 160 KiB LDS of one CU, so the 4 substeps x 30 Jacobi
+// iterations of a frame (reference softgym_cloth.h:154-155) run without touching HBM for particle positions:
+// 1024 threads (16 waves, 4 per SIMD), 4 particles per thread walked in a ROLLED loop, neighbour positions gathered from
+// LDS with ds_read_b128.  Grid = #episodes: 256 CUs advance 256 episodes concurrently.
 //
 // Two variants share all arithmetic (fs_constraints.h), so they and the CPU oracle agree bit for bit:
-//   * compact  -- the spring adjacency lives in REGISTERS: per particle 16 slots of {16-bit neighbour id, 8-bit code}
-//                 (12 VGPRs), the code indexing a <= 256-entry dictionary of distinct (rest length, stiffness) pairs
-//                 held in LDS.  A grid cloth has a few dozen distinct pairs.  No global memory traffic in the
-//                 iteration loop apart from the contact-candidate lists.
+//   * compact  -- dictionary-coded adjacency: per particle 12 or 16 slots of {16-bit LDS offset of the neighbour, 16-bit
+//                 LDS offset of a dictionary entry}, the dictionary (<= 256 distinct (rest length, stiffness) pairs; a
+//                 grid cloth has nine) in LDS; the 12 packed words of a particle are streamed from L2 one particle
+//                 ahead of their use (shared by every episode of the same cloth).
 //   * generic  -- adjacency streamed from an L2-resident ELL table (any degree, any number of distinct springs).
+// DESIGN.md 4.1 describes the stages (predict, hash, two-phase neighbour search, contact set, iterations) and what was
+// measured, tried and rejected.
 #pragma once
 #include "fs_constraints.h"
 
@@ -21,7 +23,7 @@
 #define FS_FUSED_PPT (4096 / FS_FUSED_THREADS)
 #define FS_FUSED_MAX_PARTICLES (FS_FUSED_THREADS * FS_FUSED_PPT)
 #define FS_FUSED_MAX_DEG 64
-#define FS_FUSED_BUCKETS 4096  // hashed cells (fs_cell_hash, 12 bits)
+#define FS_FUSED_BUCKETS 4096  // hashed cells (fs_fused_bucket: row hash + x)
 #define FS_FUSED_SLOTS 16      // compact adjacency slots per particle
 
 // LDS carve (bytes):
@@ -462,8 +464,9 @@ __device__ __forceinline__ void fs_fused_spring_block(FsAcc &a, const char *smem
 //
 // Register discipline (1024 threads => 128 VGPRs, and every attempt to keep per-particle state of the thread's four
 // particles in registers made hipcc interleave four inlined copies of the body and spill): the particle loop is a
-// ROLLED loop and nothing per-particle survives it in registers.  The current iterate is X (LDS), the new one goes to
-// XN (LDS) and is published after the barrier; the velocity lives in global memory (touched twice per substep); the
+// ROLLED loop and nothing per-particle survives it in registers except the four new positions, which rotate through a
+// statically indexed register file (r[q] <- r[q-1]) and are published to X after the barrier; the current iterate is X
+// (LDS); the velocity lives in global memory (touched twice per substep); the
 // packed adjacency (2 x SLOTS/2 dwords per particle, shared by all episodes of the same cloth, L2/L1 resident) and the
 // head of the contact-candidate list are fetched one particle ahead of their use.
 template <int SLOTS>
