@@ -4,6 +4,9 @@ Host-side mirror of the reference's manipulation code for MANY episodes at once 
 expressions (and therefore the same float32 / float64 roundings) per episode:
 
     SimEnv.pick_and_fling_primitive   environment/simEnv.py:283-318
+    SimEnv.pick_and_drag_primitive    environment/simEnv.py:320-345
+    SimEnv.pick_and_place_primitive   environment/simEnv.py:347-374
+    SimEnv.pick_stretch_drag_primitive  environment/simEnv.py:376-428
     SimEnv.stretch_cloth              environment/simEnv.py:140-184
     SimEnv.lift_cloth                 environment/simEnv.py:186-200
     SimEnv.fling_primitive            environment/simEnv.py:262-281
@@ -21,12 +24,14 @@ from .sim import FlingSim
 
 
 class FlingPrimitives:
-    def __init__(self, sim: FlingSim, envs, grasp_height=0.02, fling_speed=6e-3, fixed_fling_height=-1):
+    def __init__(self, sim: FlingSim, envs, grasp_height=0.02, fling_speed=6e-3, fixed_fling_height=-1,
+                 stretchdrag_dist=0.3):
         self.sim = sim
         self.envs = np.asarray(envs, np.int32).reshape(-1)
         self.grasp_height = grasp_height
         self.fling_speed = fling_speed
         self.fixed_fling_height = fixed_fling_height
+        self.stretchdrag_dist = stretchdrag_dist
         self.grasp_states = {int(e): [False, False] for e in self.envs}
         self.terminate = {int(e): False for e in self.envs}
         self.sim_steps = 0  # simulation steps issued by this object (all episodes)
@@ -189,4 +194,111 @@ class FlingPrimitives:
                 self.fling_primitive(keep, d, h, self.fling_speed)
                 for e, dd, hh in zip(keep, d, h):
                     out[e]["dist"], out[e]["fling_height"] = dd, hh
+        return [out[e] for e in envs]
+
+    # ---- simEnv.py:320-345 / :347-374: one-handed drag and pick-and-place; the second picker waits at (-0.2, 0.3, -0.2)
+    _PARK = [-0.2, 0.3, -0.2]
+
+    def _skip_unless(self, flags):
+        envs = [int(e) for e in self.envs]
+        out = {e: dict(skipped=not bool(flags[k])) for k, e in enumerate(envs)}
+        return envs, out, [e for k, e in enumerate(envs) if flags[k]]
+
+    def pick_and_drag(self, p1, p2, p1_grasp_cloth, p2_grasp_cloth=None):
+        """SimEnv.pick_and_drag_primitive (simEnv.py:320-345) for every episode: p1 start, p2 end of the drag."""
+        envs, out, act = self._skip_unless(p1_grasp_cloth)  # first grasp point not on cloth -> nothing happens
+        if act:
+            p1 = np.array(p1, np.float64).reshape(len(envs), 3)
+            p2 = np.array(p2, np.float64).reshape(len(envs), 3)
+            p1[:, 1] = self.grasp_height
+            p2[:, 1] = self.grasp_height
+            idx = {e: envs.index(e) for e in act}
+
+            def at(pos, h=None):
+                q = pos.copy()
+                if h is not None:
+                    q[1] = h
+                return [q, self._PARK]
+
+            self.movep(act, [at(p1[idx[e]], 0.3) for e in act], speed=5e-3)   # prestart
+            self.movep(act, [at(p1[idx[e]]) for e in act], speed=5e-3)
+            self.set_grasp(act, True)
+            self.movep(act, [at(p2[idx[e]]) for e in act], speed=5e-3)
+            self.set_grasp(act, False)
+            self.movep(act, [at(p2[idx[e]], 0.3) for e in act], speed=5e-3)   # postend
+            self.reset_end_effectors(act)
+        return [out[e] for e in envs]
+
+    def pick_and_place(self, p1, p2, p1_grasp_cloth, p2_grasp_cloth=None, lift_height=0.2):
+        """SimEnv.pick_and_place_primitive (simEnv.py:347-374) for every episode."""
+        envs, out, act = self._skip_unless(p1_grasp_cloth)
+        if act:
+            p1 = np.array(p1, np.float64).reshape(len(envs), 3)
+            p2 = np.array(p2, np.float64).reshape(len(envs), 3)
+            p1[:, 1] = self.grasp_height
+            p2[:, 1] = self.grasp_height
+            idx = {e: envs.index(e) for e in act}
+
+            def at(pos, h=None):
+                q = pos.copy()
+                if h is not None:
+                    q[1] = h
+                return [q, self._PARK]
+
+            self.movep(act, [at(p1[idx[e]], lift_height) for e in act], speed=5e-3)   # prepick
+            self.movep(act, [at(p1[idx[e]]) for e in act], speed=5e-3)
+            self.set_grasp(act, True)
+            self.movep(act, [at(p1[idx[e]], lift_height) for e in act], speed=5e-3)
+            self.movep(act, [at(p2[idx[e]], lift_height) for e in act], speed=5e-3)   # preplace
+            self.movep(act, [at(p2[idx[e]]) for e in act], speed=5e-3)
+            self.set_grasp(act, False)
+            self.movep(act, [at(p2[idx[e]], lift_height) for e in act], speed=5e-3)
+            self.reset_end_effectors(act)
+        return [out[e] for e in envs]
+
+    def pick_stretch_drag(self, p1, p2, p1_grasp_cloth, p2_grasp_cloth):
+        """SimEnv.pick_stretch_drag_primitive (simEnv.py:376-428) for every episode."""
+        envs, out, act = self._skip_unless([a or b for a, b in zip(p1_grasp_cloth, p2_grasp_cloth)])
+        for o in out.values():
+            o["dist"] = None
+        if act:
+            p1 = np.array(p1, np.float64).reshape(len(envs), 3)
+            p2 = np.array(p2, np.float64).reshape(len(envs), 3)
+            p1[:, 1] = self.grasp_height
+            p2[:, 1] = self.grasp_height
+            idx = {e: envs.index(e) for e in act}
+
+            def raised(pos, h):
+                q = pos.copy()
+                q[1] = h
+                return q
+
+            self.movep(act, [[raised(p1[idx[e]], 0.3), raised(p2[idx[e]], 0.3)] for e in act])
+            self.movep(act, [[p1[idx[e]], p2[idx[e]]] for e in act], speed=2e-3)
+            for e in act:  # only grasp points on cloth
+                self.grasp_states[e] = [bool(p1_grasp_cloth[idx[e]]), bool(p2_grasp_cloth[idx[e]])]
+            dist = {e: np.linalg.norm(np.array(p1[idx[e]]) - np.array(p2[idx[e]])) for e in act}
+            both = [e for e in act if all(self.grasp_states[e])]  # stretch if cloth is grasped by both
+            if both:
+                for e, d in zip(both, self.stretch_cloth(both, [dist[e] for e in both], fling_height=self.grasp_height)):
+                    dist[e] = d
+            targets_end, targets_post = [], []
+            for e in act:
+                drag_direction = np.cross(p1[idx[e]] - p2[idx[e]], np.array([0, 1, 0]))
+                drag_direction = self.stretchdrag_dist * drag_direction / np.linalg.norm(drag_direction)
+                left_start, right_start = self.picker_positions(e)  # float32 rows; + float64 direction -> float64
+                left_end = left_start + drag_direction
+                right_end = right_start + drag_direction
+                left_end[1] += 0.1  # prevent ee go under cloth
+                right_end[1] += 0.1
+                left_post, right_post = left_end.copy(), right_end.copy()
+                left_post[1] = 0.3
+                right_post[1] = 0.3
+                targets_end.append([left_end, right_end])
+                targets_post.append([left_post, right_post])
+                out[e]["dist"] = dist[e]
+            self.movep(act, targets_end, speed=2e-3)
+            self.set_grasp(act, False)
+            self.movep(act, targets_post)
+            self.reset_end_effectors(act)
         return [out[e] for e in envs]

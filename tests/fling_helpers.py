@@ -80,3 +80,28 @@ class OracleBatch:
             stable.append(ok)
             steps.append(done)
         return np.array(stable), np.array(steps, np.int32)
+
+
+def load_primitives_golden():
+    return np.load(os.path.join(GOLD, "primitives_golden.npz"))
+
+
+def run_primitives_golden(make_sim, get_positions, get_shapes):
+    """Runs the golden cases of the other manipulation primitives (drag / place / stretchdrag), batched per kind, on a
+    simulator made by make_sim(n) and checks final particle positions and picker states bit for bit."""
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_primitives_golden()
+    kinds = [str(k) for k in g["kind"]]
+    for kind in ("drag", "place", "stretchdrag"):
+        cases = [c for c, k in enumerate(kinds) if k == kind]
+        sim = make_sim(len(cases))
+        prim = FlingPrimitives(sim, range(len(cases)), stretchdrag_dist=float(g["stretchdrag_dist"]))
+        fn = {"drag": prim.pick_and_drag, "place": prim.pick_and_place, "stretchdrag": prim.pick_stretch_drag}[kind]
+        out = fn(g["p1"][cases], g["p2"][cases], g["g1"][cases], g["g2"][cases])
+        for k, c in enumerate(cases):
+            assert out[k]["skipped"] == (g["steps"][c] == 0), (kind, c)
+            if kind == "stretchdrag" and not np.isnan(g["stretch_ret"][c]):
+                assert out[k]["dist"] == g["stretch_ret"][c], (kind, c)
+            assert np.array_equal(get_positions(sim, k).view(np.uint32), g["pos"][c].view(np.uint32)), (kind, c)
+            assert np.array_equal(np.asarray(get_shapes(sim, k), np.float32).view(np.uint32), g["shapes"][c].view(np.uint32)), (kind, c)

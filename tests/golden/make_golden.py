@@ -348,6 +348,59 @@ def fling_vectors():
         rec["shapes_final"].append(orc.get_shape_states().copy())
         print("fling case", len(rec["stable"]), "terminate", env.terminate, "stretch", rets["stretch"], "lift", rets["lift"],
               "steps", rec["steps_fling"][-1], "stable", stable, "| drop: stable", stable2, "after", counter["steps"])
+    # ---- the other manipulation primitives (simEnv.py:320-428) on the same sheet
+    pcases = [("drag", [xs[3], 0.0, xs[4]], [xs[3] + 0.08, 0.0, xs[4] + 0.03], True, True),
+              ("place", [xs[-4], 0.0, xs[6]], [xs[8], 0.0, xs[-6]], True, False),
+              ("stretchdrag", [xs[1], 0.0, xs[2]], [xs[-2], 0.0, xs[2]], True, True),
+              ("stretchdrag", [xs[1], 0.0, xs[-3]], [xs[-2] + 0.06, 0.0, xs[-3]], True, False),
+              ("drag", [xs[3], 0.0, xs[4]], [xs[9], 0.0, xs[4]], False, True)]
+    prec = {"pos": [], "shapes": [], "steps": [], "stretch_ret": []}
+    for kind, p1, p2, g1, g2 in pcases:
+        orc = OracleSim()
+        orc_box["o"] = orc
+        orc.set_scene(sp)
+        orc.step(1)
+        orc.set_positions(init_pos.ravel())
+        orc.set_velocities(np.zeros(3 * init_pos.shape[0], np.float32))
+        env = SimEnv.__new__(SimEnv)
+        env.gui = False
+        env.gui_step = 0
+        env.dump_visualizations = False
+        env.default_speed = 1e-2
+        env.grasp_height = 0.02
+        env.stretchdrag_dist = 0.1
+        env.particle_radius = 0.00625
+        env.terminate = False
+        env.grasp_states = [False, False]
+        env.env_video_frames = {}
+        env.action_tool = ref_fu.PickerPickPlace(num_picker=2, particle_radius=0.00625, picker_radius=0.02,
+                                                 picker_low=(-5, 0, -5), picker_high=(5, 5, 5))
+        env.action_tool.reset([0.0, 0.1, 0.0])
+        rets = {"stretch": None}
+        o_stretch = SimEnv.stretch_cloth
+
+        def stretch2(self, *a, _o=o_stretch, **k):
+            rets["stretch"] = _o(self, *a, **k)
+            return rets["stretch"]
+        SimEnv.stretch_cloth = stretch2
+        counter["steps"] = 0
+        try:
+            fn = {"drag": env.pick_and_drag_primitive, "place": env.pick_and_place_primitive,
+                  "stretchdrag": env.pick_stretch_drag_primitive}[kind]
+            fn(np.array(p1, np.float64), np.array(p2, np.float64), g1, g2)
+        finally:
+            SimEnv.stretch_cloth = o_stretch
+        prec["pos"].append(orc.get_positions().copy())
+        prec["shapes"].append(orc.get_shape_states().copy())
+        prec["steps"].append(counter["steps"])
+        prec["stretch_ret"].append(np.nan if rets["stretch"] is None else float(rets["stretch"]))
+        print("primitive", kind, g1, g2, "steps", counter["steps"], "stretch", rets["stretch"])
+    np.savez_compressed(os.path.join(HERE, "primitives_golden.npz"), scene_params=sp, init_pos=init_pos,
+                        kind=np.array([c[0] for c in pcases]), p1=np.array([c[1] for c in pcases]),
+                        p2=np.array([c[2] for c in pcases]), g1=np.array([c[3] for c in pcases]),
+                        g2=np.array([c[4] for c in pcases]), steps=np.array(prec["steps"]),
+                        stretch_ret=np.array(prec["stretch_ret"]), pos=np.array(prec["pos"]),
+                        shapes=np.array(prec["shapes"]), stretchdrag_dist=np.array(0.1))
     np.savez_compressed(os.path.join(HERE, "fling_golden.npz"), scene_params=sp, init_pos=init_pos,
                         p1=np.array([c[0] for c in cases]), p2=np.array([c[1] for c in cases]),
                         g1=np.array([c[2] for c in cases]), g2=np.array([c[3] for c in cases]),

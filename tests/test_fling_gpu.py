@@ -90,3 +90,12 @@ def test_wait_until_stable_budget_and_reductions_match_oracle(gpu_required):
     assert np.array_equal(n_gpu.view(np.uint32), n_cpu.view(np.uint32))
     for e in range(2):
         assert np.array_equal(ctx.get_positions(e).view(np.uint32), orc.get_positions(e).view(np.uint32))
+
+
+def test_batched_drag_place_stretchdrag_match_reference_golden(gpu_required):
+    """The other manipulation primitives of SimEnv (simEnv.py:320-428) through the device-side movep, against
+    tests/golden/primitives_golden.npz."""
+    from fling_helpers import load_primitives_golden, run_primitives_golden
+
+    g = load_primitives_golden()
+    run_primitives_golden(lambda n: _make(g, n), lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))

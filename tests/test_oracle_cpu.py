@@ -444,3 +444,14 @@ def test_action_selector_host_evaluation_matches_reference_golden():
         res = sel._candidate(prims[pidx], int(x), int(yy) + gd, int(zz) + gd, g[f"c{ci}_scales"], g[f"c{ci}_depth"])
         assert res is not None and prims[pidx] == str(g[f"c{ci}_action"])
         assert np.array_equal(res["p1"], g[f"c{ci}_p1"]) and np.array_equal(res["p2"], g[f"c{ci}_p2"]), ci
+
+
+def test_drag_place_stretchdrag_host_logic_reproduces_reference_golden():
+    """primitives.pick_and_drag / pick_and_place / pick_stretch_drag on the CPU oracle retrace what the REFERENCE's
+    SimEnv.pick_and_drag_primitive / pick_and_place_primitive / pick_stretch_drag_primitive did
+    (tests/golden/primitives_golden.npz), bit for bit."""
+    from fling_helpers import OracleBatch, load_primitives_golden, run_primitives_golden
+
+    g = load_primitives_golden()
+    run_primitives_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"]),
+                          lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
