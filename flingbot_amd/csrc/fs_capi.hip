@@ -34,6 +34,7 @@ fs_ctx::~fs_ctx() {
         if (e.slab) (void)hipFree(e.slab);
         if (e.d_picked) (void)hipFree(e.d_picked);
         if (e.d_saved_w) (void)hipFree(e.d_saved_w);
+        if (e.d_snapshot) (void)hipFree(e.d_snapshot);
     }
     envs.clear();
     topo_cache.clear();

@@ -51,6 +51,8 @@ struct FsEnv {
     // on-device picker state (fs_picker.hip): picked particle per shape (-1 none), inverse masses saved at reset
     int *d_picked = nullptr;   // [FS_MAX_SHAPES]
     float *d_saved_w = nullptr;  // [n]
+    FsVec4 *d_snapshot = nullptr;  // [snapshot_n] positions kept by fs_snapshot_positions (SimEnv.preaction)
+    int snapshot_n = 0;
     double picker_threshold = 0.005, particle_radius = 0.00625;
     bool picker_ready = false;
     FsCamera cam;

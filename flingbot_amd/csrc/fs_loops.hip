@@ -227,3 +227,66 @@ extern "C" int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float
     (void)hipFree(d_buf);
     return fs_hip_ok(herr, "fs_stretch_probe") ? FS_OK : FS_ERR_HIP;
 }
+
+// ---- SimEnv.preaction / postaction (environment/simEnv.py:464-475): "did the action move the cloth at all?"
+// preaction keeps the positions; postaction takes max_i || |post_i - pre_i| ||_2 (float32, like the numpy expression
+// np.linalg.norm(np.abs(post - pre), axis=1).max()) and ends the episode when it is below 5e-2.
+__global__ __launch_bounds__(256) void fs_k_max_displacement(const FsEnvDev *envs, const int *ids, const FsVec4 *const *snap,
+                                                             float *out) {
+    __shared__ float red[256];
+    const FsEnvDev &E = envs[ids[blockIdx.x]];
+    const FsVec4 *pre = snap[blockIdx.x];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < E.n; i += blockDim.x) {
+        const FsVec4 a = E.pos[i], b = pre[i];
+        const float dx = fabsf(a.x - b.x), dy = fabsf(a.y - b.y), dz = fabsf(a.z - b.z);
+        m = fmaxf(m, sqrtf(dx * dx + dy * dy + dz * dz));
+    }
+    m = fs_block_max(m, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
+extern "C" int fs_snapshot_positions(fs_ctx *ctx, int n, const int *envs) {
+    if (!ctx || !envs || n <= 0) { fs_set_error("fs_snapshot_positions: bad arguments"); return FS_ERR_ARG; }
+    for (int k = 0; k < n; ++k) {
+        if (envs[k] < 0 || envs[k] >= ctx->n_envs || !ctx->envs[envs[k]].has_scene) {
+            fs_set_error("fs_snapshot_positions: bad episode id / no scene");
+            return FS_ERR_ARG;
+        }
+        FsEnv &e = ctx->envs[envs[k]];
+        const size_t bytes = sizeof(FsVec4) * (size_t)e.host.n;
+        if (e.d_snapshot && e.snapshot_n != e.host.n) { (void)hipFree(e.d_snapshot); e.d_snapshot = nullptr; }
+        if (!e.d_snapshot) {
+            HIP_TRY(hipMalloc((void **)&e.d_snapshot, bytes));
+            e.snapshot_n = e.host.n;
+        }
+        HIP_TRY(hipMemcpyAsync(e.d_snapshot, e.dev.pos, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return FS_OK;
+}
+
+extern "C" int fs_max_displacement(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats) {
+    if (!out || n_floats < n) { fs_set_error("fs_max_displacement: output too small"); return FS_ERR_ARG; }
+    int *d_ids = nullptr;
+    int rc = upload_list(ctx, n, envs, &d_ids);
+    if (rc != FS_OK) return rc;
+    std::vector<const FsVec4 *> h_snap(n);
+    for (int k = 0; k < n; ++k) {
+        const FsEnv &e = ctx->envs[envs[k]];
+        if (!e.d_snapshot || e.snapshot_n != e.host.n) { fs_set_error("fs_max_displacement: call fs_snapshot_positions first"); return FS_ERR_STATE; }
+        h_snap[k] = e.d_snapshot;
+    }
+    char *d_buf = nullptr;  // pointers[n] | out[n]
+    HIP_TRY(hipMalloc((void **)&d_buf, (sizeof(void *) + sizeof(float)) * n));
+    const FsVec4 **d_snap = (const FsVec4 **)d_buf;
+    float *d_out = (float *)(d_buf + sizeof(void *) * n);
+    hipError_t herr = hipMemcpyAsync(d_snap, h_snap.data(), sizeof(void *) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);  // pageable source
+    if (herr == hipSuccess) {
+        hipLaunchKernelGGL(fs_k_max_displacement, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->d_envs, d_ids, d_snap, d_out);
+        herr = hipMemcpyAsync(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_buf);
+    return fs_hip_ok(herr, "fs_max_displacement") ? FS_OK : FS_ERR_HIP;
+}

@@ -152,6 +152,24 @@ class FlingPrimitives:
         envs = [int(e) for e in envs]
         self.movep(envs, [[[0.5, 0.5, -0.5], [-0.5, 0.5, -0.5]]] * len(envs), speed=5e-3)
 
+    # ---- simEnv.py:464-475: SimEnv.preaction / postaction around an action
+    def preaction(self, envs=None):
+        envs = [int(e) for e in (self.envs if envs is None else envs)]
+        self.sim.snapshot_positions(envs)
+
+    def postaction(self, envs=None, max_steps=300, tolerance=1e-2):
+        """reset_end_effectors, wait_until_stable, and the "didn't really move cloth -> end early" test.  Returns the
+        per-episode terminate flags (also kept in self.terminate)."""
+        envs = [int(e) for e in (self.envs if envs is None else envs)]
+        self.reset_end_effectors(envs)
+        _, steps = self.sim.wait_until_stable(envs, max_steps=max_steps, tolerance=tolerance)
+        self.sim_steps += int(np.sum(steps))
+        deltas_max = self.sim.max_displacement(envs)
+        for e, d in zip(envs, deltas_max):
+            if d < 5e-2:  # if didn't really move cloth then end early
+                self.terminate[e] = True
+        return [self.terminate[e] for e in envs]
+
     # ---- simEnv.py:283-318
     def pick_and_fling(self, p1, p2, p1_grasp_cloth, p2_grasp_cloth):
         """p1, p2: [n,3] grasp positions per episode (y is overwritten by grasp_height), *_grasp_cloth: bool[n].

@@ -85,6 +85,8 @@ def load_library(build_if_missing=True):
         "fs_wait_until_stable": (ci, [vp, ci, ip, ci, C.c_double, ip, ip]),
         "fs_cloth_stats": (ci, [vp, ci, ip, fp, ci]),
         "fs_stretch_probe": (ci, [vp, ci, ip, fp, fp, ip, fp]),
+        "fs_snapshot_positions": (ci, [vp, ci, ip]),
+        "fs_max_displacement": (ci, [vp, ci, ip, fp, ci]),
         "fs_prepare_image_work_bytes": (C.c_size_t, [ci, ci, ci]),
         "fs_prepare_image": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), ci,
                                   vp, vp, vp]),
@@ -240,6 +242,18 @@ class FlingSim:
         single, near = np.zeros(ids.size, np.int32), np.empty((ids.size, 3), np.float32)
         self._ck(self.lib.fs_stretch_probe(self.h, ids.size, _ip(ids), _fp(mid), _fp(thr), _ip(single), _fp(near)))
         return single.astype(bool), near
+
+    def snapshot_positions(self, envs):
+        """SimEnv.preaction (simEnv.py:464-465): keep the current positions on the device."""
+        ids = _i([envs] if np.isscalar(envs) else envs)
+        self._ck(self.lib.fs_snapshot_positions(self.h, ids.size, _ip(ids)))
+
+    def max_displacement(self, envs):
+        """float32[n]: largest particle displacement since snapshot_positions (simEnv.py:470-472)."""
+        ids = _i([envs] if np.isscalar(envs) else envs)
+        out = np.empty(ids.size, np.float32)
+        self._ck(self.lib.fs_max_displacement(self.h, ids.size, _ip(ids), _fp(out), out.size))
+        return out
 
     def timer_start(self):
         self._ck(self.lib.fs_timer_start(self.h))

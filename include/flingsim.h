@@ -161,6 +161,11 @@ int fs_cloth_stats(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats
                            sqrt(dx*dx + dz*dz), is smallest (lowest index on ties = Python's stable sort). */
 int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float *midpoint_xz, const float *height_thr,
                      int *single_grasp_out, float *nearest_out);
+/* SimEnv.preaction / postaction (simEnv.py:464-475): keep the current positions of the listed episodes on the device,
+   and later report out[k] = max_i || |pos_i - kept_i| ||_2 in float32 -- np.linalg.norm(np.abs(post - pre), axis=1).max() --
+   which the reference compares with 5e-2 to end an episode whose action did not move the cloth. */
+int fs_snapshot_positions(fs_ctx *ctx, int n, const int *envs);
+int fs_max_displacement(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats);
 
 /* ---- observation transforms on the device ---------------------------------------------------
    learning/nets.py:155-193 prepare_image: n_transforms rotated / scaled / resized copies of one observation.

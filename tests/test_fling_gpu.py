@@ -90,6 +90,15 @@ def test_wait_until_stable_budget_and_reductions_match_oracle(gpu_required):
     assert np.array_equal(n_gpu.view(np.uint32), n_cpu.view(np.uint32))
     for e in range(2):
         assert np.array_equal(ctx.get_positions(e).view(np.uint32), orc.get_positions(e).view(np.uint32))
+    # SimEnv.preaction / postaction's displacement test (simEnv.py:464-475), float32 like the numpy expression
+    ctx.snapshot_positions([0, 1])
+    pre = [ctx.get_positions(e).reshape(-1, 4)[:, :3].copy() for e in range(2)]
+    ctx.step(9)
+    got = ctx.max_displacement([0, 1])
+    for e in range(2):
+        post = ctx.get_positions(e).reshape(-1, 4)[:, :3]
+        want = np.linalg.norm(np.abs(post - pre[e]), axis=1).max()
+        assert want.dtype == np.float32 and got[e] == want and want > 0, (e, got[e], want)
 
 
 def test_batched_drag_place_stretchdrag_match_reference_golden(gpu_required):
