@@ -38,6 +38,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     }
     const dim3 grid((max_n + FS_TILE - 1) / FS_TILE, (unsigned)ids.size());
     const dim3 block(FS_TILE);
+    // launches that cannot fill the chip are latency-bound: take the form of fs_k_iterate that requests everything up front
+    const bool eager = (size_t)max_n * ids.size() <= (size_t)32 * 4096;
     hipStream_t st = ctx->stream;
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
@@ -45,8 +47,10 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, ctx->d_envs, d_ids);
             hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, d_ids);
             hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, d_ids);
-            for (int it = 0; it < iters; ++it)
-                hipLaunchKernelGGL(fs_k_iterate, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1);
+            for (int it = 0; it < iters; ++it) {
+                if (eager) hipLaunchKernelGGL(fs_k_iterate_eager, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1);
+                else hipLaunchKernelGGL(fs_k_iterate, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1);
+            }
             hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1);
         }
     }

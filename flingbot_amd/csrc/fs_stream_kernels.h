@@ -193,60 +193,114 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
 }
 
 // ---- one Jacobi iteration: solveSprings + solveContacts + applyDeltas for particle i
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
-                                                        int sub, int flip) {
-    const int e = ids[blockIdx.y];
-    if (e < 0) return;  // retired slot
-    const FsEnvDev &E = envs[e];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
-    if (i >= E.n) return;
+template <int CHUNK, bool EAGER>
+__device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip) {
     const FsParams &p = E.p;
     const FsVec4 *__restrict__ src = flip ? E.xb : E.xa;
     FsVec4 *__restrict__ dst = flip ? E.xa : E.xb;
+    // EAGER (small launches, latency-bound: a lone episode's step is ~140 dependent kernels of a few round trips each):
+    // everything whose address does not depend on loaded data is requested before the first use -- own position, substep-start
+    // position, candidate count, the first four candidate ids -- so the kernel is three dependent round trips long
+    // (addresses -> ids -> neighbour positions) instead of seven.
     FsVec4 xi = src[i];
+    FsVec4 x0i;
+    int nc = 0, cj0[4] = {-1, -1, -1, -1};
+    if (EAGER) {
+        x0i = E.x0[i];
+        nc = E.ncount[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cj0[k] = E.nlist[(size_t)k * E.n + i];  // slots beyond the count hold stale ids: masked below
+    }
     if (!(xi.w > 0.0f)) {
         dst[i] = xi;
         return;
     }
     FsAcc a = {0.0f, 0.0f, 0.0f, 0};
     // slot-major (ELL) adjacency: the wave's loads of slot s are contiguous (the CSR rows of neighbouring particles are 12
-    // entries apart, i.e. one cache line per lane); slots ascend with the spring id, like the CSR rows.  FS_STREAM_CHUNK slots per
-    // trip: their index / length / stiffness loads and then their four position gathers are in flight together.
+    // entries apart, i.e. one cache line per lane); slots ascend with the spring id, like the CSR rows.  CHUNK slots per
+    // trip: their index / length / stiffness loads and then their position gathers are in flight together.
     const unsigned un = (unsigned)E.n;
     const int max_deg = E.max_deg;
-    for (int s0 = 0; s0 < max_deg; s0 += FS_STREAM_CHUNK) {
-        int jj[FS_STREAM_CHUNK];
-        float ll[FS_STREAM_CHUNK], kk[FS_STREAM_CHUNK];
+    FsVec4 cx0[4], c00[4];
+    for (int s0 = 0; s0 < max_deg; s0 += CHUNK) {
+        int jj[CHUNK];
+        float ll[CHUNK], kk[CHUNK];
 #pragma unroll
-        for (int q = 0; q < FS_STREAM_CHUNK; ++q) {
+        for (int q = 0; q < CHUNK; ++q) {
             const bool in = s0 + q < max_deg;
             const unsigned at = (unsigned)(s0 + q) * un + (unsigned)i;
             jj[q] = in ? E.ell_j[at] : -1;
             ll[q] = in ? E.ell_len[at] : 0.0f;
             kk[q] = in ? E.ell_k[at] : 0.0f;
         }
-        FsVec4 xj[FS_STREAM_CHUNK];
+        FsVec4 xj[CHUNK];
 #pragma unroll
-        for (int q = 0; q < FS_STREAM_CHUNK; ++q) xj[q] = src[jj[q] < 0 ? i : jj[q]];
+        for (int q = 0; q < CHUNK; ++q) xj[q] = src[jj[q] < 0 ? i : jj[q]];
+        if (EAGER && s0 == 0) {  // the first candidates' positions travel with the first springs' gathers
 #pragma unroll
-        for (int q = 0; q < FS_STREAM_CHUNK; ++q)
+            for (int k = 0; k < 4; ++k) {
+                const int j = (k < nc && cj0[k] >= 0 && cj0[k] < E.n) ? cj0[k] : i;
+                cx0[k] = src[j];
+                c00[k] = E.x0[j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CHUNK; ++q)
             fs_spring_bf(a, xi.x, xi.y, xi.z, xi.w, xj[q], ll[q], kk[q]);  // a padded slot gathers the particle itself: length 0, inactive
-        if (jj[FS_STREAM_CHUNK - 1] < 0) break;  // the padding (-1) is at the tail of every row
+        if (jj[CHUNK - 1] < 0) break;  // the padding (-1) is at the tail of every row
     }
-    const FsVec4 x0i = E.x0[i];
+    if (!EAGER) {
+        x0i = E.x0[i];
+        nc = E.ncount[i];
+    }
     const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
-    const int nc = E.ncount[i];
     const float restd = p.solidRestDistance, restd2 = restd * restd;
-    for (int q = 0; q < nc; ++q) {
-        const int j = E.nlist[(size_t)q * E.n + i];
-        const FsVec4 xj = src[j];
-        const FsVec4 x0j = E.x0[j];
-        fs_particle_contact(a, xi.x, xi.y, xi.z, xi.w, ri0, ri1, ri2, xj, xj.x - x0j.x, xj.y - x0j.y, xj.z - x0j.z, restd,
-                            restd2, p.particleFriction);
+    // four candidates per trip: their ids, then their positions and substep-start positions, are in flight together;
+    // evaluation order is unchanged
+    for (int q0 = 0; q0 < nc; q0 += 4) {
+        int cj[4];
+        FsVec4 cx[4], c0[4];
+        if (EAGER && q0 == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cj[k] = k < nc ? cj0[k] : -1; cx[k] = cx0[k]; c0[k] = c00[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cj[k] = q0 + k < nc ? E.nlist[(size_t)(q0 + k) * E.n + i] : -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = cj[k] < 0 ? i : cj[k];
+                cx[k] = src[j];
+                c0[k] = E.x0[j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cj[k] >= 0)
+                fs_particle_contact(a, xi.x, xi.y, xi.z, xi.w, ri0, ri1, ri2, cx[k], cx[k].x - c0[k].x, cx[k].y - c0[k].y,
+                                    cx[k].z - c0[k].z, restd, restd2, p.particleFriction);
     }
-    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shapes[e], sub);
+    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     dst[i] = xi;
+}
+
+// throughput form (big launches): six springs in flight, later loads issued when needed (fewer live registers)
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+                                                        int sub, int flip) {
+    const int e = ids[blockIdx.y];
+    if (e < 0) return;  // retired slot
+    const FsEnvDev &E = envs[e];
+    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+    if (i < E.n) fs_iterate_particle<FS_STREAM_CHUNK, false>(E, shapes[e], i, sub, flip);
+}
+// latency form (small launches)
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+                                                              int sub, int flip) {
+    const int e = ids[blockIdx.y];
+    if (e < 0) return;  // retired slot
+    const FsEnvDev &E = envs[e];
+    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+    if (i < E.n) fs_iterate_particle<12, true>(E, shapes[e], i, sub, flip);
 }
 
 // ---- finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping (:110)
