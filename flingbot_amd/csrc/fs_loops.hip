@@ -17,13 +17,16 @@
         if (!fs_hip_ok((call), #call)) return FS_ERR_HIP; \
     } while (0)
 
-// max over particles of max(|vx|, |vy|, |vz|); block-wide, result valid in thread 0
+// numpy's max / min propagate NaN (a NaN velocity never compares below the tolerance: wait_until_stable keeps stepping)
+__device__ __forceinline__ float fs_nanmax(float a, float b) { return (a != a || b != b) ? __int_as_float(0x7fc00000) : fmaxf(a, b); }
+
+// block-wide maximum, result valid in thread 0
 __device__ __forceinline__ float fs_block_max(float v, float *red) {
     const int t = threadIdx.x;
     red[t] = v;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+        if (t < s) red[t] = fs_nanmax(red[t], red[t + s]);
         __syncthreads();
     }
     return red[0];
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(256) void fs_k_stable_check(const FsEnvDev *envs, i
     float m = 0.0f;
     for (int i = threadIdx.x; i < E.n; i += blockDim.x) {
         const FsVec4 v = E.vel[i];
-        m = fmaxf(m, fmaxf(fabsf(v.x), fmaxf(fabsf(v.y), fabsf(v.z))));
+        m = fs_nanmax(m, fs_nanmax(fabsf(v.x), fs_nanmax(fabsf(v.y), fabsf(v.z))));
     }
     m = fs_block_max(m, red);
     if (threadIdx.x == 0) {
@@ -109,10 +112,10 @@ __global__ __launch_bounds__(256) void fs_k_cloth_stats(const FsEnvDev *envs, co
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f, vm = 0.0f;
     for (int i = threadIdx.x; i < E.n; i += blockDim.x) {
         const float y = E.pos[i].y;
-        lo = fminf(lo, y);
-        hi = fmaxf(hi, y);
+        lo = -fs_nanmax(-lo, -y);
+        hi = fs_nanmax(hi, y);
         const FsVec4 v = E.vel[i];
-        vm = fmaxf(vm, fmaxf(fabsf(v.x), fmaxf(fabsf(v.y), fabsf(v.z))));
+        vm = fs_nanmax(vm, fs_nanmax(fabsf(v.x), fs_nanmax(fabsf(v.y), fabsf(v.z))));
     }
     const float nlo = fs_block_max(-lo, red);
     __syncthreads();
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void fs_k_max_displacement(const FsEnvDev *env
     for (int i = threadIdx.x; i < E.n; i += blockDim.x) {
         const FsVec4 a = E.pos[i], b = pre[i];
         const float dx = fabsf(a.x - b.x), dy = fabsf(a.y - b.y), dz = fabsf(a.z - b.z);
-        m = fmaxf(m, sqrtf(dx * dx + dy * dy + dz * dz));
+        m = fs_nanmax(m, sqrtf(dx * dx + dy * dy + dz * dz));
     }
     m = fs_block_max(m, red);
     if (threadIdx.x == 0) out[blockIdx.x] = m;

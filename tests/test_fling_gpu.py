@@ -108,3 +108,16 @@ def test_batched_drag_place_stretchdrag_match_reference_golden(gpu_required):
 
     g = load_primitives_golden()
     run_primitives_golden(lambda n: _make(g, n), lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
+
+
+def test_reductions_propagate_nan_like_numpy(gpu_required):
+    """np.abs(v).max() with a NaN velocity is NaN and never below the tolerance: wait_until_stable keeps stepping until the
+    budget runs out; cloth_stats reports NaN like numpy's min / max."""
+    g = load_fling_golden()
+    ctx = _make(g, 1)
+    v = np.zeros((g["init_pos"].shape[0], 3), np.float32)
+    v[7, 1] = np.nan
+    ctx.set_velocities(0, v.ravel())
+    assert np.isnan(ctx.cloth_stats([0])[0, 2])
+    stable, steps = ctx.wait_until_stable(0, max_steps=3, tolerance=1e-2)
+    assert (stable, steps) == (False, 3)
