@@ -276,15 +276,22 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
         std::vector<int *> h_picked(ctx->n_envs, nullptr);
         std::vector<float *> h_saved(ctx->n_envs, nullptr);
         for (int i = 0; i < ctx->n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
-        int *d_ids = nullptr;
-        FsPickerCmd *d_cmds = nullptr;
-        int **d_picked = nullptr;
-        float **d_saved = nullptr;
+        struct DevBufs {  // freed on every exit path
+            int *ids = nullptr;
+            FsPickerCmd *cmds = nullptr;
+            int **picked = nullptr;
+            float **saved = nullptr;
+            ~DevBufs() { (void)hipFree(ids); (void)hipFree(cmds); (void)hipFree(picked); (void)hipFree(saved); }
+        } bufs;
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        HIP_TRY(hipMalloc((void **)&d_ids, sizeof(int) * h_ids.size()));
-        HIP_TRY(hipMalloc((void **)&d_cmds, sizeof(FsPickerCmd) * h_cmds.size()));
-        HIP_TRY(hipMalloc((void **)&d_picked, sizeof(int *) * ctx->n_envs));
-        HIP_TRY(hipMalloc((void **)&d_saved, sizeof(float *) * ctx->n_envs));
+        HIP_TRY(hipMalloc((void **)&bufs.ids, sizeof(int) * h_ids.size()));
+        HIP_TRY(hipMalloc((void **)&bufs.cmds, sizeof(FsPickerCmd) * h_cmds.size()));
+        HIP_TRY(hipMalloc((void **)&bufs.picked, sizeof(int *) * ctx->n_envs));
+        HIP_TRY(hipMalloc((void **)&bufs.saved, sizeof(float *) * ctx->n_envs));
+        int *d_ids = bufs.ids;
+        FsPickerCmd *d_cmds = bufs.cmds;
+        int **d_picked = bufs.picked;
+        float **d_saved = bufs.saved;
         HIP_TRY(hipMemcpy(d_ids, h_ids.data(), sizeof(int) * h_ids.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_cmds, h_cmds.data(), sizeof(FsPickerCmd) * h_cmds.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_picked, h_picked.data(), sizeof(int *) * ctx->n_envs, hipMemcpyHostToDevice));
@@ -300,7 +307,6 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
             rc = fs_step_ids(ctx, ids, 1, d_ids + s * n);
         }
         hipError_t err = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_ids); (void)hipFree(d_cmds); (void)hipFree(d_picked); (void)hipFree(d_saved);
         if (rc != FS_OK) return rc;
         HIP_TRY(err);
         // host mirrors of the shape states follow the planned trajectory
