@@ -311,6 +311,17 @@ extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
     return fs_step_ids(ctx, ids, n_steps, nullptr);
 }
 
+extern "C" int fs_step_list(fs_ctx *ctx, int n, const int *envs, int n_steps) {
+    if (!ctx || !envs || n <= 0) { fs_set_error("fs_step_list: bad arguments"); return FS_ERR_ARG; }
+    if (n_steps < 0) { fs_set_error("n_steps < 0"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int> ids(envs, envs + n);
+    for (int id : ids)
+        if (!get_env(ctx, id)) return FS_ERR_ARG;
+    if (n_steps == 0) return FS_OK;
+    return fs_step_ids(ctx, ids, n_steps, nullptr);
+}
+
 int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids) {
     int solver = ctx->solver;
     if (solver == FS_SOLVER_AUTO) {

@@ -293,3 +293,42 @@ extern "C" int fs_max_displacement(fs_ctx *ctx, int n, const int *envs, float *o
     (void)hipFree(d_buf);
     return fs_hip_ok(herr, "fs_max_displacement") ? FS_OK : FS_ERR_HIP;
 }
+
+// ---- one particle per episode set from the host without moving whole arrays: the task generator's pinned pick point
+// (environment/tasks.py:177-224 rewrites all positions and velocities through pyflex every step to move ONE particle).
+__global__ void fs_k_set_particles(const FsEnvDev *envs, const int *ids, const int *pids, const float *pos4, int zero_vel, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const FsEnvDev &E = envs[ids[k]];
+    const int pid = pids[k];
+    if (pid < 0 || pid >= E.n) return;
+    E.pos[pid] = FsVec4{pos4[4 * k], pos4[4 * k + 1], pos4[4 * k + 2], pos4[4 * k + 3]};
+    if (zero_vel) E.vel[pid] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+extern "C" int fs_set_particles(fs_ctx *ctx, int n, const int *envs, const int *particle_ids, const float *pos4,
+                                int zero_velocity) {
+    if (!particle_ids || !pos4) { fs_set_error("fs_set_particles: null argument"); return FS_ERR_ARG; }
+    int *d_ids = nullptr;
+    int rc = upload_list(ctx, n, envs, &d_ids);
+    if (rc != FS_OK) return rc;
+    for (int k = 0; k < n; ++k)
+        if (particle_ids[k] < 0 || particle_ids[k] >= ctx->envs[envs[k]].host.n) {
+            fs_set_error("fs_set_particles: particle id out of range");
+            return FS_ERR_ARG;
+        }
+    char *d_buf = nullptr;  // pids[n] | pos4[4n]
+    HIP_TRY(hipMalloc((void **)&d_buf, (sizeof(int) + 4 * sizeof(float)) * n));
+    int *d_pids = (int *)d_buf;
+    float *d_pos = (float *)(d_buf + sizeof(int) * n);
+    hipError_t herr = hipMemcpyAsync(d_pids, particle_ids, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipMemcpyAsync(d_pos, pos4, sizeof(float) * 4 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);  // pageable sources
+    if (herr == hipSuccess) {
+        hipLaunchKernelGGL(fs_k_set_particles, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_envs, d_ids, d_pids, d_pos,
+                           zero_velocity, n);
+        herr = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(d_buf);
+    return fs_hip_ok(herr, "fs_set_particles") ? FS_OK : FS_ERR_HIP;
+}

@@ -47,6 +47,7 @@ def load_library(build_if_missing=True):
         "fs_get_solver": (ci, [vp]),
         "fs_set_scene": (ci, [vp, ci, fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
         "fs_step": (ci, [vp, ci, ci]),
+        "fs_step_list": (ci, [vp, ci, ip, ci]),
         "fs_sync": (ci, [vp]),
         "fs_stream": (vp, [vp]),
         "fs_n_particles": (ci, [vp, ci]),
@@ -87,6 +88,7 @@ def load_library(build_if_missing=True):
         "fs_stretch_probe": (ci, [vp, ci, ip, fp, fp, ip, fp]),
         "fs_snapshot_positions": (ci, [vp, ci, ip]),
         "fs_max_displacement": (ci, [vp, ci, ip, fp, ci]),
+        "fs_set_particles": (ci, [vp, ci, ip, ip, fp, ci]),
         "fs_prepare_image_work_bytes": (C.c_size_t, [ci, ci, ci]),
         "fs_prepare_image": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), ci,
                                   vp, vp, vp]),
@@ -166,6 +168,12 @@ class FlingSim:
     # ---- batched
     def step(self, n_steps=1, env=-1):
         self._ck(self.lib.fs_step(self.h, int(env), int(n_steps)))
+
+    def step_list(self, envs, n_steps=1):
+        """Advance exactly the listed episodes (one batched launch sequence)."""
+        ids = _i(envs)
+        if ids.size:
+            self._ck(self.lib.fs_step_list(self.h, ids.size, _ip(ids), int(n_steps)))
 
     def sync(self):
         self._ck(self.lib.fs_sync(self.h))
@@ -254,6 +262,13 @@ class FlingSim:
         out = np.empty(ids.size, np.float32)
         self._ck(self.lib.fs_max_displacement(self.h, ids.size, _ip(ids), _fp(out), out.size))
         return out
+
+    def set_particles(self, envs, particle_ids, pos4, zero_velocity=True):
+        """One particle per episode: position + inverse mass (float32 [n,4]), velocity optionally zeroed."""
+        ids = _i([envs] if np.isscalar(envs) else envs)
+        pids = _i(np.asarray(particle_ids).reshape(-1))
+        p4 = np.ascontiguousarray(np.asarray(pos4, np.float32).reshape(ids.size, 4))
+        self._ck(self.lib.fs_set_particles(self.h, ids.size, _ip(ids), _ip(pids), _fp(p4), 1 if zero_velocity else 0))
 
     def timer_start(self):
         self._ck(self.lib.fs_timer_start(self.h))

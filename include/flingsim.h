@@ -58,6 +58,8 @@ int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int n_params, 
    Advances env (or every env with a scene when env == -1) by n_steps frames.  Asynchronous on the context's HIP
    stream; every getter synchronises. */
 int fs_step(fs_ctx *ctx, int env, int n_steps);
+/* the same for a list of episodes (each listed once): one batched launch sequence for exactly those */
+int fs_step_list(fs_ctx *ctx, int n, const int *envs, int n_steps);
 int fs_sync(fs_ctx *ctx);
 /* fs_step bracketed by HIP events recorded on the context's stream; returns the elapsed device time of the launch(es)
    in milliseconds.  Used by bench.py for the per-launch kernel duration (roofline). */
@@ -166,6 +168,10 @@ int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float *midpoint_
    which the reference compares with 5e-2 to end an episode whose action did not move the cloth. */
 int fs_snapshot_positions(fs_ctx *ctx, int n, const int *envs);
 int fs_max_displacement(fs_ctx *ctx, int n, const int *envs, float *out, int n_floats);
+/* Write ONE particle per listed episode: position + inverse mass from pos4[4k..4k+3], velocity zeroed when zero_velocity != 0.
+   The reference's task generator (environment/tasks.py:177-224) moves a pinned pick point by reading and rewriting the
+   whole position and velocity arrays through pyflex every simulation step. */
+int fs_set_particles(fs_ctx *ctx, int n, const int *envs, const int *particle_ids, const float *pos4, int zero_velocity);
 
 /* ---- observation transforms on the device ---------------------------------------------------
    learning/nets.py:155-193 prepare_image: n_transforms rotated / scaled / resized copies of one observation.

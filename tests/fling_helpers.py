@@ -105,3 +105,104 @@ def run_primitives_golden(make_sim, get_positions, get_shapes):
                 assert out[k]["dist"] == g["stretch_ret"][c], (kind, c)
             assert np.array_equal(get_positions(sim, k).view(np.uint32), g["pos"][c].view(np.uint32)), (kind, c)
             assert np.array_equal(np.asarray(get_shapes(sim, k), np.float32).view(np.uint32), g["shapes"][c].view(np.uint32)), (kind, c)
+
+
+class OracleTaskSim:
+    """The slice of the FlingSim interface flingbot_amd.tasks uses, on N bare CPU oracles (no scene yet)."""
+
+    def __init__(self, n):
+        from oracle import OracleSim
+
+        self.sims = [OracleSim() for _ in range(n)]
+
+    def set_scene(self, e, scene_params):
+        self.sims[e].set_scene(scene_params)
+
+    def step_list(self, envs, n_steps=1):
+        for e in envs:
+            self.sims[e].step(n_steps)
+
+    def add_sphere(self, e, radius, pos, quat):
+        self.sims[e].add_sphere(radius, pos, quat)
+
+    def get_shape_states(self, e):
+        return self.sims[e].get_shape_states()
+
+    def set_shape_states(self, e, s):
+        self.sims[e].set_shape_states(s)
+
+    def get_positions(self, e):
+        return self.sims[e].get_positions()
+
+    def set_positions(self, e, p):
+        self.sims[e].set_positions(p)
+
+    def get_velocities(self, e):
+        return self.sims[e].get_velocities()
+
+    def get_phases(self, e):
+        return self.sims[e].get_phases()
+
+    def set_particles(self, envs, pids, pos4, zero_velocity=True):
+        for e, pid, p4 in zip(envs, pids, pos4):
+            pos = self.sims[e].get_positions().reshape(-1, 4).copy()
+            pos[pid] = np.asarray(p4, np.float32)
+            self.sims[e].set_positions(pos.ravel())
+            if zero_velocity:
+                vel = self.sims[e].get_velocities().reshape(-1, 3).copy()
+                vel[pid] = 0
+                self.sims[e].set_velocities(vel.ravel())
+
+    def cloth_stats(self, envs):
+        out = np.empty((len(envs), 3), np.float32)
+        for k, e in enumerate(envs):
+            pos = self.sims[e].get_positions().reshape(-1, 4)
+            out[k] = (pos[:, 1].min(), pos[:, 1].max(), np.abs(self.sims[e].get_velocities()).max())
+        return out
+
+    def wait_until_stable(self, envs, max_steps=300, tolerance=1e-2):
+        stable, steps = [], []
+        for e in envs:
+            done, ok = 0, False
+            for _ in range(max_steps):
+                if np.abs(self.sims[e].get_velocities()).max() < tolerance:
+                    ok = True
+                    break
+                self.sims[e].step(1)
+                done += 1
+            stable.append(ok)
+            steps.append(done)
+        return np.array(stable), np.array(steps, np.int32)
+
+    def coverage(self):
+        from oracle.coverage import covered_area
+
+        return [covered_area(s.get_positions()) if s.n else 0.0 for s in self.sims]
+
+
+def check_tasks_against_golden(make_sim):
+    """Seeds numpy's and Python's generators like the golden run, draws the task parameters with the product's
+    draw_task_parameters and generates the tasks on make_sim(n); everything the reference returned must be reproduced."""
+    import random
+
+    from flingbot_amd import tasks as ftasks
+
+    g = np.load(os.path.join(GOLD, "task_golden.npz"))
+    params = []
+    for ci in range(2):
+        seed = int(g[f"t{ci}_seed"])
+        random.seed(seed)
+        np.random.seed(seed)
+        params.append(ftasks.draw_task_parameters(min_cloth_size=20, strict_min_edge_length=20, max_cloth_size=30))
+    sim = make_sim(2)
+    out = ftasks.generate_hard_tasks(sim, params)
+    for ci, task in enumerate(out):
+        assert task is not None
+        assert task["cloth_size"].tolist() == g[f"t{ci}_cloth_size"].tolist()
+        assert np.array_equal(task["cloth_stiff"], g[f"t{ci}_cloth_stiff"]) and task["cloth_mass"] == float(g[f"t{ci}_cloth_mass"])
+        assert task["flatten_area"] == float(g[f"t{ci}_flatten_area"])
+        for k in ("particle_pos", "particle_vel", "shape_pos"):
+            assert np.array_equal(np.asarray(task[k], np.float32).view(np.uint32), g[f"t{ci}_{k}"].view(np.uint32)), (ci, k)
+        assert np.array_equal(task["phase"], g[f"t{ci}_phase"])
+        assert abs(task["initial_coverage"] - float(g[f"t{ci}_initial_coverage"])) <= 1e-12
+    return out

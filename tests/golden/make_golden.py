@@ -509,8 +509,93 @@ def action_vectors():
     np.savez_compressed(os.path.join(HERE, "action_golden.npz"), **out)
 
 
+def task_vectors():
+    """The reference's task generator generate_randomization(task_difficulty='hard', grid cloth)
+    (environment/tasks.py:105-275, with flex_utils set_scene / set_to_flatten / center_object / wait_until_stable /
+    get_current_covered_area) on the oracle-backed `pyflex` stub, for seeded random draws and a reduced cloth-size range
+    (the generator's own min/max arguments) so the CPU oracle finishes in seconds."""
+    sys.path.insert(0, ROOT)
+    from oracle import OracleSim
+    import random
+    import torch  # noqa: F401
+    import scipy.ndimage  # noqa: F401
+
+    if not hasattr(np, "alltrue"):
+        np.alltrue = np.all
+    if not hasattr(np, "float"):
+        np.float = float  # flex_utils.py:406 (numpy 1.x alias)
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, name): return _Any()
+
+    def anystub(name):
+        m = types.ModuleType(name)
+
+        def _ga(attr):
+            if attr.startswith("__"):
+                raise AttributeError(attr)
+            return _Any()
+        m.__getattr__ = _ga
+        m.__path__ = []
+        m.__file__ = "<stub %s>" % name
+        sys.modules[name] = m
+        return m
+
+    for name in ("h5py", "filelock", "imageio", "trimesh", "OpenEXR", "Imath", "cv2", "PIL", "skimage", "skimage.morphology",
+                 "matplotlib", "matplotlib.pyplot", "ray", "pyflex"):
+        if name != "pyflex":
+            try:
+                __import__(name)
+                continue
+            except Exception:
+                pass
+        anystub(name)
+    sys.modules["ray"].remote = lambda f: f
+    box = {}
+    pf = sys.modules["pyflex"]
+    for name in ("get_positions", "set_positions", "get_velocities", "set_velocities", "get_shape_states",
+                 "set_shape_states", "add_sphere", "get_phases", "set_phases"):
+        setattr(pf, name, (lambda nm: lambda *a, **k: getattr(box["o"], nm)(*a, **k))(name))
+    counter = {"steps": 0}
+
+    def _step(*a, **k):
+        counter["steps"] += 1
+        box["o"].step(1)
+    pf.step = _step
+    pf.set_scene = lambda scene_idx=0, scene_params=None, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), \
+        faces=(), thread_idx=0: box["o"].set_scene(scene_params, vertices, stretch_edges, bend_edges, shear_edges, faces)
+    for m in [k for k in sys.modules if k == "environment" or k.startswith("environment.") or k in ("flex_utils", "nets")]:
+        del sys.modules[m]
+    sys.path.insert(0, REF)
+    from environment import tasks as ref_tasks
+    from environment import flex_utils as ref_fu
+
+    out = {}
+    for ci, seed in enumerate((3, 11)):
+        random.seed(seed)
+        np.random.seed(seed)
+        box["o"] = OracleSim()
+        tool = ref_fu.PickerPickPlace(num_picker=2, particle_radius=0.00625, picker_radius=0.05,
+                                      picker_low=(-5, 0, -5), picker_high=(5, 5, 5))
+        counter["steps"] = 0
+        task = ref_tasks.generate_randomization(tool, min_cloth_size=20, strict_min_edge_length=20, max_cloth_size=30,
+                                                task_difficulty="hard", cloth_type="grid")
+        print("task", ci, "seed", seed, None if task is None else (task["cloth_size"], float(task["cloth_mass"]),
+              float(task["initial_coverage"]), float(task["flatten_area"])), "steps", counter["steps"])
+        assert task is not None
+        out[f"t{ci}_seed"] = np.array(seed)
+        out[f"t{ci}_steps"] = np.array(counter["steps"])
+        for k in ("particle_pos", "particle_vel", "shape_pos", "phase", "cloth_size", "cloth_stiff"):
+            out[f"t{ci}_{k}"] = np.asarray(task[k])
+        for k in ("initial_coverage", "flatten_area", "cloth_mass"):
+            out[f"t{ci}_{k}"] = np.array(float(task[k]))
+    np.savez_compressed(os.path.join(HERE, "task_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling", "action"]
+    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling", "action", "task"]
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:
@@ -525,3 +610,5 @@ if __name__ == "__main__":
         fling_vectors()
     if "action" in which:
         action_vectors()
+    if "task" in which:
+        task_vectors()

@@ -455,3 +455,11 @@ def test_drag_place_stretchdrag_host_logic_reproduces_reference_golden():
     g = load_primitives_golden()
     run_primitives_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"]),
                           lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
+
+
+def test_task_generator_host_logic_reproduces_reference_golden():
+    """flingbot_amd.tasks.generate_hard_tasks on the CPU oracle retraces the REFERENCE's generate_randomization
+    (tests/golden/task_golden.npz: two seeded hard tasks), including the random draws, bit for bit."""
+    from fling_helpers import OracleTaskSim, check_tasks_against_golden
+
+    check_tasks_against_golden(lambda n: OracleTaskSim(n))
