@@ -167,3 +167,28 @@ def generate_hard_tasks(sim, params, picker_radius=0.05):
             'mesh_bend_edges': np.array([]), 'mesh_shear_edges': np.array([]), 'mesh_faces': np.array([]),
         }
     return tasks
+
+
+def load_tasks(sim, tasks, cloth_pos=(0, 2, 0)):
+    """set_scene(config=task.get_config(), state=task.get_state()) (flex_utils.py:320-355, tasks.py:374-411) for episode e =
+    index in `tasks`: build the scene, step once, then overwrite positions / velocities / phases (and the shape states when
+    the scene has shapes: with none, pyflex.set_shape_states copies nothing).  None entries are left untouched."""
+    envs = [e for e, t in enumerate(tasks) if t is not None]
+    cam_pos, cam_angle = np.array([0, 2, 0]), np.array([np.pi * 0.5, -np.pi * 0.5, 0])
+    for e in envs:
+        t = tasks[e]
+        size = [-1, -1] if len(t['mesh_verts']) > 0 else list(t['cloth_size'])
+        scene_params = np.array([*cloth_pos, *size, *t['cloth_stiff'], 2, *cam_pos, *cam_angle, 720, 720, t['cloth_mass'],
+                                 t['flip_mesh']])
+        sim.set_scene(e, scene_params, t['mesh_verts'], t['mesh_stretch_edges'], t['mesh_bend_edges'],
+                      t['mesh_shear_edges'], t['mesh_faces'])
+    sim.step_list(envs, 1)
+    for e in envs:
+        t = tasks[e]
+        sim.set_positions(e, t['particle_pos'])
+        sim.set_velocities(e, t['particle_vel'])
+        if sim.n_shapes(e) > 0:
+            sim.set_shape_states(e, t['shape_pos'])
+        sim.set_phases(e, t['phase'])
+        sim.set_camera_params(e, [*cam_pos, *cam_angle, 720, 720])
+    return envs
