@@ -63,19 +63,31 @@ def flattened_positions(cloth_dimx, cloth_dimz, cloth_particle_radius=0.00625):
     return new_pos
 
 
-def draw_task_parameters(min_cloth_size=64, strict_min_edge_length=64, max_cloth_size=104):
-    """The random draws of ONE generate_randomization call, in its order (tasks.py:120-122, 147-148, 179, 188), from the
-    global numpy / Python generators.  Returns None where the reference returns None (both edges too short)."""
+def draw_task_parameters(min_cloth_size=64, strict_min_edge_length=64, max_cloth_size=104, task_difficulty='hard'):
+    """The random draws of ONE generate_randomization call, in its order (tasks.py:120-122, 147-148; hard :179, 188; easy
+    :229, 239 ten times), from the global numpy / Python generators.  Returns None where the reference returns None (both
+    edges too short)."""
     cloth_dimx = np.random.randint(min_cloth_size, max_cloth_size)
     cloth_dimy = np.random.randint(min_cloth_size, max_cloth_size)
     if cloth_dimx < strict_min_edge_length and cloth_dimy < strict_min_edge_length:
         return None
     stiffness = np.random.uniform(0.85, 0.95, 3)
     cloth_mass = np.random.uniform(0.2, 2.0)
-    pickpoint = random.randint(0, cloth_dimx * cloth_dimy - 1)
-    height = np.random.random(1) * 1.0 + 0.5
-    return dict(cloth_size=[cloth_dimx, cloth_dimy], cloth_stiff=stiffness, cloth_mass=cloth_mass, pickpoint=pickpoint,
-                height=height)
+    out = dict(cloth_size=[cloth_dimx, cloth_dimy], cloth_stiff=stiffness, cloth_mass=cloth_mass,
+               task_difficulty=task_difficulty)
+    if task_difficulty == 'hard':
+        out['pickpoint'] = random.randint(0, cloth_dimx * cloth_dimy - 1)
+        out['height'] = np.random.random(1) * 1.0 + 0.5
+    elif task_difficulty == 'easy':
+        out['throws'] = []
+        for _ in range(10):
+            pickpoint = random.randint(0, cloth_dimx * cloth_dimy - 1)
+            displacement = np.random.uniform(-0.2, 0.2, 3)
+            displacement[1] = 0.2
+            out['throws'].append((pickpoint, displacement))
+    else:
+        raise NotImplementedError()
+    return out
 
 
 def _picker_reset_states(center, picker_radius=0.05, num_picker=2):
@@ -96,8 +108,14 @@ def _center_object(sim, envs):
 
 
 def generate_hard_tasks(sim, params, picker_radius=0.05):
+    """Kept name of generate_tasks (both difficulties are handled there)."""
+    return generate_tasks(sim, params, picker_radius)
+
+
+def generate_tasks(sim, params, picker_radius=0.05):
     """params: one dict per episode of `sim` (draw_task_parameters(); None entries are skipped like the reference's `return
-    None`).  Returns one task dict per entry (None for skipped / rejected ones) with the reference's keys."""
+    None`), all of the same task_difficulty.  Returns one task dict per entry (None for skipped / rejected ones) with the
+    reference's keys."""
     envs = [e for e, p in enumerate(params) if p is not None]
     tasks = [None] * len(params)
     if not envs:
@@ -120,6 +138,37 @@ def generate_hard_tasks(sim, params, picker_radius=0.05):
         sim.set_positions(e, new_pos.flatten())
         flat_area[e] = covered_area_of(new_pos)
     _center_object(sim, envs)
+    difficulty = params[envs[0]].get('task_difficulty', 'hard')
+    assert all(params[e].get('task_difficulty', 'hard') == difficulty for e in envs), "one difficulty per batch"
+    if difficulty == 'easy':
+        _easy_throws(sim, envs, params)
+    else:
+        _hard_lift(sim, envs, params)
+    return _finish_tasks(sim, envs, params, tasks, flat_area, difficulty)
+
+
+def _easy_throws(sim, envs, params):
+    """tasks.py:225-258: ten times, a random vertex is pinned and dragged 100 steps along a random displacement."""
+    speed = 0.01
+    for throw in range(10):
+        pick = {e: int(params[e]['throws'][throw][0]) for e in envs}
+        orig_w, start, target = {}, {}, {}
+        for e in envs:
+            curr = sim.get_positions(e)
+            orig_w[e] = curr[pick[e] * 4 + 3]
+            start[e] = curr[pick[e] * 4: pick[e] * 4 + 3].copy()            # float32
+            target[e] = start[e] + params[e]['throws'][throw][1]             # float64
+        sim.set_particles(envs, [pick[e] for e in envs], [[*start[e], 0.0] for e in envs], zero_velocity=False)
+        for j in range(int(1 / speed)):
+            at = {e: ((target[e] - start[e]) * (j * speed) + start[e]).astype(np.float32) for e in envs}
+            sim.set_particles(envs, [pick[e] for e in envs], [[*at[e], 0.0] for e in envs], zero_velocity=True)
+            sim.step_list(envs, 1)
+        # reset to previous cloth parameters: the particle keeps where the solver has it (kinematic: the last pinned position)
+        last = {e: ((target[e] - start[e]) * ((int(1 / speed) - 1) * speed) + start[e]).astype(np.float32) for e in envs}
+        sim.set_particles(envs, [pick[e] for e in envs], [[*last[e], orig_w[e]] for e in envs], zero_velocity=False)
+
+
+def _hard_lift(sim, envs, params):
     # ---- hard task (tasks.py:177-224): pin a random particle, raise it over 200 steps ...
     pick = {e: int(params[e]["pickpoint"]) for e in envs}
     orig_w, pick_pos, init_h = {}, {}, {}
@@ -152,6 +201,9 @@ def generate_hard_tasks(sim, params, picker_radius=0.05):
         active = [e for e, v in zip(active, vmax) if not ((v < 1e-1) and j > 5)]
     # release: the pinned particle gets its inverse mass back (tasks.py:221-224)
     sim.set_particles(envs, [pick[e] for e in envs], [[*pick_pos[e], orig_w[e]] for e in envs], zero_velocity=False)
+
+
+def _finish_tasks(sim, envs, params, tasks, flat_area, difficulty):
     sim.wait_until_stable(envs)  # wait_until_stable(gui=gui): 300 steps at most, tolerance 1e-2
     stats = sim.cloth_stats(envs)
     keep = [e for e, s_ in zip(envs, stats) if not (s_[1] > 0.4)]  # heights.max() > 0.4: "probably an error" -> None
@@ -163,7 +215,7 @@ def generate_hard_tasks(sim, params, picker_radius=0.05):
             'particle_pos': sim.get_positions(e), 'particle_vel': sim.get_velocities(e), 'initial_coverage': coverage[e],
             'shape_pos': sim.get_shape_states(e), 'phase': sim.get_phases(e), 'flatten_area': flat_area[e], 'flip_mesh': 0,
             'cloth_size': np.array(p["cloth_size"]), 'cloth_stiff': p["cloth_stiff"], 'cloth_mass': p["cloth_mass"],
-            'task_difficulty': 'hard', 'mesh_verts': np.array([]), 'mesh_stretch_edges': np.array([]),
+            'task_difficulty': difficulty, 'mesh_verts': np.array([]), 'mesh_stretch_edges': np.array([]),
             'mesh_bend_edges': np.array([]), 'mesh_shear_edges': np.array([]), 'mesh_faces': np.array([]),
         }
     return tasks

@@ -188,21 +188,27 @@ def check_tasks_against_golden(make_sim):
     from flingbot_amd import tasks as ftasks
 
     g = np.load(os.path.join(GOLD, "task_golden.npz"))
-    params = []
-    for ci in range(2):
-        seed = int(g[f"t{ci}_seed"])
-        random.seed(seed)
-        np.random.seed(seed)
-        params.append(ftasks.draw_task_parameters(min_cloth_size=20, strict_min_edge_length=20, max_cloth_size=30))
-    sim = make_sim(2)
-    out = ftasks.generate_hard_tasks(sim, params)
-    for ci, task in enumerate(out):
-        assert task is not None
-        assert task["cloth_size"].tolist() == g[f"t{ci}_cloth_size"].tolist()
-        assert np.array_equal(task["cloth_stiff"], g[f"t{ci}_cloth_stiff"]) and task["cloth_mass"] == float(g[f"t{ci}_cloth_mass"])
-        assert task["flatten_area"] == float(g[f"t{ci}_flatten_area"])
-        for k in ("particle_pos", "particle_vel", "shape_pos"):
-            assert np.array_equal(np.asarray(task[k], np.float32).view(np.uint32), g[f"t{ci}_{k}"].view(np.uint32)), (ci, k)
-        assert np.array_equal(task["phase"], g[f"t{ci}_phase"])
-        assert abs(task["initial_coverage"] - float(g[f"t{ci}_initial_coverage"])) <= 1e-12
-    return out
+    n_cases = sum(1 for k in g.files if k.endswith("_seed"))
+    results = {}
+    for difficulty in ("hard", "easy"):
+        cases = [ci for ci in range(n_cases) if str(g[f"t{ci}_difficulty"]) == difficulty]
+        params = []
+        for ci in cases:
+            seed = int(g[f"t{ci}_seed"])
+            random.seed(seed)
+            np.random.seed(seed)
+            params.append(ftasks.draw_task_parameters(min_cloth_size=20, strict_min_edge_length=20, max_cloth_size=30,
+                                                      task_difficulty=difficulty))
+        sim = make_sim(len(cases))
+        out = ftasks.generate_tasks(sim, params)
+        for ci, task in zip(cases, out):
+            assert task is not None and task["task_difficulty"] == difficulty
+            assert task["cloth_size"].tolist() == g[f"t{ci}_cloth_size"].tolist()
+            assert np.array_equal(task["cloth_stiff"], g[f"t{ci}_cloth_stiff"]) and task["cloth_mass"] == float(g[f"t{ci}_cloth_mass"])
+            assert task["flatten_area"] == float(g[f"t{ci}_flatten_area"])
+            for k in ("particle_pos", "particle_vel", "shape_pos"):
+                assert np.array_equal(np.asarray(task[k], np.float32).view(np.uint32), g[f"t{ci}_{k}"].view(np.uint32)), (ci, k)
+            assert np.array_equal(task["phase"], g[f"t{ci}_phase"])
+            assert abs(task["initial_coverage"] - float(g[f"t{ci}_initial_coverage"])) <= 1e-12
+            results[ci] = task
+    return results

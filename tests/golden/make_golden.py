@@ -573,7 +573,7 @@ def task_vectors():
     from environment import flex_utils as ref_fu
 
     out = {}
-    for ci, seed in enumerate((3, 11)):
+    for ci, (seed, difficulty) in enumerate(((3, "hard"), (11, "hard"), (5, "easy"))):
         random.seed(seed)
         np.random.seed(seed)
         box["o"] = OracleSim()
@@ -581,11 +581,12 @@ def task_vectors():
                                       picker_low=(-5, 0, -5), picker_high=(5, 5, 5))
         counter["steps"] = 0
         task = ref_tasks.generate_randomization(tool, min_cloth_size=20, strict_min_edge_length=20, max_cloth_size=30,
-                                                task_difficulty="hard", cloth_type="grid")
+                                                task_difficulty=difficulty, cloth_type="grid")
         print("task", ci, "seed", seed, None if task is None else (task["cloth_size"], float(task["cloth_mass"]),
               float(task["initial_coverage"]), float(task["flatten_area"])), "steps", counter["steps"])
         assert task is not None
         out[f"t{ci}_seed"] = np.array(seed)
+        out[f"t{ci}_difficulty"] = np.array(difficulty)
         out[f"t{ci}_steps"] = np.array(counter["steps"])
         for k in ("particle_pos", "particle_vel", "shape_pos", "phase", "cloth_size", "cloth_stiff"):
             out[f"t{ci}_{k}"] = np.asarray(task[k])
