@@ -1,0 +1,122 @@
+"""BatchedFlingEnv -- SimEnv.reset / step (environment/simEnv.py:477-515, 663-697) for many episodes on one GPU.
+
+Composition of the device-side pieces of this package, one call per stage for ALL episodes where the stage allows it:
+    tasks.load_tasks + FlingPrimitives.setup_pickers          SimEnv.reset           (simEnv.py:663-697)
+    fs_render -> preprocess_obs -> fs_prepare_image           get_obs / prepare_image (simEnv.py:709-737, nets.py:177-193)
+    ActionSelector.select (fs_select_action)                  get_max_value_valid_action (simEnv.py:560-661)
+    FlingPrimitives.pick_and_fling / drag / place / stretchdrag   the action handlers  (simEnv.py:283-428)
+    preaction / postaction, coverage                          SimEnv.step            (simEnv.py:464-515)
+Stated deviations (the stages below depend on cv2 / skimage, absent from this image, and are therefore NOT pinned):
+  * the observation is rendered directly at image_dim x image_dim instead of 720 x 720 + cv2.resize (flex_utils.py:418-427);
+  * no adaptive scaling / HSV cloth mask (simEnv.py:699-735): the scale factors are used as given;
+  * the grasp-on-cloth flags use a Euclidean disc of conservative_grasp_radius on `depth != 2.0` instead of cv2.circle masks
+    (simEnv.py:235-255).
+Every other stage is pinned on its own in tests/ (see DESIGN.md 4.4-4.65).
+"""
+import numpy as np
+import torch
+
+from . import nets
+from .action import ActionSelector
+from .primitives import FlingPrimitives
+from .tasks import load_tasks
+
+
+class BatchedFlingEnv:
+    def __init__(self, sim, action_primitives=("fling",), obs_dim=64, image_dim=128, num_rotations=12,
+                 scale_factors=(1.0, 1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75), pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5,
+                 reach_distance_limit=1.2, conservative_grasp_radius=4, episode_length=10, grasp_height=0.02,
+                 fling_speed=6e-3, stretchdrag_dist=0.3, device="cuda:0"):
+        self.sim = sim
+        self.actions = list(action_primitives)
+        self.obs_dim, self.image_dim = int(obs_dim), int(image_dim)
+        if "fling" in self.actions:  # nets.py:213-218
+            self.rotations = [(2 * i / (num_rotations - 1) - 1) * 90 for i in range(num_rotations)]
+        else:
+            self.rotations = [(2 * i / num_rotations - 1) * 180 for i in range(num_rotations)]
+        self.scale_factors = np.array(scale_factors, np.float64)
+        self.transformations = [(r, s) for r in self.rotations for s in self.scale_factors]  # product(rotations, scales)
+        self.conservative_grasp_radius = int(conservative_grasp_radius)
+        self.episode_length = int(episode_length)
+        self.device = torch.device(device)
+        self.selector = ActionSelector(self.actions, self.rotations, obs_dim, pix_grasp_dist, pix_drag_dist, pix_place_dist,
+                                       reach_distance_limit, stretchdrag_dist=stretchdrag_dist, grasp_height=grasp_height)
+        self._prim_kwargs = dict(grasp_height=grasp_height, fling_speed=fling_speed, stretchdrag_dist=stretchdrag_dist)
+        self.envs, self.prim = [], None
+        self.timestep, self.terminate = {}, {}
+        self.pretransform_depth = {}
+
+    # ---- SimEnv.reset for a batch of tasks (entry e of `tasks` becomes episode e)
+    def reset(self, tasks):
+        self.envs = load_tasks(self.sim, tasks)
+        for e in self.envs:
+            cp = self.sim.get_camera_params(e)
+            self.sim.set_camera_params(e, [*cp[2:8], self.image_dim, self.image_dim])
+        self.init_coverage = np.array(self.sim.coverage())
+        self.prim = FlingPrimitives(self.sim, self.envs, **self._prim_kwargs)
+        self.prim.setup_pickers()
+        self.timestep = {e: 0 for e in self.envs}
+        self.terminate = {e: False for e in self.envs}
+        return self.observe()
+
+    def get_obs(self, e):
+        """render + flip + preprocess_obs (flex_utils.py:418-427, utils.py:579-582): float32 [4, S, S] on the device."""
+        s_ = self.image_dim
+        rgba, depth = self.sim.render(e)
+        rgb = np.flip(rgba.reshape(s_, s_, 4), 0)[:, :, :3]
+        d = np.flip(depth.reshape(s_, s_), 0).copy()
+        self.pretransform_depth[e] = d
+        return torch.cat((torch.tensor(rgb.copy()).float() / 255, torch.tensor(d).unsqueeze(2)), dim=2).permute(2, 0, 1).to(self.device)
+
+    def observe(self):
+        """{episode: transformed observation [T, 4, D, D] (CUDA)} for the episodes that are still running."""
+        return {e: nets.prepare_image(self.get_obs(e), self.transformations, self.obs_dim)
+                for e in self.envs if not self.terminate[e]}
+
+    def _on_cloth(self, depth, pix):
+        yy, xx = np.ogrid[:depth.shape[0], :depth.shape[1]]
+        r = self.conservative_grasp_radius
+        if r <= 0:
+            return True
+        disc = (yy - pix[0]) ** 2 + (xx - pix[1]) ** 2 <= r * r
+        return bool((depth != 2.0)[disc].all())
+
+    # ---- SimEnv.step for every running episode: value_maps[e] = {primitive: CUDA tensor [T, D, D]}
+    def step(self, value_maps):
+        run = [e for e in self.envs if not self.terminate[e] and e in value_maps]
+        if not run:
+            return {}, {}, dict(self.terminate), {}
+        self.prim.preaction(run)
+        prev = np.array(self.sim.coverage())
+        chosen = {}
+        for e in run:
+            action, params = self.selector.select(value_maps[e], self.scale_factors, self.pretransform_depth[e])
+            if action is not None:
+                d, pix = self.pretransform_depth[e], params["pretransform_pixels"]
+                params["p1_grasp_cloth"] = self._on_cloth(d, (pix[0][1], pix[0][0]))
+                params["p2_grasp_cloth"] = self._on_cloth(d, (pix[1][1], pix[1][0]))
+                chosen[e] = (action, params)
+        for action in self.actions:  # one batched primitive call per action type
+            es = [e for e in run if e in chosen and chosen[e][0] == action]
+            if not es:
+                continue
+            sub = FlingPrimitives(self.sim, es, **self._prim_kwargs)
+            sub.grasp_states = {e: self.prim.grasp_states[e] for e in es}
+            p1 = [chosen[e][1]["p1"] for e in es]
+            p2 = [chosen[e][1]["p2"] for e in es]
+            g1 = [chosen[e][1]["p1_grasp_cloth"] for e in es]
+            g2 = [chosen[e][1]["p2_grasp_cloth"] for e in es]
+            fn = {"fling": sub.pick_and_fling, "drag": sub.pick_and_drag, "place": sub.pick_and_place,
+                  "stretchdrag": sub.pick_stretch_drag}[action]
+            fn(p1, p2, g1, g2)
+            self.prim.sim_steps += sub.sim_steps
+            for e in es:
+                self.prim.terminate[e] = self.prim.terminate[e] or sub.terminate[e]
+        self.prim.postaction(run)
+        curr = np.array(self.sim.coverage())
+        rewards = {}
+        for e in run:
+            self.timestep[e] += 1
+            self.terminate[e] = self.prim.terminate[e] or self.timestep[e] >= self.episode_length
+            rewards[e] = float(curr[e] - prev[e])
+        return self.observe(), rewards, dict(self.terminate), {e: chosen.get(e, (None, None))[0] for e in run}

@@ -173,12 +173,15 @@ class FlingPrimitives:
     # ---- simEnv.py:464-475: SimEnv.preaction / postaction around an action
     def preaction(self, envs=None):
         envs = [int(e) for e in (self.envs if envs is None else envs)]
-        self.sim.snapshot_positions(envs)
+        if envs:
+            self.sim.snapshot_positions(envs)
 
     def postaction(self, envs=None, max_steps=300, tolerance=1e-2):
         """reset_end_effectors, wait_until_stable, and the "didn't really move cloth -> end early" test.  Returns the
         per-episode terminate flags (also kept in self.terminate)."""
         envs = [int(e) for e in (self.envs if envs is None else envs)]
+        if not envs:
+            return []
         self.reset_end_effectors(envs)
         _, steps = self.sim.wait_until_stable(envs, max_steps=max_steps, tolerance=tolerance)
         self.sim_steps += int(np.sum(steps))

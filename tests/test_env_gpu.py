@@ -1,0 +1,42 @@
+"""BatchedFlingEnv (flingbot_amd/env.py): SimEnv.reset / step composed from the device-side stages for several episodes.
+The stages are pinned individually elsewhere; this checks the composition's contract (shapes, rewards, termination)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_env_reset_and_step(gpu_required):
+    from flingbot_amd import nets, sim as fsim, tasks as ftasks
+    from flingbot_amd.env import BatchedFlingEnv
+
+    random.seed(2)
+    np.random.seed(2)
+    n = 3
+    params = [ftasks.draw_task_parameters(min_cloth_size=40, strict_min_edge_length=40, max_cloth_size=56) for _ in range(n)]
+    gen = fsim.FlingSim(n_envs=n, solver=0)
+    tasks = ftasks.generate_tasks(gen, params)
+    ctx = fsim.FlingSim(n_envs=n, solver=0)
+    env = BatchedFlingEnv(ctx, image_dim=96, episode_length=2)
+    obs = env.reset(tasks)
+    assert sorted(obs) == list(range(n))
+    T = len(env.transformations)
+    assert all(o.is_cuda and tuple(o.shape) == (T, 4, 64, 64) for o in obs.values())
+    torch.manual_seed(0)
+    net = nets.SpatialValueNet(rgb_only=True, device=env.device).to(env.device).eval()
+    steps_taken = 0
+    for step in range(2):
+        if not obs:
+            break  # every episode ended early ("didn't really move cloth", simEnv.py:473-475)
+        steps_taken += 1
+        with torch.no_grad():
+            vmaps = {e: {"fling": net(o).squeeze(1)} for e, o in obs.items()}
+        obs, rewards, terminate, actions = env.step(vmaps)
+        assert all(np.isfinite(r) for r in rewards.values())
+        assert set(actions.values()) <= {"fling", None}
+    assert steps_taken >= 1 and all(terminate.values())  # episode_length = 2 (or an early end)
+    assert obs == {}                                       # nothing left to observe
+    assert env.prim.sim_steps > 0
