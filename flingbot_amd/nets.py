@@ -54,6 +54,9 @@ class ResidualBlock(nn.Module):
         return self.relu(out)
 
 
+_vn_work = {}
+
+
 class SpatialValueNet(nn.Module):
     def __init__(self, rgb_only=False, depth_only=False, steps=0, device='cuda', **kwargs):
         super().__init__()
@@ -71,6 +74,7 @@ class SpatialValueNet(nn.Module):
         self.mean, self.std = mean, std  # plain attributes, not buffers: they are not in the reference's state_dict
         self.steps = nn.parameter.Parameter(torch.tensor(steps), requires_grad=False)
         self._folded = None
+        self._hip = None
 
     def setup_net(self):
         blocks = [BasicBlock(self.input_channels, 16, 3, 1)]
@@ -94,15 +98,61 @@ class SpatialValueNet(nn.Module):
 
     def forward(self, obs):
         if self._folded is not None and not self.training:
+            if self._hip is not None and obs.is_cuda and obs.dim() == 4 and tuple(obs.shape[-2:]) == (64, 64):
+                return self._forward_hip(obs)
             return self._folded(self.preprocess_obs(obs).contiguous(memory_format=torch.channels_last))
         return self.net(self.preprocess_obs(obs))
 
+    def _forward_hip(self, obs):
+        """The whole forward (normalisation included) in libflingsim's fs_value_net_forward (csrc/fs_valuenet.hip):
+        10 launches, the 16 -> 16 convolutions of a residual block fused in LDS on fp32 MFMA."""
+        import ctypes as C
+        lib, params = self._hip
+        c = int(obs.shape[1])
+        if self.rgb_only:
+            if c not in (3, 4):
+                raise Exception
+            off = 0
+        elif self.depth_only:
+            if c not in (1, 4):
+                raise Exception
+            off = 3 if c == 4 else 0
+        else:
+            off = 0
+        if off + self.input_channels > c:
+            raise Exception
+        obs = obs.contiguous().float()
+        if params.device != obs.device:
+            params = params.to(obs.device)
+            object.__setattr__(self, '_hip', (lib, params))
+        batch = int(obs.shape[0])
+        out = torch.empty((batch, 1, 64, 64), dtype=torch.float32, device=obs.device)
+        if batch == 0:
+            return out
+        nbytes = int(lib.fs_value_net_work_bytes(batch, 64))
+        key = obs.device.index
+        work = _vn_work.get(key)
+        if work is None or work.numel() < nbytes:
+            work = torch.empty(nbytes, dtype=torch.uint8, device=obs.device)
+            _vn_work[key] = work
+        with torch.cuda.device(obs.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            rc = lib.fs_value_net_forward(C.c_void_p(params.data_ptr()), C.c_void_p(obs.data_ptr()), c, off,
+                                          self.input_channels, batch, 64, C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(work.data_ptr()), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("fs_value_net_forward: " + lib.fs_last_error().decode())
+        return out
+
     # ---- inference fast path -------------------------------------------------------------------------------------
-    def fold_batchnorm(self):
+    def fold_batchnorm(self, hip=None):
         """Build an eval-only copy of `net` with every BatchNorm folded into the preceding convolution
         (w' = w * g / sqrt(var + eps), b' = beta - mean * g / sqrt(var + eps)) in channels-last layout.
         18 conv + 17 BN + activations become 18 conv(+bias) launches.  The parameters of `net` are untouched, so
-        state_dict() keeps the reference layout."""
+        state_dict() keeps the reference layout.
+        hip: also pack the folded weights for the hand-written forward (fs_value_net_forward), which then serves CUDA
+        observations of 64 x 64 pixels; default = whenever the parameters live on a GPU.  Call again after loading
+        new weights."""
         self.eval()
 
         def fold(conv, bn):
@@ -131,7 +181,36 @@ class SpatialValueNet(nn.Module):
         for p in folded.parameters():
             p.requires_grad_(False)
         object.__setattr__(self, '_folded', folded)  # not registered: keeps state_dict identical to the reference
+        dev = next(self.net.parameters()).device
+        if hip is None:
+            hip = dev.type == 'cuda'
+        object.__setattr__(self, '_hip', self._pack_hip(folded, dev) if hip else None)
         return self
+
+    def _pack_hip(self, folded, dev):
+        import ctypes as C
+        from .sim import load_library
+        lib = load_library()  # raises when libflingsim is missing: no silent change of path
+        fp = C.POINTER(C.c_float)
+
+        def host(t):
+            return np.ascontiguousarray(t.detach().cpu().numpy(), np.float32)
+
+        blocks = list(folded)[2:-1]
+        w_blocks = np.stack([host(c.weight) for b in blocks for c in (b.c1, b.c2)])
+        b_blocks = np.stack([host(c.bias) for b in blocks for c in (b.c1, b.c2)])
+        assert w_blocks.shape == (16, 16, 16, 3, 3) and b_blocks.shape == (16, 16)
+        mean = np.ascontiguousarray(np.atleast_1d(self.mean.numpy()), np.float32)
+        std = np.ascontiguousarray(np.atleast_1d(self.std.numpy()), np.float32)
+        w_first, b_first, w_last = host(folded[0].weight), host(folded[0].bias), host(folded[-1].weight)
+        packed = np.zeros(int(lib.fs_value_net_param_floats()), np.float32)
+        rc = lib.fs_value_net_pack(self.input_channels, mean.ctypes.data_as(fp), std.ctypes.data_as(fp),
+                                   w_first.ctypes.data_as(fp), b_first.ctypes.data_as(fp), w_blocks.ctypes.data_as(fp),
+                                   b_blocks.ctypes.data_as(fp), w_last.ctypes.data_as(fp), packed.ctypes.data_as(fp))
+        if rc != 0:
+            raise RuntimeError("fs_value_net_pack: " + lib.fs_last_error().decode())
+        params = torch.from_numpy(packed)
+        return lib, (params.to(dev) if dev.type == 'cuda' else params)
 
 
 def crop_center(img, crop):

@@ -96,6 +96,10 @@ def load_library(build_if_missing=True):
         "fs_select_action": (ci, [vp, ci, ip, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci, C.c_double,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                   C.c_double, C.POINTER(C.c_longlong), fp, vp, vp]),
+        "fs_value_net_param_floats": (C.c_size_t, []),
+        "fs_value_net_work_bytes": (C.c_size_t, [ci, ci]),
+        "fs_value_net_pack": (ci, [ci, fp, fp, fp, fp, fp, fp, fp, fp]),
+        "fs_value_net_forward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
         "fs_timer_start": (ci, [vp]),
         "fs_timer_stop": (ci, [vp, fp]),
         "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),

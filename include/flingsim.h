@@ -212,6 +212,27 @@ int fs_select_action(const float *d_values, int n_primitives, const int *primiti
                      double stretchdrag_dist, double grasp_height, long long *best_index_out, float *best_value_out,
                      void *d_work, void *stream);
 
+/* ---- value network forward ------------------------------------------------------------------
+   SpatialValueNet.forward (learning/nets.py:81-141) in eval mode for size x size = 64 x 64 observations (the
+   reference's obs_dim): normalise, Conv3x3(C->16)+BN+LeakyReLU, 8 residual blocks of two Conv3x3(16->16)+BN, Conv3x3(16->1).
+   The caller folds each BatchNorm into the preceding convolution (w' = w g / sqrt(var + eps),
+   b' = beta - running_mean g / sqrt(var + eps)) and packs the result once:
+     fs_value_net_pack   host -> host.  in_channels 1 / 3 / 4; mean, std float32[in_channels] (preprocess_obs :131-137);
+                         w_first [16][in_channels][3][3], b_first [16]; w_blocks [16 convs][16][16][3][3] in network order
+                         (block 0 conv1, block 0 conv2, block 1 conv1, ...), b_blocks [16][16]; w_last [1][16][3][3];
+                         packed float32[fs_value_net_param_floats()]
+     fs_value_net_forward  d_params: the packed block copied to the device; d_obs device float32
+                         [batch][obs_channels][64][64], of which channels channel_offset .. channel_offset+in_channels-1
+                         feed the network (rgb_only: 0..2, depth_only: 3); d_out device float32 [batch][64][64];
+                         d_work device scratch of fs_value_net_work_bytes(batch, 64) bytes; stream: hipStream_t.
+   fp32 throughout (the 16->16 convolutions on v_mfma_f32_16x16x4_f32); any other size returns FS_ERR_ARG. */
+size_t fs_value_net_param_floats(void);
+size_t fs_value_net_work_bytes(int batch, int size);
+int fs_value_net_pack(int in_channels, const float *mean, const float *std, const float *w_first, const float *b_first,
+                      const float *w_blocks, const float *b_blocks, const float *w_last, float *packed);
+int fs_value_net_forward(const float *d_params, const float *d_obs, int obs_channels, int channel_offset,
+                         int in_channels, int batch, int size, float *d_out, void *d_work, void *stream);
+
 /* ---- host-only entry points (no HIP device needed) ------------------------------------------------------------
    Scene builder exposed on its own so host logic can be checked without a GPU: same arguments as fs_set_scene. */
 typedef struct fs_host_scene fs_host_scene;

@@ -110,7 +110,13 @@ def nets_vectors():
     with torch.no_grad():
         out = pol.value_nets["fling"](obs)
         acted = pol.act([obs, obs[:2]])
+    g64 = torch.Generator().manual_seed(2)  # obs_dim-sized observations (the size the hand-written forward serves)
+    obs64 = torch.rand(2, 4, 64, 64, generator=g64)
+    obs64[:, 3] = 1.9 + 0.1 * obs64[:, 3]
+    with torch.no_grad():
+        out64 = pol.value_nets["fling"](obs64)
     arrays = {"sd::" + k: v.numpy() for k, v in sd.items()}
+    arrays.update(obs64=obs64.numpy(), out64=out64.numpy())
     arrays.update(obs=obs.numpy(), out=out.numpy(), act0=acted[0]["fling"].numpy(), act1=acted[1]["fling"].numpy(),
                   rotations=np.array(pol.rotations), num_transforms=np.array(pol.num_transforms))
     np.savez_compressed(os.path.join(HERE, "nets_golden.npz"), **arrays)
