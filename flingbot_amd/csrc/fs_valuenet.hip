@@ -13,19 +13,24 @@
 //     there and takes the identity from the input tile -- per block the activations cross HBM / L2 once in, once out;
 //   * both convolutions run on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32: M = 16 pixels of a row, N = the
 //     16 output channels -- no padding --, K = 4 input channels of one filter tap; 36 instructions per 16-pixel tile).
-//     Each lane keeps its B operands (the folded weights) for both convolutions in 72 VGPRs for the whole kernel; the A
+//     The B operands (the folded weights, 36 registers per convolution) come from LDS when a convolution starts; the A
 //     operand is one ds_read_b32 per MFMA with a compile-time offset.  Channel planes are 16 (mod 32) dwords apart, so
 //     the four 16-lane channel groups of a wavefront read disjoint banks;
 //   * bias, ReLU, the residual add and the zero padding are applied in the accumulator registers;
 //   * a wavefront works on 5 (conv1) / 4 (conv2) row tiles at once: independent accumulators cover the 40-cycle
-//     dependent-MFMA latency and share the B registers;
-//   * workgroup ids are mapped so that the 8 strips of an image run on ONE XCD (the dispatcher places workgroup n on XCD
+//     dependent-MFMA latency and share the B operand, and the A operands are read one filter tap ahead;
+//   * the kernel is persistent (one workgroup per CU -- the 101 KB tile allows one): the B operands are staged in LDS
+//     once, and the next strip's rows are requested from global memory before the current strip's convolutions start;
+//   * strip ids are mapped so that the 8 strips of an image run on ONE XCD (the dispatcher places workgroup n on XCD
 //     n % 8): neighbouring strips' halo rows are served by that XCD's L2.
+// Measured (one MI355X, scripts/cnn_timing.py, profiles/r01_cnn_*): 0.36 ms per observation of 96 x 64 x 64 against 1.49 ms
+// for the folded network on MIOpen; 2.32 ms for 8 observations = 101 TFLOP/s of useful fp32 arithmetic (64 % of the MFMA
+// fp32 peak; 12.5 % more is spent recomputing conv1 on the halo rows instead of a round trip through HBM).
 // The first (C -> 16, LeakyReLU) and last (16 -> 1) layers are 9 % and 6 % of a 16 -> 16 layer's arithmetic and run as
 // plain VALU kernels with the weights in scalar registers.
 //
 // Numerics: fp32 throughout, MFMA accumulation is an ordered fmaf chain; results differ from MIOpen's by summation order
-// only (tests/test_valuenet_gpu.py: <= 1e-5 absolute on O(1) outputs against the PyTorch fp32 module and against the
+// only (tests/test_valuenet_gpu.py: <= 2e-5 absolute on O(1) outputs against the PyTorch fp32 module and against the
 // reference's own outputs in tests/golden/nets_golden.npz).
 #include <hip/hip_runtime.h>
 
@@ -43,7 +48,8 @@ typedef float vn_f32x4 __attribute__((ext_vector_type(4)));
 #define VN_CS_IN 880         // LDS channel stride of the 12-row input tile  (12 * 72 = 864, rounded up to 16 mod 32)
 #define VN_CS_MID 720        // LDS channel stride of the 10-row conv1 output (10 * 72 = 720 = 16 mod 32)
 #define VN_THREADS 512
-#define VN_BLOCK_LDS_BYTES (16 * (VN_CS_IN + VN_CS_MID) * 4)
+#define VN_BLOCK_LDS_BYTES ((16 * (VN_CS_IN + VN_CS_MID) + 2 * 36 * 64) * 4)
+#define VN_PERSISTENT_WGS 256  // one workgroup per CU (its LDS tile allows one), multiple of 8
 
 // packed parameter block (floats)
 #define VN_OFF_MEAN 0
@@ -111,36 +117,61 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_head(const float *__restri
 // 36 k-steps (9 taps x 4 channel groups) over NT row tiles two rows apart; `a` is the lane's LDS base address.
 template <int CS, int NT>
 __device__ __forceinline__ void vn_mma(const float *a, const float (&w)[36], vn_f32x4 (&acc)[NT]) {
+    // A operands one filter tap (4 channel groups x NT tiles) ahead of the MFMAs that consume them
+    float cur[4][NT], nxt[4][NT];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            const int off = cg * 4 * CS + (tap / 3) * VN_RS + (tap % 3);
+        for (int j = 0; j < NT; ++j) cur[cg][j] = a[cg * 4 * CS + j * 2 * VN_RS];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) {
+            const int off = ((tap + 1) / 3) * VN_RS + ((tap + 1) % 3);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) nxt[cg][j] = a[off + cg * 4 * CS + j * 2 * VN_RS];
+        }
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[off + j * 2 * VN_RS], w[tap * 4 + cg], acc[j], 0, 0, 0);
-        }
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[cg][j], w[tap * 4 + cg], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cur[cg][j] = nxt[cg][j];
+    }
 }
 
-__global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restrict__ P, const float *__restrict__ in,
-                                                            int batch, float *__restrict__ out) {
-    extern __shared__ float vn_lds[];
-    float *s_in = vn_lds, *s_mid = vn_lds + 16 * VN_CS_IN;
-    int b, strip;
-    if (!vn_tile_of(blockIdx.x, batch, b, strip)) return;
-    const int t = threadIdx.x, l = t & 63, wv = t >> 6, y0 = strip * VN_ROWS;
-    const int oc = l & 15, kg = l >> 4;
-
-    // input tile: image rows y0-2 .. y0+9 of all 16 channels, zero outside the image
+// global -> register half of the input-tile load: image rows y0-2 .. y0+9 of all 16 channels, zero outside the image
+__device__ __forceinline__ void vn_fetch_tile(const float *__restrict__ in, int b, int y0, int t, float4 (&r)[6]) {
     const float *src = in + (size_t)b * 16 * VN_W * VN_W;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int idx = t + VN_THREADS * k, ch = idx / 192, rem = idx % 192, row = rem >> 4, q = rem & 15;
         const int y = y0 - 2 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)y < (unsigned)VN_W) v = *(const float4 *)(src + ((size_t)ch * VN_W + y) * VN_W + 4 * q);
-        *(float4 *)(s_in + ch * VN_CS_IN + row * VN_RS + 4 + 4 * q) = v;
+        r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)y < (unsigned)VN_W) r[k] = *(const float4 *)(src + ((size_t)ch * VN_W + y) * VN_W + 4 * q);
     }
+}
+
+// Persistent: workgroup n handles tiles n, n + gridDim.x, ... (gridDim.x is a multiple of 8, so a tile keeps its XCD).
+// The next tile's input is requested from global memory before the current tile's convolutions start and is written to
+// LDS after they end; the B operands are loaded once per workgroup.
+__global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restrict__ P, const float *__restrict__ in,
+                                                            int batch, int n_tiles, float *__restrict__ out) {
+    extern __shared__ float vn_lds[];
+    float *s_in = vn_lds, *s_mid = vn_lds + 16 * VN_CS_IN;
+    const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+    const int oc = l & 15, kg = l >> 4;
+    int tile = blockIdx.x, b, strip;
+    if (tile >= n_tiles) return;
+    bool live = vn_tile_of(tile, batch, b, strip);
+    float4 pre[6];
+    if (live) vn_fetch_tile(in, b, strip * VN_ROWS, t, pre);
+
+    // halo columns are written once; the tile loads never touch them
     if (t < 16 * 24) {
         const int ch = t / 24, rem = t % 24;
         s_in[ch * VN_CS_IN + (rem >> 1) * VN_RS + ((rem & 1) ? 68 : 3)] = 0.f;
@@ -149,50 +180,77 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restr
         const int ch = t / 20, rem = t % 20;
         s_mid[ch * VN_CS_MID + (rem >> 1) * VN_RS + ((rem & 1) ? 68 : 3)] = 0.f;
     }
-    // this lane's B operands: k-step s = tap * 4 + cg holds W[oc][4 cg + kg][tap]
-    float w1[36], w2[36];
-#pragma unroll
-    for (int s = 0; s < 36; ++s) {
-        w1[s] = P[s * 64 + l];
-        w2[s] = P[VN_CONV_STRIDE + s * 64 + l];
+    // B operands of both convolutions, staged once per workgroup: k-step s = tap * 4 + cg of lane l holds
+    // W[oc][4 cg + kg][tap]; each convolution pulls its 36 registers from here when it starts
+    float *s_w = s_mid + 16 * VN_CS_MID;
+    for (int k = t; k < 36 * 64; k += VN_THREADS) {
+        s_w[k] = P[k];
+        s_w[36 * 64 + k] = P[VN_CONV_STRIDE + k];
     }
     const float b1 = P[36 * 64 + oc], b2 = P[VN_CONV_STRIDE + 36 * 64 + oc];
-    __syncthreads();
-
     const int xt = wv & 3, rpar = wv >> 2;
     const int a_lane = rpar * VN_RS + xt * 16 + (l & 15) + 3;   // A[m = l & 15][k = l >> 4]
     const int c_lane = xt * 16 + 4 * kg + 4;                    // D[m = 4 (l >> 4) + i][n = l & 15]
-    {   // conv1 + bias + ReLU -> s_mid rows rpar, rpar+2, ..., rpar+8  (image rows y0-1+m)
-        vn_f32x4 acc[5];
+
+    for (;;) {
+        const int y0 = strip * VN_ROWS, bcur = b;
+        if (live) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc[j] = (vn_f32x4){b1, b1, b1, b1};
-        vn_mma<VN_CS_IN, 5>(s_in + kg * VN_CS_IN + a_lane, w1, acc);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int m = rpar + 2 * j, ym = y0 - 1 + m;
-            vn_f32x4 v = acc[j];
-            const bool inside = (unsigned)ym < (unsigned)VN_W;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = (inside && v[i] > 0.f) ? v[i] : 0.f;
-            *(vn_f32x4 *)(s_mid + oc * VN_CS_MID + m * VN_RS + c_lane) = v;
+            for (int k = 0; k < 6; ++k) {
+                const int idx = t + VN_THREADS * k, ch = idx / 192, rem = idx % 192, row = rem >> 4, q = rem & 15;
+                *(float4 *)(s_in + ch * VN_CS_IN + row * VN_RS + 4 + 4 * q) = pre[k];
+            }
         }
-    }
-    __syncthreads();
-    {   // conv2 + bias + identity + ReLU -> global rows y0 + rpar, +2, +4, +6
-        vn_f32x4 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = (vn_f32x4){b2, b2, b2, b2};
-        vn_mma<VN_CS_MID, 4>(s_mid + kg * VN_CS_MID + a_lane, w2, acc);
-        float *dst = out + ((size_t)b * 16 + oc) * VN_W * VN_W;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int o = rpar + 2 * j;
-            const vn_f32x4 id = *(const vn_f32x4 *)(s_in + oc * VN_CS_IN + (o + 2) * VN_RS + c_lane);
-            vn_f32x4 v = acc[j] + id;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
-            *(vn_f32x4 *)(dst + (size_t)(y0 + o) * VN_W + xt * 16 + 4 * kg) = v;
+        __syncthreads();
+        const bool cur_live = live;
+        tile += gridDim.x;
+        const bool more = tile < n_tiles;
+        if (more) {
+            live = vn_tile_of(tile, batch, b, strip);
+            if (live) vn_fetch_tile(in, b, strip * VN_ROWS, t, pre);
         }
+        if (cur_live) {
+            {   // conv1 + bias + ReLU -> s_mid rows rpar, rpar+2, ..., rpar+8  (image rows y0-1+m)
+                vn_f32x4 acc[5];
+                float w1[36];
+#pragma unroll
+                for (int s = 0; s < 36; ++s) w1[s] = s_w[s * 64 + l];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[j] = (vn_f32x4){b1, b1, b1, b1};
+                vn_mma<VN_CS_IN, 5>(s_in + kg * VN_CS_IN + a_lane, w1, acc);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int m = rpar + 2 * j, ym = y0 - 1 + m;
+                    vn_f32x4 v = acc[j];
+                    const bool inside = (unsigned)ym < (unsigned)VN_W;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = (inside && v[i] > 0.f) ? v[i] : 0.f;
+                    *(vn_f32x4 *)(s_mid + oc * VN_CS_MID + m * VN_RS + c_lane) = v;
+                }
+            }
+            __syncthreads();
+            {   // conv2 + bias + identity + ReLU -> global rows y0 + rpar, +2, +4, +6
+                vn_f32x4 acc[4];
+                float w2[36];
+#pragma unroll
+                for (int s = 0; s < 36; ++s) w2[s] = s_w[(36 + s) * 64 + l];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = (vn_f32x4){b2, b2, b2, b2};
+                vn_mma<VN_CS_MID, 4>(s_mid + kg * VN_CS_MID + a_lane, w2, acc);
+                float *dst = out + ((size_t)bcur * 16 + oc) * VN_W * VN_W;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = rpar + 2 * j;
+                    const vn_f32x4 id = *(const vn_f32x4 *)(s_in + oc * VN_CS_IN + (o + 2) * VN_RS + c_lane);
+                    vn_f32x4 v = acc[j] + id;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+                    *(vn_f32x4 *)(dst + (size_t)(y0 + o) * VN_W + xt * 16 + 4 * kg) = v;
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();  // every wave is done with s_in / s_mid before the next tile overwrites them
     }
 }
 
@@ -297,8 +355,9 @@ int fs_value_net_forward(const float *d_params, const float *d_obs, int obs_chan
         hipLaunchKernelGGL(fs_k_vn_head<4>, dim3(grid), dim3(VN_THREADS), 0, st, d_params, d_obs, obs_channels,
                            channel_offset, batch, act_a);
     for (int blk = 0; blk < 8; ++blk) {
-        hipLaunchKernelGGL(fs_k_vn_block, dim3(grid), dim3(VN_THREADS), VN_BLOCK_LDS_BYTES, st,
-                           d_params + VN_OFF_CONV + 2 * blk * VN_CONV_STRIDE, act_a, batch, act_b);
+        hipLaunchKernelGGL(fs_k_vn_block, dim3(grid < VN_PERSISTENT_WGS ? grid : VN_PERSISTENT_WGS), dim3(VN_THREADS),
+                           VN_BLOCK_LDS_BYTES, st, d_params + VN_OFF_CONV + 2 * blk * VN_CONV_STRIDE, act_a, batch, grid,
+                           act_b);
         float *tmp = act_a; act_a = act_b; act_b = tmp;
     }
     hipLaunchKernelGGL(fs_k_vn_tail, dim3(grid), dim3(VN_THREADS), 0, st, d_params, act_a, batch, d_out);

@@ -16,7 +16,7 @@ for mode in ("reference module graph ", "BN folded, channels_last", "hand-writte
         net.fold_batchnorm(hip=False)
     elif mode.startswith("hand"):
         net.fold_batchnorm(hip=True)
-    for batch in (96, 768):
+    for batch in ([int(a) for a in sys.argv[1:]] or [96, 768]):
         x = torch.rand(batch, 4, 64, 64, device=dev)
         with torch.no_grad():
             for _ in range(5):

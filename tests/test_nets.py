@@ -136,3 +136,39 @@ def test_forward_matches_reference_gpu(gpu_required):
     assert len(res) == 3 and res[0]["fling"].shape == (96, 64, 64)
     single = pol.act([big[1]])[0]["fling"]
     assert np.abs(single.numpy() - res[1]["fling"].numpy()).max() < 1e-4  # batching does not change results
+
+
+def test_value_net_pack_layout():
+    """fs_value_net_pack (host-only C-ABI entry): the packed block holds the folded weights where the kernels expect
+    them -- head [ic][tap][oc], per convolution the MFMA B operand of k-step tap*4+cg for lane l = W[l&15][4cg+(l>>4)][tap]."""
+    from flingbot_amd import nets
+
+    torch.manual_seed(7)
+    net = nets.SpatialValueNet(rgb_only=True, device="cpu").eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape) + 0.5)
+    net.fold_batchnorm(hip=True)
+    lib, packed = net._hip
+    p = packed.numpy()
+    assert p.shape == (int(lib.fs_value_net_param_floats()),) and p.shape[0] == 8 + 576 + 16 + 16 * (36 * 64 + 16) + 144
+    f = net._folded
+    assert np.allclose(p[0:3], 0.18) and np.allclose(p[4:7], 0.1) and p[3] == 0 and p[7] == 1
+    w0 = f[0].weight.numpy()
+    head = p[8:8 + 576].reshape(4, 9, 16)
+    assert np.array_equal(head[:3], w0.reshape(16, 3, 9).transpose(1, 2, 0)) and not head[3].any()
+    assert np.array_equal(p[584:600], f[0].bias.numpy())
+    convs = [c for b in list(f)[2:-1] for c in (b.c1, b.c2)]
+    lanes = np.arange(64)
+    for ci, conv in enumerate(convs):
+        blk = p[600 + ci * 2320: 600 + (ci + 1) * 2320]
+        w = conv.weight.numpy().reshape(16, 16, 9)
+        for tap in (0, 4, 8):
+            for cg in range(4):
+                assert np.array_equal(blk[(tap * 4 + cg) * 64:(tap * 4 + cg + 1) * 64], w[lanes & 15, 4 * cg + (lanes >> 4), tap])
+        assert np.array_equal(blk[2304:], conv.bias.numpy())
+    assert np.array_equal(p[600 + 16 * 2320:], f[-1].weight.numpy().ravel())
+    # CPU observations keep using the folded PyTorch modules
+    with torch.no_grad():
+        assert net(torch.rand(2, 4, 64, 64)).shape == (2, 1, 64, 64)
