@@ -100,9 +100,10 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
 extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
 extern "C" int fs_n_envs(const fs_ctx *ctx) { return ctx ? ctx->n_envs : FS_ERR_ARG; }
 extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
-    if (!ctx || solver < 0 || solver > 3) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    if (!ctx || solver < 0 || solver > 4) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
     ctx->force_generic_fused = (solver == FS_SOLVER_FUSED_GENERIC);
-    ctx->solver = solver == FS_SOLVER_FUSED_GENERIC ? FS_SOLVER_FUSED : solver;
+    ctx->force_ell_stream = (solver == FS_SOLVER_STREAM_ELL);
+    ctx->solver = solver == FS_SOLVER_FUSED_GENERIC ? FS_SOLVER_FUSED : (solver == FS_SOLVER_STREAM_ELL ? FS_SOLVER_STREAM : solver);
     return FS_OK;
 }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
@@ -165,6 +166,8 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         topo->code_w = c.take<uint32_t>(size_t(8) * n + 1);
         topo->nbr_w = c.take<uint32_t>(size_t(8) * n + 1);
         topo->restnear_w = c.take<uint32_t>(size_t(8) * n + 1);
+        topo->sdict = c.take<FsVec4>(256);
+        topo->scode = c.take<FsU32x4>(n + 1);
         topo->tris = c.take<int>(size_t(3) * s.t + 1);
         topo->vt_off = c.take<int>(n + 1);
         topo->vt_tri = c.take<int>(size_t(3) * s.t + 1);
@@ -191,6 +194,9 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         up(topo->code_w, s.code_w.data(), size_t(8) * n * 4);
         up(topo->nbr_w, s.nbr_w.data(), size_t(8) * n * 4);
     }
+    topo->sdict_size = s.sdict_size;
+    up(topo->sdict, s.sdict.data(), 1024 * 4);
+    if (s.sdict_size > 0) up(topo->scode, s.scode.data(), n * 16);
     topo->restnear_ok = s.restnear_ok;
     up(topo->restnear_w, s.restnear_w.data(), size_t(8) * n * 4);
     up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
@@ -274,6 +280,7 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     d.restnear_w = topo->restnear_w; d.restnear_ok = topo->restnear_ok;
     d.find_mode = phase_find_mode(scene.phase.data(), scene.n, topo->restnear_ok);
     d.dict_size = topo->dict_size; d.dict = topo->dict; d.code_w = topo->code_w; d.nbr_w = topo->nbr_w;
+    d.sdict = topo->sdict; d.scode = topo->scode; d.sdict_size = topo->sdict_size; d.pad1 = 0;
     d.p = scene.params;
 
     // uploads (main.cpp:1025-1085): positions, velocities (zero), phases

@@ -26,6 +26,9 @@ struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
     int dict_size = 0;
     float *dict = nullptr;
     uint32_t *code_w = nullptr, *nbr_w = nullptr, *restnear_w = nullptr;
+    int sdict_size = 0;
+    FsVec4 *sdict = nullptr;
+    FsU32x4 *scode = nullptr;
     int restnear_ok = 0;
     int *tris = nullptr;  // 3t
     int *vt_off = nullptr, *vt_tri = nullptr;  // vertex -> triangles CSR
@@ -62,6 +65,7 @@ struct fs_ctx {
     int device = 0;
     int n_envs = 0;
     int solver = 0;
+    bool force_ell_stream = false;     // FS_SOLVER_STREAM_ELL: streaming kernels with the uncompressed ELL adjacency
     bool force_generic_fused = false;  // FS_SOLVER_FUSED_GENERIC: fused kernel with the streamed ELL adjacency
     hipStream_t stream = nullptr;
     std::vector<FsEnv> envs;

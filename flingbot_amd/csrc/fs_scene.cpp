@@ -187,6 +187,36 @@ void build_compact_adjacency(FsHostScene &s) {
     s.dict_size = int(entries.size());
 }
 
+void build_stream_codes(FsHostScene &s) {
+    s.sdict_size = 0;
+    s.sdict.assign(1024, 0.0f);
+    s.scode.clear();
+    const int n = s.n;
+    if (s.max_deg > 16 || n <= 0) return;
+    struct Key { int32_t d; uint32_t l, k; };
+    std::vector<Key> entries;
+    s.scode.assign(size_t(4) * n, 0xffffffffu);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    for (int i = 0; i < n; ++i)
+        for (int a = s.adj_off[i]; a < s.adj_off[i + 1]; ++a) {
+            const Key key{s.adj_j[a] - i, bits(s.adj_len[a]), bits(s.adj_k[a])};
+            size_t c = 0;
+            for (; c < entries.size(); ++c)
+                if (entries[c].d == key.d && entries[c].l == key.l && entries[c].k == key.k) break;
+            if (c == entries.size()) {
+                if (entries.size() == 255) { s.scode.clear(); return; }  // too many distinct springs
+                entries.push_back(key);
+                memcpy(&s.sdict[4 * c], &key.d, 4);
+                s.sdict[4 * c + 1] = s.adj_len[a];
+                s.sdict[4 * c + 2] = s.adj_k[a];
+            }
+            const int slot = a - s.adj_off[i];
+            uint32_t &w = s.scode[size_t(4) * i + slot / 4];
+            w = (w & ~(0xffu << (8 * (slot % 4)))) | (uint32_t(c) << (8 * (slot % 4)));
+        }
+    s.sdict_size = int(entries.size());
+}
+
 // Rest-near sets with exactly the device's fp32 test: e = rest_i - rest_j, e.x*e.x + e.y*e.y + e.z*e.z < r*r.
 void build_restnear(FsHostScene &s) {
     const int n = s.n;
@@ -337,6 +367,7 @@ std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const 
 
     build_adjacency(s);
     build_compact_adjacency(s);
+    build_stream_codes(s);
     build_restnear(s);
     build_vertex_triangles(s);
     return "";

@@ -42,6 +42,14 @@ struct FsHostScene {
     std::vector<float> dict;        // 2 * 256: (len, k) pairs
     std::vector<uint32_t> code_w;   // [8][n]
     std::vector<uint32_t> nbr_w;    // [8][n]
+    // compact adjacency for the streaming kernels (any n): dictionary of distinct (neighbour offset j - i, rest length,
+    // stiffness) triples -- a grid cloth has < 200 of them -- and ONE byte per spring slot: 16 bytes per particle instead
+    // of 12 x (index, length, stiffness) = 144.  sdict[c] = (bits(j - i), len, k, 0); code 255 = empty slot and
+    // sdict[255] = 0 (the slot then gathers the particle itself with zero length: a no-op).  sdict_size = 0 when
+    // max_deg > 16 or there are more than 255 distinct triples (the kernels then stream the ELL arrays).
+    int sdict_size = 0;
+    std::vector<float> sdict;       // [256][4]
+    std::vector<uint32_t> scode;    // [n][4], slot s in byte s of the particle's 16
     // rest-pose neighbours for the SelfCollideFilter test (NvFlex.h:166,564-565): ids of the particles closer than the
     // interaction radius in the rest pose, 16 slots of 16 bits packed two per word, [8][n], 0xffff = empty.
     // restnear_ok = 0 when some particle has more than 16 of them or n > 65535 (the kernels then test rest positions).

@@ -193,8 +193,12 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
 }
 
 // ---- one Jacobi iteration: solveSprings + solveContacts + applyDeltas for particle i
-template <int CHUNK, bool EAGER>
-__device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip) {
+// CODED: the spring slots come from the one-byte codes + the (offset, length, stiffness) dictionary the workgroup holds
+// in LDS (fs_scene.h build_stream_codes) instead of the three ELL arrays: 16 bytes of adjacency per particle and
+// iteration instead of 144, which is what keeps the adjacency of a launch in the L2s.
+template <int CHUNK, bool EAGER, bool CODED>
+__device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip,
+                                                    const FsVec4 *sdict) {
     const FsParams &p = E.p;
     const FsVec4 *__restrict__ src = flip ? E.xb : E.xa;
     FsVec4 *__restrict__ dst = flip ? E.xa : E.xb;
@@ -203,9 +207,11 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
     // position, candidate count, the first four candidate ids -- so the kernel is three dependent round trips long
     // (addresses -> ids -> neighbour positions) instead of seven.
     FsVec4 xi = src[i];
+    FsU32x4 cw = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (CODED) cw = E.scode[i];
     FsVec4 x0i;
     int nc = 0, cj0[4] = {-1, -1, -1, -1};
-    if (EAGER) {
+    {   // both forms: the loads whose addresses depend on nothing but i go out first
         x0i = E.x0[i];
         nc = E.ncount[i];
 #pragma unroll
@@ -225,13 +231,26 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
     for (int s0 = 0; s0 < max_deg; s0 += CHUNK) {
         int jj[CHUNK];
         float ll[CHUNK], kk[CHUNK];
+        if (CODED) {
 #pragma unroll
-        for (int q = 0; q < CHUNK; ++q) {
-            const bool in = s0 + q < max_deg;
-            const unsigned at = (unsigned)(s0 + q) * un + (unsigned)i;
-            jj[q] = in ? E.ell_j[at] : -1;
-            ll[q] = in ? E.ell_len[at] : 0.0f;
-            kk[q] = in ? E.ell_k[at] : 0.0f;
+            for (int q = 0; q < CHUNK; ++q) {
+                const int s = s0 + q;
+                const unsigned word = s < 8 ? (s < 4 ? cw.x : cw.y) : (s < 12 ? cw.z : cw.w);
+                const unsigned code = s < 16 ? (word >> (8 * (s & 3))) & 255u : 255u;
+                const FsVec4 d = sdict[code];  // entry 255 is all zero: the slot gathers the particle itself, length 0
+                jj[q] = code == 255u ? -1 : i + __float_as_int(d.x);
+                ll[q] = d.y;
+                kk[q] = d.z;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CHUNK; ++q) {
+                const bool in = s0 + q < max_deg;
+                const unsigned at = (unsigned)(s0 + q) * un + (unsigned)i;
+                jj[q] = in ? E.ell_j[at] : -1;
+                ll[q] = in ? E.ell_len[at] : 0.0f;
+                kk[q] = in ? E.ell_k[at] : 0.0f;
+            }
         }
         FsVec4 xj[CHUNK];
 #pragma unroll
@@ -249,10 +268,6 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
             fs_spring_bf(a, xi.x, xi.y, xi.z, xi.w, xj[q], ll[q], kk[q]);  // a padded slot gathers the particle itself: length 0, inactive
         if (jj[CHUNK - 1] < 0) break;  // the padding (-1) is at the tail of every row
     }
-    if (!EAGER) {
-        x0i = E.x0[i];
-        nc = E.ncount[i];
-    }
     const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
     const float restd = p.solidRestDistance, restd2 = restd * restd;
     // four candidates per trip: their ids, then their positions and substep-start positions, are in flight together;
@@ -264,8 +279,13 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
 #pragma unroll
             for (int k = 0; k < 4; ++k) { cj[k] = k < nc ? cj0[k] : -1; cx[k] = cx0[k]; c0[k] = c00[k]; }
         } else {
+            if (q0 == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cj[k] = q0 + k < nc ? E.nlist[(size_t)(q0 + k) * E.n + i] : -1;
+                for (int k = 0; k < 4; ++k) cj[k] = (k < nc && cj0[k] >= 0 && cj0[k] < E.n) ? cj0[k] : -1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cj[k] = q0 + k < nc ? E.nlist[(size_t)(q0 + k) * E.n + i] : -1;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int j = cj[k] < 0 ? i : cj[k];
@@ -284,23 +304,41 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
     dst[i] = xi;
 }
 
+// The spring dictionary of the workgroup's episode -> LDS (one entry per thread; FS_TILE = 256 = dictionary size).
+template <bool CODED>
+__device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict) {
+    if (CODED) {
+        const int t = threadIdx.x;
+        sdict[t] = t < E.sdict_size ? E.sdict[t] : FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();
+    }
+}
+
 // throughput form (big launches): six springs in flight, later loads issued when needed (fewer live registers)
+template <bool CODED>
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
                                                         int sub, int flip) {
+    __shared__ FsVec4 sdict[CODED ? 256 : 1];
     const int e = ids[blockIdx.y];
     if (e < 0) return;  // retired slot
     const FsEnvDev &E = envs[e];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
-    if (i < E.n) fs_iterate_particle<FS_STREAM_CHUNK, false>(E, shapes[e], i, sub, flip);
+    if (blockIdx.x * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
+    fs_stage_sdict<CODED>(E, sdict);
+    if (i < E.n) fs_iterate_particle<FS_STREAM_CHUNK, false, CODED>(E, shapes[e], i, sub, flip, sdict);
 }
 // latency form (small launches)
+template <bool CODED>
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
                                                               int sub, int flip) {
+    __shared__ FsVec4 sdict[CODED ? 256 : 1];
     const int e = ids[blockIdx.y];
     if (e < 0) return;  // retired slot
     const FsEnvDev &E = envs[e];
     const int i = blockIdx.x * FS_TILE + threadIdx.x;
-    if (i < E.n) fs_iterate_particle<12, true>(E, shapes[e], i, sub, flip);
+    if (blockIdx.x * FS_TILE >= E.n) return;
+    fs_stage_sdict<CODED>(E, sdict);
+    if (i < E.n) fs_iterate_particle<12, true, CODED>(E, shapes[e], i, sub, flip, sdict);
 }
 
 // ---- finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping (:110)

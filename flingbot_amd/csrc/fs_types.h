@@ -31,6 +31,7 @@ struct FsParams {
 };
 
 struct FsVec4 { float x, y, z, w; };
+struct FsU32x4 { uint32_t x, y, z, w; };
 
 // Kinematic collision shapes of one episode (spheres; reference helpers.h:484 AddSphere).
 struct FsShapesDev {
@@ -74,6 +75,11 @@ struct FsEnvDev {
     const float *dict;       // [256][2]
     const uint32_t *code_w;  // [8][n]
     const uint32_t *nbr_w;   // [8][n]
+    // compact adjacency (streaming kernels): (j - i, len, k) dictionary + one byte per spring slot (fs_scene.h)
+    const FsVec4 *sdict;     // [256], x = bits(j - i)
+    const FsU32x4 *scode;    // [n]
+    int sdict_size;          // 0 = unavailable
+    int pad1;
     // rest-pose neighbour ids for the SelfCollideFilter test, packed like nbr_w but holding plain particle ids
     const uint32_t *restnear_w;  // [8][n], 0xffff = empty
     int restnear_ok;

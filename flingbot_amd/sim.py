@@ -12,6 +12,7 @@ import numpy as np
 from . import build as _build
 
 FS_SOLVER_AUTO, FS_SOLVER_STREAM, FS_SOLVER_FUSED = 0, 1, 2
+FS_SOLVER_FUSED_GENERIC, FS_SOLVER_STREAM_ELL = 3, 4  # test / comparison variants (include/flingsim.h)
 
 _lib = None
 

@@ -35,6 +35,7 @@ typedef struct fs_ctx fs_ctx;
 #define FS_SOLVER_STREAM 1  /* per-stage kernels over HBM-resident SoA state (any particle count) */
 #define FS_SOLVER_FUSED 2   /* one workgroup per episode, particle state resident in LDS for the whole step */
 #define FS_SOLVER_FUSED_GENERIC 3 /* FUSED, but spring adjacency streamed from L2 instead of register-resident */
+#define FS_SOLVER_STREAM_ELL 4    /* STREAM, but with the uncompressed (index, length, stiffness) adjacency arrays */
 
 const char *fs_last_error(void);
 int fs_version(void);

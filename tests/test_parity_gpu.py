@@ -34,7 +34,7 @@ def _assert_state_equal(hip, orc, what=""):
         f"{what}: velocities not bit-exact (max abs diff {np.abs(vh - vo).max():.3e})"
 
 
-SOLVERS = [1, 2]  # FS_SOLVER_STREAM, FS_SOLVER_FUSED
+SOLVERS = [1, 2, 4]  # FS_SOLVER_STREAM (one-byte spring codes), FS_SOLVER_FUSED, FS_SOLVER_STREAM_ELL (uncompressed adjacency)
 
 
 @pytest.mark.parametrize("dims", [(32, 32), (64, 64), (5, 3), (1, 1), (2, 1)])
