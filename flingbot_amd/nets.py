@@ -272,6 +272,7 @@ def rotation_matrices(rotations, size):
 
 
 _prep_work = {}
+_prep_mats = {}
 
 
 def prepare_image_device(img, transformations, dim: int):
@@ -285,9 +286,14 @@ def prepare_image_device(img, transformations, dim: int):
     assert img.is_cuda and img.dim() == 3 and img.shape[-1] == img.shape[-2], "expects a CUDA (C, S, S) observation"
     img = img.contiguous().float()
     ch, size = int(img.shape[0]), int(img.shape[-1])
-    rots = [float(t[0]) for t in transformations]
+    rots = tuple(float(t[0]) for t in transformations)
     scales = np.ascontiguousarray([float(t[1]) for t in transformations], np.float64)
-    mats, offs = rotation_matrices(rots, size)
+    mkey = (rots, size)
+    if mkey not in _prep_mats:  # a policy asks for the same rotations at every observation
+        if len(_prep_mats) > 16:
+            _prep_mats.clear()
+        _prep_mats[mkey] = rotation_matrices(rots, size)
+    mats, offs = _prep_mats[mkey]
     n = len(rots)
     key = (img.device.index, ch, size, n)
     nbytes = int(lib.fs_prepare_image_work_bytes(ch, size, n))
