@@ -378,32 +378,36 @@ class MaximumValuePolicy(nn.Module, Policy):
         self.action_expl_prob *= self.action_expl_decay
         self.value_expl_prob *= self.value_expl_decay
 
-    def random_value_map(self):
-        return torch.rand(len(self.rotations) * len(self.scale_factors), self.obs_dim, self.obs_dim)
+    def random_value_map(self, device=None):
+        return torch.rand(len(self.rotations) * len(self.scale_factors), self.obs_dim, self.obs_dim, device=device)
 
     def _explore(self, value_maps):
         """Value / action exploration on one environment's dict of value maps (nets.py:279-293)."""
-        value_maps = {k: (v if not self.should_explore_value() else self.random_value_map())
+        value_maps = {k: (v if not self.should_explore_value() else self.random_value_map(v.device))
                       for k, v in value_maps.items()}
         if self.should_explore_action():
             random_action, action_val_map = random.choice(list(value_maps.items()))
             min_val = action_val_map.min()
-            value_maps = {k: (v if k == random_action else torch.ones(v.size()) * min_val)
+            value_maps = {k: (v if k == random_action else torch.ones(v.size(), device=v.device) * min_val)
                           for k, v in value_maps.items()}
         return value_maps
 
     def get_action_single(self, obs):
         return self.act([obs])[0]
 
-    def act(self, obs):
+    def act(self, obs, keep_on_device=False):
         """list of [T,4,D,D] observation stacks -> list of {primitive: [T,D,D] cpu tensor}.  All environments go through
-        each value net in ONE batched forward (the reference loops per environment)."""
+        each value net in ONE batched forward (the reference loops per environment).  keep_on_device (additive): leave the
+        value maps on the policy's device for a consumer that selects the action there (action.ActionSelector)."""
         if len(obs) == 0:
             return []
         with torch.no_grad():
             sizes = [o.shape[0] for o in obs]
             batch = torch.cat([o.to(self.device, non_blocking=True) for o in obs], dim=0)
-            outs = {k: net(batch).squeeze(1).cpu().split(sizes) for k, net in self.value_nets.items()}
+            outs = {}
+            for k, net in self.value_nets.items():
+                maps = net(batch).squeeze(1)
+                outs[k] = (maps if keep_on_device else maps.cpu()).split(sizes)
             return [self._explore({k: outs[k][e] for k in outs}) for e in range(len(obs))]
 
     def steps(self):
