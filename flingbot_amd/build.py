@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libflingsim.so")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["fs_capi.hip", "fs_solver.hip", "fs_render.hip", "fs_picker.hip", "fs_loops.hip", "fs_image.hip", "fs_action.hip", "fs_valuenet.hip", "fs_hostapi.hip", "fs_scene.cpp"]
+LIB_SOURCES = ["fs_capi.hip", "fs_solver.hip", "fs_render.hip", "fs_picker.hip", "fs_loops.hip", "fs_image.hip", "fs_action.hip", "fs_valuenet.hip", "fs_observe.hip", "fs_hostapi.hip", "fs_scene.cpp"]
 HIP_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", f"--offload-arch={ARCH}", "-Wall",
              "-Wno-unused-function", "-Wno-unused-result"]
 

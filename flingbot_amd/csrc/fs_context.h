@@ -99,5 +99,6 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
 bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env);
 // renderer / coverage
 int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth);
+int fs_render_device(fs_ctx *ctx, int env, unsigned char **d_rgba_out, float **d_depth_out);
 int fs_normals_env(fs_ctx *ctx, int env, float *out4n);
 int fs_coverage_all(fs_ctx *ctx, double *out);

@@ -182,7 +182,9 @@ int fs_coverage_all(fs_ctx *ctx, double *out) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // pyflex.render -- see fs_raster_kernels.h
-int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth) {
+// Renders into the context's scratch and leaves the frame there: *d_rgba_out (uint8 RGBA, bottom-up rows) and
+// *d_depth_out (float32) stay valid until the next render on this context; the work is enqueued on ctx->stream.
+int fs_render_device(fs_ctx *ctx, int env, unsigned char **d_rgba_out, float **d_depth_out) {
     FsEnv &e = ctx->envs[env];
     const int W = e.cam.width, H = e.cam.height;
     const int n = e.host.n, T = e.host.t;
@@ -231,7 +233,19 @@ int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth) {
     hipLaunchKernelGGL(fs_k_shade, dim3((W + 15) / 16, (H + 15) / 16), dim3(16, 16), 0, st, fr, e.dev.pos, d_nrm,
                        e.topo->tris, T, d_sv, d_sn, n_sph_tris, d_z, d_shadow, d_rgba, d_depth);
     HIP_TRY(hipGetLastError());
-    const size_t px = size_t(W) * H;
+    *d_rgba_out = d_rgba;
+    *d_depth_out = d_depth;
+    return FS_OK;
+}
+
+int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth) {
+    unsigned char *d_rgba = nullptr;
+    float *d_depth = nullptr;
+    int rc = fs_render_device(ctx, env, &d_rgba, &d_depth);
+    if (rc != FS_OK) return rc;
+    const FsEnv &e = ctx->envs[env];
+    hipStream_t st = ctx->stream;
+    const size_t px = size_t(e.cam.width) * e.cam.height;
     char *stg = (char *)fs_stage(ctx, px * 8);
     if (!stg) return FS_ERR_HIP;
     HIP_TRY(hipMemcpyAsync(stg, d_rgba, px * 4, hipMemcpyDeviceToHost, st));

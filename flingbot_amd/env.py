@@ -6,11 +6,12 @@ Composition of the device-side pieces of this package, one call per stage for AL
     ActionSelector.select (fs_select_action)                  get_max_value_valid_action (simEnv.py:560-661)
     FlingPrimitives.pick_and_fling / drag / place / stretchdrag   the action handlers  (simEnv.py:283-428)
     preaction / postaction, coverage                          SimEnv.step            (simEnv.py:464-515)
-Stated deviations (the stages below depend on cv2 / skimage, absent from this image, and are therefore NOT pinned):
-  * the observation is rendered directly at image_dim x image_dim instead of 720 x 720 + cv2.resize (flex_utils.py:418-427);
-  * no adaptive scaling / HSV cloth mask (simEnv.py:699-735): the scale factors are used as given;
-  * the grasp-on-cloth flags use a Euclidean disc of conservative_grasp_radius on `depth != 2.0` instead of cv2.circle masks
-    (simEnv.py:235-255).
+The observation stage (get_image's cv2.resize of the 720 x 720 render, the HSV cloth mask, its largest connected
+component and the adaptive scale SimEnv.get_obs derives from it, simEnv.py:699-737) runs on the device in fs_observe
+(csrc/fs_observe.hip); it follows OpenCV's / skimage's documented algorithms (oracle/observe.py) -- cv2 and skimage are
+absent from this image, so that boundary is NOT pinned to the reference's own build.
+Stated deviation: the grasp-on-cloth flags use a Euclidean disc of conservative_grasp_radius on `depth != 2.0` instead of
+cv2.circle masks (simEnv.py:235-255).
 Every other stage is pinned on its own in tests/ (see DESIGN.md 4.4-4.65).
 """
 import numpy as np
@@ -23,13 +24,15 @@ from .tasks import load_tasks
 
 
 class BatchedFlingEnv:
-    def __init__(self, sim, action_primitives=("fling",), obs_dim=64, image_dim=128, num_rotations=12,
+    def __init__(self, sim, action_primitives=("fling",), obs_dim=64, image_dim=400, num_rotations=12,
                  scale_factors=(1.0, 1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75), pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5,
                  reach_distance_limit=1.2, conservative_grasp_radius=4, episode_length=10, grasp_height=0.02,
-                 fling_speed=6e-3, stretchdrag_dist=0.3, device="cuda:0"):
+                 fling_speed=6e-3, stretchdrag_dist=0.3, device="cuda:0", render_dim=720, use_adaptive_scaling=True):
         self.sim = sim
         self.actions = list(action_primitives)
         self.obs_dim, self.image_dim = int(obs_dim), int(image_dim)
+        self.render_dim = int(render_dim)  # pyflex renders 720 x 720 (get_image reshapes to it, flex_utils.py:421)
+        self.use_adaptive_scaling = bool(use_adaptive_scaling)
         if "fling" in self.actions:  # nets.py:213-218
             self.rotations = [(2 * i / (num_rotations - 1) - 1) * 90 for i in range(num_rotations)]
         else:
@@ -45,13 +48,14 @@ class BatchedFlingEnv:
         self.envs, self.prim = [], None
         self.timestep, self.terminate = {}, {}
         self.pretransform_depth = {}
+        self.adaptive_scale_factors = {}
 
     # ---- SimEnv.reset for a batch of tasks (entry e of `tasks` becomes episode e)
     def reset(self, tasks):
         self.envs = load_tasks(self.sim, tasks)
         for e in self.envs:
             cp = self.sim.get_camera_params(e)
-            self.sim.set_camera_params(e, [*cp[2:8], self.image_dim, self.image_dim])
+            self.sim.set_camera_params(e, [*cp[2:8], self.render_dim, self.render_dim])
         self.init_coverage = np.array(self.sim.coverage())
         self.prim = FlingPrimitives(self.sim, self.envs, **self._prim_kwargs)
         self.prim.setup_pickers()
@@ -60,18 +64,32 @@ class BatchedFlingEnv:
         return self.observe()
 
     def get_obs(self, e):
-        """render + flip + preprocess_obs (flex_utils.py:418-427, utils.py:579-582): float32 [4, S, S] on the device."""
-        s_ = self.image_dim
-        rgba, depth = self.sim.render(e)
-        rgb = np.flip(rgba.reshape(s_, s_, 4), 0)[:, :, :3]
-        d = np.flip(depth.reshape(s_, s_), 0).copy()
-        self.pretransform_depth[e] = d
-        return torch.cat((torch.tensor(rgb.copy()).float() / 255, torch.tensor(d).unsqueeze(2)), dim=2).permute(2, 0, 1).to(self.device)
+        """SimEnv.get_obs (simEnv.py:710-737): render, resize to image_dim, cloth mask -> adaptive scale factors,
+        preprocess_obs -- all in fs_observe; returns float32 [4, S, S] on the device."""
+        obs, bbox = self.sim.observe(e, self.image_dim)
+        self.pretransform_depth[e] = obs[3].cpu().numpy()
+        factors = self.scale_factors.copy()
+        if self.use_adaptive_scaling and bbox[4] > 0:
+            dim = self.image_dim  # dimx == dimy
+            cropx = max(dim - 2 * int(bbox[0]), dim - 2 * (dim - int(bbox[1])))
+            cropy = max(dim - 2 * int(bbox[2]), dim - 2 * (dim - int(bbox[3])))
+            crop = int(max(cropx, cropy) * 1.5)  # some breathing room
+            if crop < dim:
+                factors *= crop / dim
+        self.adaptive_scale_factors[e] = factors
+        return obs
+
+    def get_transformations(self, e):
+        return [(r, s) for r in self.rotations for s in self.adaptive_scale_factors[e]]  # product(rotations, scales)
 
     def observe(self):
         """{episode: transformed observation [T, 4, D, D] (CUDA)} for the episodes that are still running."""
-        return {e: nets.prepare_image(self.get_obs(e), self.transformations, self.obs_dim)
-                for e in self.envs if not self.terminate[e]}
+        out = {}
+        for e in self.envs:
+            if not self.terminate[e]:
+                obs = self.get_obs(e)
+                out[e] = nets.prepare_image(obs, self.get_transformations(e), self.obs_dim)
+        return out
 
     def _on_cloth(self, depth, pix):
         yy, xx = np.ogrid[:depth.shape[0], :depth.shape[1]]
@@ -90,7 +108,7 @@ class BatchedFlingEnv:
         prev = np.array(self.sim.coverage())
         chosen = {}
         for e in run:
-            action, params = self.selector.select(value_maps[e], self.scale_factors, self.pretransform_depth[e])
+            action, params = self.selector.select(value_maps[e], self.adaptive_scale_factors[e], self.pretransform_depth[e])
             if action is not None:
                 d, pix = self.pretransform_depth[e], params["pretransform_pixels"]
                 params["p1_grasp_cloth"] = self._on_cloth(d, (pix[0][1], pix[0][0]))

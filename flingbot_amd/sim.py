@@ -97,6 +97,8 @@ def load_library(build_if_missing=True):
         "fs_select_action": (ci, [vp, ci, ip, ci, ci, ci, ci, ci, C.POINTER(C.c_double), vp, ci, C.c_double,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                   C.c_double, C.POINTER(C.c_longlong), fp, vp, vp]),
+        "fs_observe_work_bytes": (C.c_size_t, [ci]),
+        "fs_observe": (ci, [vp, ci, ci, vp, vp, ip, vp]),
         "fs_value_net_param_floats": (C.c_size_t, []),
         "fs_value_net_work_bytes": (C.c_size_t, [ci, ci]),
         "fs_value_net_pack": (ci, [ci, fp, fp, fp, fp, fp, fp, fp, fp]),
@@ -394,6 +396,27 @@ class FlingSim:
         self._ck(self.lib.fs_render(self.h, env, rgba.ctypes.data_as(C.POINTER(C.c_ubyte)), rgba.size, _fp(depth),
                                     depth.size))
         return rgba, depth
+
+    def observe(self, env, image_dim, want_mask=False):
+        """get_image + get_cloth_mask + preprocess_obs on the device (fs_observe, csrc/fs_observe.hip): renders episode
+        `env` with its camera and returns (obs float32 CUDA tensor [4, S, S], bbox int[5] = x.min, x.max, y.min, y.max and
+        pixel count of the largest cloth component (-1 / 0 when there is none)[, mask uint8 CUDA tensor [S, S]])."""
+        import torch
+        s_ = int(image_dim)
+        dev = torch.device("cuda", self.device)
+        obs = torch.empty((4, s_, s_), dtype=torch.float32, device=dev)
+        mask = torch.empty((s_, s_), dtype=torch.uint8, device=dev) if want_mask else None
+        nbytes = int(self.lib.fs_observe_work_bytes(s_))
+        work = getattr(self, "_observe_work", None)
+        if work is None or work.numel() < nbytes:
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._observe_work = work
+        torch.cuda.current_stream(dev).synchronize()  # the buffers above may still be in use on torch's stream
+        bbox = np.zeros(5, np.int32)
+        self._ck(self.lib.fs_observe(self.h, int(env), s_, C.c_void_p(obs.data_ptr()),
+                                     C.c_void_p(mask.data_ptr()) if want_mask else None, _ip(bbox),
+                                     C.c_void_p(work.data_ptr())))
+        return (obs, bbox, mask) if want_mask else (obs, bbox)
 
     def get_last_neighbors(self, env=0):
         n = self.n_particles(env)

@@ -213,6 +213,23 @@ int fs_select_action(const float *d_values, int n_primitives, const int *primiti
                      double stretchdrag_dist, double grasp_height, long long *best_index_out, float *best_value_out,
                      void *d_work, void *stream);
 
+/* ---- observation stage on the device ---------------------------------------------------------
+   Everything the reference does on the host between pyflex.render() and prepare_image, without downloading the frame:
+   get_image (environment/flex_utils.py:418-427: flip rows, drop alpha, cv2.resize INTER_LINEAR to image_dim),
+   SimEnv.get_cloth_mask (environment/simEnv.py:699-708: RGB2HSV, inRange((0,0,0),(100,100,100)) == 0, largest connected
+   component, environment/utils.py:585-601), the bounding box SimEnv.get_obs derives its adaptive scale from
+   (simEnv.py:717-731) and preprocess_obs (environment/utils.py:579-582).
+     d_obs   device float32 [4][image_dim][image_dim]: rgb / 255 and depth, rows top-down
+     d_mask  device uint8 [image_dim][image_dim] (1 = pixel of the largest cloth component) or NULL
+     bbox    host int[5]: x.min, x.max, y.min, y.max of np.where(mask) (x = row) and the component's pixel count; -1 / 0
+             when no pixel passes the colour test (the reference's get_obs then leaves the scale factors alone)
+     d_work  device scratch of fs_observe_work_bytes(image_dim) bytes
+   Renders with the episode's camera (fs_set_camera_params), runs on the context's stream and returns when the results are
+   complete.  cv2 / skimage conventions are restated in oracle/observe.py (parity with the reference's own cv2 build is
+   unpinned: cv2 is absent from the build image). */
+size_t fs_observe_work_bytes(int image_dim);
+int fs_observe(fs_ctx *ctx, int env, int image_dim, float *d_obs, unsigned char *d_mask, int *bbox, void *d_work);
+
 /* ---- value network forward ------------------------------------------------------------------
    SpatialValueNet.forward (learning/nets.py:81-141) in eval mode for size x size = 64 x 64 observations (the
    reference's obs_dim): normalise, Conv3x3(C->16)+BN+LeakyReLU, 8 residual blocks of two Conv3x3(16->16)+BN, Conv3x3(16->1).

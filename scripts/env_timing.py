@@ -17,7 +17,7 @@ tasks = ftasks.generate_tasks(gen, [ftasks.draw_task_parameters() for _ in range
 gen.close()
 t_gen = time.perf_counter() - t0
 ctx = fsim.FlingSim(n_envs=E, solver=0)
-env = BatchedFlingEnv(ctx, image_dim=128, episode_length=n_steps)
+env = BatchedFlingEnv(ctx, image_dim=int(sys.argv[2]) if len(sys.argv) > 2 else 400, episode_length=n_steps)
 t0 = time.perf_counter(); obs = env.reset(tasks); torch.cuda.synchronize(); t_reset = time.perf_counter() - t0
 net = nets.SpatialValueNet(rgb_only=True, device=env.device).to(env.device).eval().fold_batchnorm()
 cov0 = np.array(ctx.coverage())

@@ -11,12 +11,13 @@ from flingbot_amd.evaluate import run_episodes
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+image_dim = int(sys.argv[3]) if len(sys.argv) > 3 else 400   # the 720 x 720 render is resized to this (reference: image_dim)
 random.seed(0); np.random.seed(0); torch.manual_seed(0)
 gen = fsim.FlingSim(n_envs=E, solver=0)
 tasks = ftasks.generate_tasks(gen, [ftasks.draw_task_parameters() for _ in range(E)])
 gen.close()
 ctx = fsim.FlingSim(n_envs=E, solver=0)
-env = BatchedFlingEnv(ctx, image_dim=128, episode_length=steps)
+env = BatchedFlingEnv(ctx, image_dim=image_dim, episode_length=steps)
 policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
                                  obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
                                  depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
