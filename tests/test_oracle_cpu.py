@@ -463,3 +463,46 @@ def test_task_generator_host_logic_reproduces_reference_golden():
     from fling_helpers import OracleTaskSim, check_tasks_against_golden
 
     check_tasks_against_golden(lambda n: OracleTaskSim(n))
+
+
+def test_observe_oracle_known_answers():
+    """oracle/observe.py (cv2 / skimage conventions restated; unpinned against the reference's own cv2 build): colour
+    conversion against the analytic HSV of exactly representable colours, resize invariants, component selection."""
+    import colorsys
+    from oracle import observe as oo
+
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [100, 100, 100], [255, 255, 255], [0, 0, 0], [200, 100, 50],
+                    [10, 200, 190], [101, 100, 100], [100, 100, 101]]], np.uint8)
+    hsv = oo.rgb2hsv_u8(px)[0].astype(int)
+    for p, (h, s, v) in zip(px[0], hsv):
+        eh, es, ev = colorsys.rgb_to_hsv(*(p / 255.0))
+        assert abs(h - eh * 180) <= 0.51 and abs(s - es * 255) <= 0.51 and v == round(ev * 255), (p, h, s, v)
+    # cloth test: dark / grey pixels (all of H, S, V <= 100) are background, anything brighter or more saturated is cloth
+    assert oo.cloth_mask_raw(px)[0].tolist() == [1, 1, 1, 0, 1, 0, 1, 1, 1, 1]
+    # bilinear resize: constants stay constant, identity size is a copy, a horizontal ramp stays monotone, range preserved
+    assert np.unique(oo.resize_linear_u8(np.full((72, 72, 3), 137, np.uint8), 40)).tolist() == [137]
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (72, 72, 3)).astype(np.uint8)
+    assert np.array_equal(oo.resize_linear_u8(img, 72), img)
+    ramp = np.repeat(np.arange(72, dtype=np.uint8)[None, :, None] * 3, 72, 0).repeat(3, 2)
+    out = oo.resize_linear_u8(ramp, 40)
+    assert (np.diff(out[:, :, 0].astype(int), axis=1) >= 0).all() and out.min() >= 0 and out.max() <= 213
+    d = rng.rand(72, 72).astype(np.float32)
+    r = oo.resize_linear_f32(d, 40)
+    assert r.dtype == np.float32 and r.min() >= d.min() and r.max() <= d.max()
+    assert np.allclose(oo.resize_linear_f32(np.full((72, 72), 2.0, np.float32), 40), 2.0)
+    # taps of cv::resize: destination 0 of a 720 -> 400 resize samples source 0.4 -> index 0, fraction 0.4
+    s_, f_ = oo._linear_taps(400, 720)
+    assert s_[0] == 0 and abs(f_[0] - 0.4) < 1e-6 and s_[-1] == 718 and abs(f_[-1] - 0.6) < 1e-4  # float32 (718.6 - 718)
+    # largest component: 8-connectivity, ties go to the component met first in raster order, empty mask -> None
+    m = np.zeros((10, 10), np.uint8)
+    m[1:3, 1:3] = 1; m[3, 3] = 1            # 5 pixels, diagonal contact counts
+    m[6:8, 6:8] = 1; m[8, 5] = 1            # 5 pixels as well
+    big = oo.largest_component(m)
+    assert big.sum() == 5 and big[1, 1] == 1 and big[6, 6] == 0
+    m[8, 8] = 1                              # second blob now has 6
+    assert oo.largest_component(m)[6, 6] == 1
+    assert oo.largest_component(np.zeros((4, 4), np.uint8)) is None and oo.adaptive_crop(None) is None
+    # SimEnv.get_obs crop: a centred 10 x 10 blob in a 100 x 100 image -> max(100 - 2 * 45, 100 - 2 * (100 - 54)) * 1.5
+    c = np.zeros((100, 100), np.uint8); c[45:55, 45:55] = 1
+    assert oo.adaptive_crop(c) == int(max(100 - 2 * 45, 100 - 2 * (100 - 54)) * 1.5) == 15
