@@ -10,8 +10,8 @@ The observation stage (get_image's cv2.resize of the 720 x 720 render, the HSV c
 component and the adaptive scale SimEnv.get_obs derives from it, simEnv.py:699-737) runs on the device in fs_observe
 (csrc/fs_observe.hip); it follows OpenCV's / skimage's documented algorithms (oracle/observe.py) -- cv2 and skimage are
 absent from this image, so that boundary is NOT pinned to the reference's own build.
-Stated deviation: the grasp-on-cloth flags use a Euclidean disc of conservative_grasp_radius on `depth != 2.0` instead of
-cv2.circle masks (simEnv.py:235-255).
+The grasp-on-cloth flags (simEnv.py:235-255) test `depth != 2.0` on a Euclidean disc of conservative_grasp_radius, which
+is pixel for pixel the filled cv2.circle (OpenCV's midpoint fill) for radii up to 6; the reference's default is 1.
 Every other stage is pinned on its own in tests/ (see DESIGN.md 4.4-4.65).
 """
 import numpy as np
@@ -26,7 +26,7 @@ from .tasks import load_tasks
 class BatchedFlingEnv:
     def __init__(self, sim, action_primitives=("fling",), obs_dim=64, image_dim=400, num_rotations=12,
                  scale_factors=(1.0, 1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75), pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5,
-                 reach_distance_limit=1.2, conservative_grasp_radius=4, episode_length=10, grasp_height=0.02,
+                 reach_distance_limit=1.2, conservative_grasp_radius=1, episode_length=10, grasp_height=0.02,
                  fling_speed=6e-3, stretchdrag_dist=0.3, device="cuda:0", render_dim=720, use_adaptive_scaling=True):
         self.sim = sim
         self.actions = list(action_primitives)
