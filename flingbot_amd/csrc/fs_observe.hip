@@ -137,9 +137,17 @@ __global__ __launch_bounds__(256) void fs_k_obs_ccl(int S, int *label, FsObsResu
 
 __global__ __launch_bounds__(256) void fs_k_obs_count(int S, const int *__restrict__ label, int *count) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= S * S) return;
-    const int l = label[idx];
-    if (l >= 0) atomicAdd(&count[l], 1);
+    const int l = idx < S * S ? label[idx] : -1;
+    // a wavefront's pixels mostly share one root: one atomic per distinct root and wavefront instead of one per pixel
+    bool todo = l >= 0;
+    while (__any(todo)) {
+        const unsigned long long live = __ballot(todo);
+        const int leader = __ffsll((long long)live) - 1;
+        const int root = __shfl(l, leader);
+        const unsigned long long same = __ballot(todo && l == root);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&count[root], __popcll(same));
+        if (l == root) todo = false;
+    }
 }
 
 __global__ __launch_bounds__(256) void fs_k_obs_best(int S, const int *__restrict__ count, FsObsResult *res) {
