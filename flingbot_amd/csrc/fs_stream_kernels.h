@@ -154,15 +154,25 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
         qn = 0;
     };
 
-    for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int b0 = fs_stream_bucket(cx - 1, cy + dy, cz + dz);
+    // the bounds of all nine runs are requested together: nine dependent round trips (bounds -> positions, run after run)
+    // become one
+    int run_b0[9], run_beg[9], run_end[9];
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+        const int b0 = fs_stream_bucket(cx - 1, cy + (r9 % 3 - 1), cz + (r9 / 3 - 1));
+        run_b0[r9] = b0;
+        run_beg[r9] = (b0 == 0) ? 0 : fill[b0 - 1];
+        run_end[r9] = fill[b0 + 2 - (FS_GRID_BUCKETS - 1) > 0 ? FS_GRID_BUCKETS - 1 : b0 + 2];
+    }
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+            const int b0 = run_b0[r9];
             const int wrap = b0 + 2 - (FS_GRID_BUCKETS - 1);  // > 0: that many buckets continue at bucket 0
             for (int seg = 0; seg < 2; ++seg) {
                 int beg, end;
                 if (seg == 0) {
-                    beg = (b0 == 0) ? 0 : fill[b0 - 1];
-                    end = fill[wrap > 0 ? FS_GRID_BUCKETS - 1 : b0 + 2];
+                    beg = run_beg[r9];
+                    end = run_end[r9];
                 } else {
                     if (wrap <= 0) break;
                     beg = 0;
