@@ -579,6 +579,34 @@ def task_vectors():
     from environment import flex_utils as ref_fu
 
     out = {}
+    # load_cloth (environment/tasks.py:39-103) on a small synthetic quad mesh (ours: a 6 x 5 vertex sheet with a notch cut
+    # out, OBJ faces in v/vt form, shuffled face order): vertices, triangles, stretch / bend / shear edge lists in the
+    # reference's own order (the order of its Python sets), which fixes the spring ids the solver accumulates in.
+    rng = np.random.RandomState(4)
+    nx, ny = 6, 5
+    lines = ["# synthetic quad mesh for tests/golden (not reference data)"]
+    for j in range(ny):
+        for i in range(nx):
+            lines.append("v %.6f %.6f %.6f" % (0.02 * i, 0.003 * ((i * 7 + j * 3) % 5), 0.025 * j))
+    for j in range(ny):
+        for i in range(nx):
+            lines.append("vt %.4f %.4f" % (i / (nx - 1), j / (ny - 1)))
+    quads = [(i, j) for j in range(ny - 1) for i in range(nx - 1) if not (i >= 3 and j >= 2)]
+    for q in rng.permutation(len(quads)):
+        i, j = quads[q]
+        ids = [j * nx + i + 1, j * nx + i + 2, (j + 1) * nx + i + 2, (j + 1) * nx + i + 1]
+        lines.append("f " + " ".join("%d/%d" % (v, v) for v in ids))
+    obj_text = "\n".join(lines) + "\n"
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix="_processed.obj", delete=False) as fh:
+        fh.write(obj_text)
+        obj_path = fh.name
+    verts, tri_faces, stretch, bend, shear = ref_tasks.load_cloth(obj_path)
+    os.unlink(obj_path)
+    out["obj_text"] = np.array(obj_text)
+    out["obj_vertices"], out["obj_faces"] = np.asarray(verts), np.asarray(tri_faces)
+    out["obj_stretch"], out["obj_bend"], out["obj_shear"] = np.asarray(stretch), np.asarray(bend), np.asarray(shear)
+    print("load_cloth:", verts.shape, tri_faces.shape, stretch.shape, bend.shape, shear.shape)
     for ci, (seed, difficulty) in enumerate(((3, "hard"), (11, "hard"), (5, "easy"))):
         random.seed(seed)
         np.random.seed(seed)
