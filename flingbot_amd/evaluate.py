@@ -54,3 +54,20 @@ def run_episodes(policy, env, tasks, max_steps=None, fold=True):
                  "best_coverage": float(trace.max(axis=0).mean()), "episode_delta_coverage": float((final - init).mean()),
                  "episode_length": float(lengths.mean())},
     }
+
+
+def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=run_episodes, **kwargs):
+    """BASELINE.json configs[3] for the evaluation loop: global episode g runs on rank g // episodes_per_rank (one process
+    per GPU, launched with torch.distributed.run); the only exchange is the all_gather of the per-episode initial / final
+    coverages at the end (RCCL over xGMI, 4 bytes per episode).  Returns this rank's statistics plus `all_init_coverage`
+    / `all_final_coverage` ordered by global episode id."""
+    from . import distributed as fdist
+
+    rank, _, world = fdist.init_from_env()
+    mine = [tasks[g] for g in fdist.episode_range(rank, episodes_per_rank)]
+    stats = runner(policy, env, mine, **kwargs)
+    device = getattr(env, "device", None) if torch.cuda.is_available() else None
+    stats["all_init_coverage"] = fdist.gather_rewards(stats["init_coverage"], device=device).cpu().numpy()
+    stats["all_final_coverage"] = fdist.gather_rewards(stats["final_coverage"], device=device).cpu().numpy()
+    stats["rank"], stats["world"] = rank, world
+    return stats

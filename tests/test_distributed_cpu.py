@@ -80,3 +80,50 @@ def test_single_rank_helpers_need_no_process_group():
     assert fdist.gather_rewards([1.0, 2.0]).tolist() == [1.0, 2.0]
     assert fdist.max_over_ranks(0.25) == 0.25
     fdist.barrier()
+
+
+SHARDED_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["FS_ROOT"])
+import torch
+from flingbot_amd import distributed as fdist
+from flingbot_amd.evaluate import run_episodes_sharded
+
+def fake_runner(policy, env, tasks):           # stands in for the GPU loop: coverage derived from the task itself
+    init = np.array([t["seed"] * 0.01 for t in tasks])
+    return {"init_coverage": init, "final_coverage": init + 0.5, "n": len(tasks)}
+
+tasks = [{"seed": g} for g in range(8)]
+stats = run_episodes_sharded(None, None, tasks, episodes_per_rank=4, runner=fake_runner)
+print(json.dumps({"rank": stats["rank"], "world": stats["world"], "n": stats["n"], "mine": stats["init_coverage"].tolist(),
+                  "all_init": stats["all_init_coverage"].tolist(), "all_final": stats["all_final_coverage"].tolist()}))
+fdist.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_sharded_evaluation_gathers_by_global_episode(tmp_path):
+    """evaluate.run_episodes_sharded on two gloo ranks: each rank runs only its own tasks, every rank ends with the
+    coverages of all episodes in global order."""
+    import json
+
+    script = tmp_path / "sharded.py"
+    script.write_text(SHARDED_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FS_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert np.allclose(outs[0]["mine"], [0.0, 0.01, 0.02, 0.03]) and np.allclose(outs[1]["mine"], [0.04, 0.05, 0.06, 0.07])
+    for o in outs:
+        assert o["world"] == 2 and o["n"] == 4
+        assert np.allclose(o["all_init"], np.arange(8) * 0.01) and np.allclose(o["all_final"], np.arange(8) * 0.01 + 0.5)
