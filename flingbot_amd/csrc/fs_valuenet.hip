@@ -334,14 +334,16 @@ int fs_value_net_forward(const float *d_params, const float *d_obs, int obs_chan
         return FS_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the device's copy of the kernel
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         if (hipFuncSetAttribute((const void *)fs_k_vn_block, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 VN_BLOCK_LDS_BYTES) != hipSuccess) {
             fs_set_error("fs_value_net_forward: cannot reserve LDS for fs_k_vn_block");
             return FS_ERR_HIP;
         }
-        attr_set = true;
+        attr_set[dev] = true;
     }
     float *act_a = (float *)d_work, *act_b = act_a + (size_t)batch * 16 * size * size;
     const int grid = ((batch + 7) / 8) * 64;
