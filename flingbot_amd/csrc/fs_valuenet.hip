@@ -43,13 +43,34 @@
 typedef float vn_f32x4 __attribute__((ext_vector_type(4)));
 
 #define VN_W 64              // image width the kernels are built for (the reference's obs_dim)
-#define VN_ROWS 8            // output rows per workgroup
+#define VN_HT_ROWS 8         // output rows per workgroup of the first / last layer kernels
+#ifndef VN_ROWS
+#define VN_ROWS 8            // output rows per strip of the residual-block kernel (8: one workgroup per CU; 4: two)
+#endif
+#define VN_THREADS 512
+#if VN_ROWS == 8
 #define VN_RS 72             // LDS row stride in floats: image column x lives at x + 4 (16-byte aligned), halos at 3 and 68
 #define VN_CS_IN 880         // LDS channel stride of the 12-row input tile  (12 * 72 = 864, rounded up to 16 mod 32)
 #define VN_CS_MID 720        // LDS channel stride of the 10-row conv1 output (10 * 72 = 720 = 16 mod 32)
-#define VN_THREADS 512
-#define VN_BLOCK_LDS_BYTES ((16 * (VN_CS_IN + VN_CS_MID) + 2 * 36 * 64) * 4)
+#define VN_NT1 5             // row tiles per wavefront: conv1 (10 rows over two wavefront rows)
+#define VN_NT2 4             //                          conv2 (8 rows)
 #define VN_PERSISTENT_WGS 256  // one workgroup per CU (its LDS tile allows one), multiple of 8
+#define VN_WAVES_PER_EU 2
+#elif VN_ROWS == 4
+#define VN_RS 68             // right halo (column 68) of a row aliases the unused column 0 of the next row
+#define VN_CS_IN 560         // 8 rows  * 68 = 544 -> 16 mod 32
+#define VN_CS_MID 432        // 6 rows  * 68 = 408 -> 16 mod 32
+#define VN_NT1 3
+#define VN_NT2 2
+#define VN_PERSISTENT_WGS 512  // two workgroups per CU: 2 x 81920 B of LDS = all 160 KiB
+#define VN_WAVES_PER_EU 4
+#else
+#error "VN_ROWS must be 8 or 4"
+#endif
+#define VN_IN_ROWS (VN_ROWS + 4)
+#define VN_MID_ROWS (VN_ROWS + 2)
+#define VN_STRIPS (VN_W / VN_ROWS)
+#define VN_BLOCK_LDS_BYTES ((16 * (VN_CS_IN + VN_CS_MID) + 2 * 36 * 64) * 4)
 
 // packed parameter block (floats)
 #define VN_OFF_MEAN 0
@@ -62,10 +83,11 @@ typedef float vn_f32x4 __attribute__((ext_vector_type(4)));
 #define VN_PARAM_FLOATS (VN_OFF_TAILW + 144)
 
 // workgroup id -> (image, strip) with all strips of an image on one XCD
+template <int STRIPS = 8>
 __device__ __forceinline__ bool vn_tile_of(int n, int batch, int &image, int &strip) {
     const int xcd = n & 7, k = n >> 3;
-    image = (k >> 3) * 8 + xcd;
-    strip = k & 7;
+    image = (k / STRIPS) * 8 + xcd;
+    strip = k % STRIPS;
     return image < batch;
 }
 
@@ -74,10 +96,10 @@ template <int C>
 __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_head(const float *__restrict__ P, const float *__restrict__ obs,
                                                            int obs_channels, int c_off, int batch,
                                                            float *__restrict__ out) {
-    __shared__ float tile[C][10][VN_RS];
+    __shared__ float tile[C][10][72];
     int b, strip;
     if (!vn_tile_of(blockIdx.x, batch, b, strip)) return;
-    const int t = threadIdx.x, y0 = strip * VN_ROWS;
+    const int t = threadIdx.x, y0 = strip * VN_HT_ROWS;
     for (int idx = t; idx < C * 160; idx += VN_THREADS) {
         const int c = idx / 160, rem = idx % 160, r = rem >> 4, q = rem & 15, y = y0 - 1 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -116,8 +138,9 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_head(const float *__restri
 // ---- one residual block --------------------------------------------------------------------------------------------
 // 36 k-steps (9 taps x 4 channel groups) over NT row tiles two rows apart; `a` is the lane's LDS base address.
 template <int CS, int NT>
-__device__ __forceinline__ void vn_mma(const float *a, const float (&w)[36], vn_f32x4 (&acc)[NT]) {
-    // A operands one filter tap (4 channel groups x NT tiles) ahead of the MFMAs that consume them
+__device__ __forceinline__ void vn_mma(const float *a, const float *w, vn_f32x4 (&acc)[NT]) {
+    // A operands one filter tap (4 channel groups x NT tiles) ahead of the MFMAs that consume them; the B operands of a
+    // tap (w = this lane's column of the staged weights, 64 floats per k-step) are read from LDS with that tap
     float cur[4][NT], nxt[4][NT];
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg)
@@ -125,6 +148,9 @@ __device__ __forceinline__ void vn_mma(const float *a, const float (&w)[36], vn_
         for (int j = 0; j < NT; ++j) cur[cg][j] = a[cg * 4 * CS + j * 2 * VN_RS];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+        float wt[4];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) wt[cg] = w[(tap * 4 + cg) * 64];
         if (tap < 8) {
             const int off = ((tap + 1) / 3) * VN_RS + ((tap + 1) % 3);
 #pragma unroll
@@ -136,7 +162,7 @@ __device__ __forceinline__ void vn_mma(const float *a, const float (&w)[36], vn_
         for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[cg][j], w[tap * 4 + cg], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[cg][j], wt[cg], acc[j], 0, 0, 0);
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg)
 #pragma unroll
@@ -145,11 +171,12 @@ __device__ __forceinline__ void vn_mma(const float *a, const float (&w)[36], vn_
 }
 
 // global -> register half of the input-tile load: image rows y0-2 .. y0+9 of all 16 channels, zero outside the image
-__device__ __forceinline__ void vn_fetch_tile(const float *__restrict__ in, int b, int y0, int t, float4 (&r)[6]) {
+#define VN_FETCH (16 * VN_IN_ROWS * 16 / VN_THREADS)  // float4 per thread of one input tile
+__device__ __forceinline__ void vn_fetch_tile(const float *__restrict__ in, int b, int y0, int t, float4 (&r)[VN_FETCH]) {
     const float *src = in + (size_t)b * 16 * VN_W * VN_W;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int idx = t + VN_THREADS * k, ch = idx / 192, rem = idx % 192, row = rem >> 4, q = rem & 15;
+    for (int k = 0; k < VN_FETCH; ++k) {
+        const int idx = t + VN_THREADS * k, ch = idx / (VN_IN_ROWS * 16), rem = idx % (VN_IN_ROWS * 16), row = rem >> 4, q = rem & 15;
         const int y = y0 - 2 + row;
         r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((unsigned)y < (unsigned)VN_W) r[k] = *(const float4 *)(src + ((size_t)ch * VN_W + y) * VN_W + 4 * q);
@@ -159,7 +186,7 @@ __device__ __forceinline__ void vn_fetch_tile(const float *__restrict__ in, int 
 // Persistent: workgroup n handles tiles n, n + gridDim.x, ... (gridDim.x is a multiple of 8, so a tile keeps its XCD).
 // The next tile's input is requested from global memory before the current tile's convolutions start and is written to
 // LDS after they end; the B operands are loaded once per workgroup.
-__global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restrict__ P, const float *__restrict__ in,
+__global__ __launch_bounds__(VN_THREADS, VN_WAVES_PER_EU) void fs_k_vn_block(const float *__restrict__ P, const float *__restrict__ in,
                                                             int batch, int n_tiles, float *__restrict__ out) {
     extern __shared__ float vn_lds[];
     float *s_in = vn_lds, *s_mid = vn_lds + 16 * VN_CS_IN;
@@ -167,17 +194,17 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restr
     const int oc = l & 15, kg = l >> 4;
     int tile = blockIdx.x, b, strip;
     if (tile >= n_tiles) return;
-    bool live = vn_tile_of(tile, batch, b, strip);
-    float4 pre[6];
+    bool live = vn_tile_of<VN_STRIPS>(tile, batch, b, strip);
+    float4 pre[VN_FETCH];
     if (live) vn_fetch_tile(in, b, strip * VN_ROWS, t, pre);
 
     // halo columns are written once; the tile loads never touch them
-    if (t < 16 * 24) {
-        const int ch = t / 24, rem = t % 24;
+    if (t < 16 * 2 * VN_IN_ROWS) {
+        const int ch = t / (2 * VN_IN_ROWS), rem = t % (2 * VN_IN_ROWS);
         s_in[ch * VN_CS_IN + (rem >> 1) * VN_RS + ((rem & 1) ? 68 : 3)] = 0.f;
     }
-    if (t < 16 * 20) {
-        const int ch = t / 20, rem = t % 20;
+    if (t < 16 * 2 * VN_MID_ROWS) {
+        const int ch = t / (2 * VN_MID_ROWS), rem = t % (2 * VN_MID_ROWS);
         s_mid[ch * VN_CS_MID + (rem >> 1) * VN_RS + ((rem & 1) ? 68 : 3)] = 0.f;
     }
     // B operands of both convolutions, staged once per workgroup: k-step s = tap * 4 + cg of lane l holds
@@ -196,8 +223,8 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restr
         const int y0 = strip * VN_ROWS, bcur = b;
         if (live) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int idx = t + VN_THREADS * k, ch = idx / 192, rem = idx % 192, row = rem >> 4, q = rem & 15;
+            for (int k = 0; k < VN_FETCH; ++k) {
+                const int idx = t + VN_THREADS * k, ch = idx / (VN_IN_ROWS * 16), rem = idx % (VN_IN_ROWS * 16), row = rem >> 4, q = rem & 15;
                 *(float4 *)(s_in + ch * VN_CS_IN + row * VN_RS + 4 + 4 * q) = pre[k];
             }
         }
@@ -206,20 +233,17 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restr
         tile += gridDim.x;
         const bool more = tile < n_tiles;
         if (more) {
-            live = vn_tile_of(tile, batch, b, strip);
+            live = vn_tile_of<VN_STRIPS>(tile, batch, b, strip);
             if (live) vn_fetch_tile(in, b, strip * VN_ROWS, t, pre);
         }
         if (cur_live) {
             {   // conv1 + bias + ReLU -> s_mid rows rpar, rpar+2, ..., rpar+8  (image rows y0-1+m)
-                vn_f32x4 acc[5];
-                float w1[36];
+                vn_f32x4 acc[VN_NT1];
 #pragma unroll
-                for (int s = 0; s < 36; ++s) w1[s] = s_w[s * 64 + l];
+                for (int j = 0; j < VN_NT1; ++j) acc[j] = (vn_f32x4){b1, b1, b1, b1};
+                vn_mma<VN_CS_IN, VN_NT1>(s_in + kg * VN_CS_IN + a_lane, s_w + l, acc);
 #pragma unroll
-                for (int j = 0; j < 5; ++j) acc[j] = (vn_f32x4){b1, b1, b1, b1};
-                vn_mma<VN_CS_IN, 5>(s_in + kg * VN_CS_IN + a_lane, w1, acc);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
+                for (int j = 0; j < VN_NT1; ++j) {
                     const int m = rpar + 2 * j, ym = y0 - 1 + m;
                     vn_f32x4 v = acc[j];
                     const bool inside = (unsigned)ym < (unsigned)VN_W;
@@ -230,16 +254,13 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restr
             }
             __syncthreads();
             {   // conv2 + bias + identity + ReLU -> global rows y0 + rpar, +2, +4, +6
-                vn_f32x4 acc[4];
-                float w2[36];
+                vn_f32x4 acc[VN_NT2];
 #pragma unroll
-                for (int s = 0; s < 36; ++s) w2[s] = s_w[(36 + s) * 64 + l];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = (vn_f32x4){b2, b2, b2, b2};
-                vn_mma<VN_CS_MID, 4>(s_mid + kg * VN_CS_MID + a_lane, w2, acc);
+                for (int j = 0; j < VN_NT2; ++j) acc[j] = (vn_f32x4){b2, b2, b2, b2};
+                vn_mma<VN_CS_MID, VN_NT2>(s_mid + kg * VN_CS_MID + a_lane, s_w + 36 * 64 + l, acc);
                 float *dst = out + ((size_t)bcur * 16 + oc) * VN_W * VN_W;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < VN_NT2; ++j) {
                     const int o = rpar + 2 * j;
                     const vn_f32x4 id = *(const vn_f32x4 *)(s_in + oc * VN_CS_IN + (o + 2) * VN_RS + c_lane);
                     vn_f32x4 v = acc[j] + id;
@@ -257,10 +278,10 @@ __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_block(const float *__restr
 // ---- last layer: Conv3x3(16 -> 1), no bias, no activation -----------------------------------------------------------
 __global__ __launch_bounds__(VN_THREADS) void fs_k_vn_tail(const float *__restrict__ P, const float *__restrict__ in,
                                                            int batch, float *__restrict__ out) {
-    __shared__ float tile[16][10][VN_RS];
+    __shared__ float tile[16][10][72];
     int b, strip;
     if (!vn_tile_of(blockIdx.x, batch, b, strip)) return;
-    const int t = threadIdx.x, y0 = strip * VN_ROWS;
+    const int t = threadIdx.x, y0 = strip * VN_HT_ROWS;
     const float *src = in + (size_t)b * 16 * VN_W * VN_W;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -346,7 +367,8 @@ int fs_value_net_forward(const float *d_params, const float *d_obs, int obs_chan
         attr_set[dev] = true;
     }
     float *act_a = (float *)d_work, *act_b = act_a + (size_t)batch * 16 * size * size;
-    const int grid = ((batch + 7) / 8) * 64;
+    const int grid = ((batch + 7) / 8) * 64;                 // first / last layer: 8 strips of 8 rows per image
+    const int tiles = ((batch + 7) / 8) * 8 * VN_STRIPS;     // residual blocks: VN_STRIPS strips per image
     if (in_channels == 1)
         hipLaunchKernelGGL(fs_k_vn_head<1>, dim3(grid), dim3(VN_THREADS), 0, st, d_params, d_obs, obs_channels,
                            channel_offset, batch, act_a);
@@ -357,8 +379,8 @@ int fs_value_net_forward(const float *d_params, const float *d_obs, int obs_chan
         hipLaunchKernelGGL(fs_k_vn_head<4>, dim3(grid), dim3(VN_THREADS), 0, st, d_params, d_obs, obs_channels,
                            channel_offset, batch, act_a);
     for (int blk = 0; blk < 8; ++blk) {
-        hipLaunchKernelGGL(fs_k_vn_block, dim3(grid < VN_PERSISTENT_WGS ? grid : VN_PERSISTENT_WGS), dim3(VN_THREADS),
-                           VN_BLOCK_LDS_BYTES, st, d_params + VN_OFF_CONV + 2 * blk * VN_CONV_STRIDE, act_a, batch, grid,
+        hipLaunchKernelGGL(fs_k_vn_block, dim3(tiles < VN_PERSISTENT_WGS ? tiles : VN_PERSISTENT_WGS), dim3(VN_THREADS),
+                           VN_BLOCK_LDS_BYTES, st, d_params + VN_OFF_CONV + 2 * blk * VN_CONV_STRIDE, act_a, batch, tiles,
                            act_b);
         float *tmp = act_a; act_a = act_b; act_b = tmp;
     }
