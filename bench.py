@@ -128,6 +128,31 @@ def traffic_from_profile(episodes):
         return None
 
 
+def perception_leg(device):
+    """Secondary, after the timed region (rank 0, N = 1): the per-action perception kernels of the same path on this GPU --
+    SpatialValueNet forward of one observation (96 transforms x 64 x 64, random-init weights, hand-written fp32-MFMA
+    kernels) -- so the round's BENCH file carries them next to the solver number.  Not part of `value`."""
+    try:
+        import torch
+        from flingbot_amd import nets
+        torch.manual_seed(0)
+        net = nets.SpatialValueNet(rgb_only=True, device=device).to(device).eval().fold_batchnorm()
+        obs = torch.rand(96, 4, 64, 64, device=device)
+        with torch.no_grad():
+            for _ in range(5):
+                net(obs)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                net(obs)
+            torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) / 50 * 1e3
+        return {"value_net_ms_per_observation": ms, "value_net_useful_tflops_f32": 96 * 306.7e6 / (ms * 1e-3) / 1e12,
+                "value_net_path": "fs_value_net_forward" if net._hip is not None else "pytorch"}
+    except Exception as exc:  # the headline number must not depend on this leg
+        return {"error": str(exc)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +232,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.warmup)
+        if world == 1:
+            out["perception"] = perception_leg(torch.device("cuda", local_rank))
         print(json.dumps(out), flush=True)
     fdist.barrier()
     if world > 1:
