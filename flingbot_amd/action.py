@@ -8,6 +8,8 @@ There is no host search: without the HIP library this module raises.
 """
 import ctypes as C
 
+import threading
+
 import numpy as np
 import torch
 
@@ -194,7 +196,7 @@ class ActionSelector:
         kinds = np.ascontiguousarray([KINDS[a] for a in self.actions], np.int32)
         fx = float(compute_intrinsics(39.5978, S)[0, 0])
         nbytes = int(self.lib.fs_select_action_work_bytes(T))
-        key = (stacked.device.index, T)
+        key = (stacked.device.index, T, threading.get_ident())  # scratch per host thread
         work = _work.get(key)
         if work is None or work.numel() < nbytes:
             work = torch.empty(nbytes, dtype=torch.uint8, device=stacked.device)

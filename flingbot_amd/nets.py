@@ -10,6 +10,7 @@ looping per environment (nets.py:228-229).  cv2 / ray are not needed: padding an
 numpy following OpenCV's conventions (BORDER_REPLICATE; INTER_NEAREST source index = floor(dst * src/dst)).
 """
 import random
+import threading
 from time import time
 from typing import List
 
@@ -130,7 +131,7 @@ class SpatialValueNet(nn.Module):
         if batch == 0:
             return out
         nbytes = int(lib.fs_value_net_work_bytes(batch, 64))
-        key = obs.device.index
+        key = (obs.device.index, threading.get_ident())  # per host thread: launches of two threads interleave
         work = _vn_work.get(key)
         if work is None or work.numel() < nbytes:
             work = torch.empty(nbytes, dtype=torch.uint8, device=obs.device)
@@ -295,7 +296,7 @@ def prepare_image_device(img, transformations, dim: int):
         _prep_mats[mkey] = rotation_matrices(rots, size)
     mats, offs = _prep_mats[mkey]
     n = len(rots)
-    key = (img.device.index, ch, size, n)
+    key = (img.device.index, ch, size, n, threading.get_ident())  # scratch per host thread
     nbytes = int(lib.fs_prepare_image_work_bytes(ch, size, n))
     work = _prep_work.get(key)
     if work is None or work.numel() < nbytes:
