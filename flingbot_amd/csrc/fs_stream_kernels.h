@@ -280,22 +280,23 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
     }
     const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
     const float restd = p.solidRestDistance, restd2 = restd * restd;
-    // four candidates per trip: their ids, then their positions and substep-start positions, are in flight together;
+    // four candidates per trip.  The ids of trip t+1 are requested together with the positions / substep-start positions of
+    // trip t (the first trip's ids came with the particle's own loads), so a trip costs one round trip, not two;
     // evaluation order is unchanged
+    int cj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cj[k] = (k < nc && cj0[k] >= 0 && cj0[k] < E.n) ? cj0[k] : -1;
     for (int q0 = 0; q0 < nc; q0 += 4) {
-        int cj[4];
+        int cjn[4] = {-1, -1, -1, -1};
+        if (q0 + 4 < nc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cjn[k] = q0 + 4 + k < nc ? E.nlist[(size_t)(q0 + 4 + k) * E.n + i] : -1;
+        }
         FsVec4 cx[4], c0[4];
         if (EAGER && q0 == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { cj[k] = k < nc ? cj0[k] : -1; cx[k] = cx0[k]; c0[k] = c00[k]; }
+            for (int k = 0; k < 4; ++k) { cx[k] = cx0[k]; c0[k] = c00[k]; }
         } else {
-            if (q0 == 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cj[k] = (k < nc && cj0[k] >= 0 && cj0[k] < E.n) ? cj0[k] : -1;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cj[k] = q0 + k < nc ? E.nlist[(size_t)(q0 + k) * E.n + i] : -1;
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int j = cj[k] < 0 ? i : cj[k];
@@ -308,6 +309,8 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
             if (cj[k] >= 0)
                 fs_particle_contact(a, xi.x, xi.y, xi.z, xi.w, ri0, ri1, ri2, cx[k], cx[k].x - c0[k].x, cx[k].y - c0[k].y,
                                     cx[k].z - c0[k].z, restd, restd2, p.particleFriction);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
     fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
