@@ -30,6 +30,14 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch first, when it is installed: this image's torch wheel bundles its own ROCm runtime, and a process in which
+    # the system runtime (linked by libflingsim) initialised the GPU before torch did cannot use torch.cuda afterwards
+    # ("No HIP GPUs are available").  The device-resident stages (observe, prepare_image, value network, action selection)
+    # hand torch tensors to this library, so both runtimes end up in one process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = os.environ.get("FLINGSIM_LIB", _build.LIB)  # development override: an alternative build of the library
     if not os.path.exists(path):
         if not build_if_missing:
