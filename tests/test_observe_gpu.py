@@ -22,7 +22,7 @@ def _scene(ctx, e, dims, seed, crumple=True):
     return env
 
 
-@pytest.mark.parametrize("render_dim,image_dim", [(720, 400), (720, 128), (256, 256), (300, 77)])
+@pytest.mark.parametrize("render_dim,image_dim", [(720, 400), (720, 128), (256, 256), (300, 77), (128, 200)])
 def test_observe_matches_oracle(gpu_required, render_dim, image_dim):
     from flingbot_amd import sim as fsim
     from oracle import observe as oo
