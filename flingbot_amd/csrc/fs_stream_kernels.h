@@ -129,7 +129,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
     for (int q = 0; q < 8; ++q) near.w[q] = c.mode == 1 ? E.restnear_w[(size_t)q * n + i] : 0xffffffffu;
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
     int phi = 0, qn = 0;
-    FsNbList L = {FS_NB_EMPTY, FS_NB_EMPTY, FS_NB_EMPTY, FS_NB_EMPTY, 0};
+    FsNbList L = fs_nb_empty();
     FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
     bool have_meta = false;
     uint32_t *queue = &queue_s[0][threadIdx.x];
