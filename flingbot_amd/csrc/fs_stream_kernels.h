@@ -100,7 +100,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 // order (thread <-> slot of the sorted copy in xb); phase A scans the 9 runs (3 adjacent buckets each) four candidates per
 // trip and parks a packed entry (slot | 4-bit hit mask) per trip with hits in a per-thread LDS queue; phase B walks the
 // queue one survivor per trip: id, self test, phase / rest-pose filter (set membership on the packed rest-near ids when
-// the whole cloth is one phase), sorted duplicate-free insertion with the four smallest ids staged in registers.
+// the whole cloth is one phase), sorted duplicate-free insertion with the smallest ids (FS_NB_STAGED = 8) staged in registers.
 // A bucket spans [end[b-1], end[b]) of the sorted arrays (cell_fill holds the ends after the scatter).
 #define FS_STREAM_FINDQ 32
 __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids) {
