@@ -281,6 +281,9 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     d.find_mode = phase_find_mode(scene.phase.data(), scene.n, topo->restnear_ok);
     d.dict_size = topo->dict_size; d.dict = topo->dict; d.code_w = topo->code_w; d.nbr_w = topo->nbr_w;
     d.sdict = topo->sdict; d.scode = topo->scode; d.sdict_size = topo->sdict_size; d.pad1 = 0;
+    d.gp_count = scene.sdict_size > 0 ? scene.gp_count : 0;  // the pattern is used together with the spring codes
+    d.gp_dimx = scene.gp_dimx; d.gp_dimz = scene.gp_dimz; d.gp_pad = 0;
+    for (int q = 0; q < 16; ++q) { d.gp_dx[q] = scene.gp_dx[q]; d.gp_dz[q] = scene.gp_dz[q]; }
     d.p = scene.params;
 
     // uploads (main.cpp:1025-1085): positions, velocities (zero), phases

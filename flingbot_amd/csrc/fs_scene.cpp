@@ -217,6 +217,38 @@ void build_stream_codes(FsHostScene &s) {
     s.sdict_size = int(entries.size());
 }
 
+void build_grid_pattern(FsHostScene &s, int dimx, int dimz) {
+    s.gp_count = 0;
+    s.gp_dimx = dimx; s.gp_dimz = dimz;
+    const int n = s.n;
+    if (dimx < 5 || dimz < 5 || (long long)dimx * dimz != n || s.max_deg > 16) return;
+    // canonical list: the incident springs of an interior particle (two cells away from every border)
+    const int ic = 2 * dimx + 2;
+    const int cdeg = s.adj_off[ic + 1] - s.adj_off[ic];
+    if (cdeg <= 0 || cdeg > 16) return;
+    int cdx[16], cdz[16];
+    for (int q = 0; q < cdeg; ++q) {
+        const int j = s.adj_j[s.adj_off[ic] + q];
+        cdz[q] = j / dimx - 2;
+        cdx[q] = j % dimx - 2;
+        if (cdx[q] < -2 || cdx[q] > 2 || cdz[q] < -2 || cdz[q] > 2) return;
+    }
+    // every particle: its list == the in-bounds canonical entries, in canonical order
+    for (int i = 0; i < n; ++i) {
+        const int ix = i % dimx, iz = i / dimx;
+        int a = s.adj_off[i];
+        for (int q = 0; q < cdeg; ++q) {
+            const int jx = ix + cdx[q], jz = iz + cdz[q];
+            if (jx < 0 || jx >= dimx || jz < 0 || jz >= dimz) continue;
+            if (a >= s.adj_off[i + 1] || s.adj_j[a] != jz * dimx + jx) return;
+            ++a;
+        }
+        if (a != s.adj_off[i + 1]) return;
+    }
+    for (int q = 0; q < cdeg; ++q) { s.gp_dx[q] = cdx[q]; s.gp_dz[q] = cdz[q]; }
+    s.gp_count = cdeg;
+}
+
 // Rest-near sets with exactly the device's fp32 test: e = rest_i - rest_j, e.x*e.x + e.y*e.y + e.z*e.z < r*r.
 void build_restnear(FsHostScene &s) {
     const int n = s.n;
@@ -368,6 +400,7 @@ std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const 
     build_adjacency(s);
     build_compact_adjacency(s);
     build_stream_codes(s);
+    build_grid_pattern(s, nv > 0 ? 0 : dimx, nv > 0 ? 0 : dimz);
     build_restnear(s);
     build_vertex_triangles(s);
     return "";

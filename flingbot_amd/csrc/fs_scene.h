@@ -50,6 +50,12 @@ struct FsHostScene {
     int sdict_size = 0;
     std::vector<float> sdict;       // [256][4]
     std::vector<uint32_t> scode;    // [n][4], slot s in byte s of the particle's 16
+    // grid pattern (streaming kernels): when the cloth is the dimx x dimz grid and every particle's incident springs, in
+    // spring-id order, are exactly the in-bounds members of ONE canonical list of (dx, dz) offsets taken in that list's
+    // order, a kernel can compute all neighbour ids of particle (ix, iz) arithmetically -- the spring gathers then need
+    // no adjacency load in front of them.  gp_count = 0 when the pattern does not hold (meshes, tiny grids).
+    int gp_count = 0, gp_dimx = 0, gp_dimz = 0;
+    int gp_dx[16] = {0}, gp_dz[16] = {0};
     // rest-pose neighbours for the SelfCollideFilter test (NvFlex.h:166,564-565): ids of the particles closer than the
     // interaction radius in the rest pose, 16 slots of 16 bits packed two per word, [8][n], 0xffff = empty.
     // restnear_ok = 0 when some particle has more than 16 of them or n > 65535 (the kernels then test rest positions).

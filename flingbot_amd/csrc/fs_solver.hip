@@ -44,7 +44,13 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     // faster there (104x104 x 64 episodes 2.66 -> 2.52 ms/step, the 32-episode evaluation loop 5.0 -> 4.6 s), while the
     // latency form loses the time of the dictionary's barrier (one 104x104 episode 0.74 -> 0.79 ms/step)
     bool coded = !ctx->force_ell_stream && !eager;
-    for (int id : ids) coded = coded && ctx->envs[id].dev.sdict_size > 0;
+    // grid cloths: neighbour ids computed from the particle's grid coordinates (fs_k_iterate_grid)
+    bool grid_form = !ctx->force_ell_stream;
+    for (int id : ids) {
+        const FsEnvDev &d = ctx->envs[id].dev;
+        grid_form = grid_form && d.sdict_size > 0 && d.gp_count > 0 && d.gp_count <= FS_GRID_SLOTS;
+    }
+    grid_form = grid_form && (size_t)max_n * ids.size() >= (size_t)96 * 4096;
     hipStream_t st = ctx->stream;
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
@@ -54,6 +60,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, d_ids);
             for (int it = 0; it < iters; ++it) {
                 auto kern = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
+                if (grid_form) kern = fs_k_iterate_grid;
                 hipLaunchKernelGGL(kern, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1);
             }
             hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1);

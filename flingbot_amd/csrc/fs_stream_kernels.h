@@ -317,6 +317,103 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
     dst[i] = xi;
 }
 
+// GRID form of the iteration (grid cloths, FsEnvDev::gp_count > 0): the neighbour ids of particle (ix, iz) follow from the
+// canonical (dx, dz) offsets in the episode descriptor -- scalar data -- so the twelve spring gathers are requested together
+// with the particle's own loads instead of one round trip later (behind the adjacency); lengths and stiffnesses come from
+// the one-byte codes + dictionary as in the CODED form.  The dictionary entry of the thread is requested first and staged
+// while those loads are in flight.  In-bounds canonical entries, taken in canonical order, ARE the particle's springs in
+// spring-id order (verified per particle by build_grid_pattern), so the accumulation order is unchanged.  Used for the
+// big launches only (>= 96 x 4096 particles: 104x104 x 64 episodes 2.63 -> 2.48 ms/step, crumpled 64x64 x 128 3.15 -> 3.01);
+// below that the barrier of the dictionary staging costs more than the saved round trip (measured: slower than the
+// latency form for 1..32 episodes, also with the lengths taken from the ELL arrays instead of the dictionary).
+#define FS_GRID_SLOTS 12
+__device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, const FsShapesDev &shape_set, int i_raw, bool valid,
+                                                         int sub, int flip, FsVec4 *sdict) {
+    const FsParams &p = E.p;
+    const FsVec4 *__restrict__ src = flip ? E.xb : E.xa;
+    FsVec4 *__restrict__ dst = flip ? E.xa : E.xb;
+    const int t = threadIdx.x;
+    const FsVec4 dent = t < E.sdict_size ? E.sdict[t] : FsVec4{0.0f, 0.0f, 0.0f, 0.0f};  // oldest load: staged below
+    const int i = valid ? i_raw : 0;
+    FsVec4 xi = src[i];
+    const FsU32x4 cw = E.scode[i];
+    const FsVec4 x0i = E.x0[i];
+    const int nc = valid ? E.ncount[i] : 0;
+    int cj0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cj0[k] = E.nlist[(size_t)k * E.n + i];  // slots beyond the count hold stale ids: masked below
+    const int dimx = E.gp_dimx, dimz = E.gp_dimz, cnt = E.gp_count;
+    const int iz = i / dimx, ix = i - iz * dimx;
+    FsVec4 xj[FS_GRID_SLOTS];
+    unsigned inb = 0u;
+#pragma unroll
+    for (int q = 0; q < FS_GRID_SLOTS; ++q) {
+        const int jx = ix + E.gp_dx[q], jz = iz + E.gp_dz[q];
+        const bool in = q < cnt && (unsigned)jx < (unsigned)dimx && (unsigned)jz < (unsigned)dimz;
+        inb |= (unsigned)in << q;
+        xj[q] = src[in ? jz * dimx + jx : i];
+    }
+    sdict[t] = dent;
+    __syncthreads();
+    if (!valid) return;
+    if (!(xi.w > 0.0f)) {
+        dst[i] = xi;
+        return;
+    }
+    FsAcc a = {0.0f, 0.0f, 0.0f, 0};
+    int slot = 0;
+#pragma unroll
+    for (int q = 0; q < FS_GRID_SLOTS; ++q) {
+        if ((inb >> q) & 1u) {
+            const unsigned word = slot < 8 ? (slot < 4 ? cw.x : cw.y) : (slot < 12 ? cw.z : cw.w);
+            const FsVec4 d = sdict[(word >> (8 * (slot & 3))) & 255u];
+            fs_spring_bf(a, xi.x, xi.y, xi.z, xi.w, xj[q], d.y, d.z);
+            ++slot;
+        }
+    }
+    const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
+    const float restd = p.solidRestDistance, restd2 = restd * restd;
+    // candidates: four per trip, the ids of the next trip requested with the positions of the current one
+    int cj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cj[k] = (k < nc && cj0[k] >= 0 && cj0[k] < E.n) ? cj0[k] : -1;
+    for (int q0 = 0; q0 < nc; q0 += 4) {
+        int cjn[4] = {-1, -1, -1, -1};
+        if (q0 + 4 < nc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cjn[k] = q0 + 4 + k < nc ? E.nlist[(size_t)(q0 + 4 + k) * E.n + i] : -1;
+        }
+        FsVec4 cx[4], c0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = cj[k] < 0 ? i : cj[k];
+            cx[k] = src[j];
+            c0[k] = E.x0[j];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cj[k] >= 0)
+                fs_particle_contact(a, xi.x, xi.y, xi.z, xi.w, ri0, ri1, ri2, cx[k], cx[k].x - c0[k].x, cx[k].y - c0[k].y,
+                                    cx[k].z - c0[k].z, restd, restd2, p.particleFriction);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
+    }
+    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
+    dst[i] = xi;
+}
+
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+                                                             int sub, int flip) {
+    __shared__ FsVec4 sdict[256];
+    const int e = ids[blockIdx.y];
+    if (e < 0) return;  // retired slot
+    const FsEnvDev &E = envs[e];
+    if (blockIdx.x * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
+    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+    fs_iterate_particle_grid(E, shapes[e], i, i < E.n, sub, flip, sdict);
+}
+
 // The spring dictionary of the workgroup's episode -> LDS (one entry per thread; FS_TILE = 256 = dictionary size).
 template <bool CODED>
 __device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict) {

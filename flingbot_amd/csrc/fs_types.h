@@ -80,6 +80,9 @@ struct FsEnvDev {
     const FsU32x4 *scode;    // [n]
     int sdict_size;          // 0 = unavailable
     int pad1;
+    // grid pattern (fs_scene.h): canonical (dx, dz) offsets of a particle's springs in spring-id order; gp_count = 0 = none
+    int gp_count, gp_dimx, gp_dimz, gp_pad;
+    int gp_dx[16], gp_dz[16];
     // rest-pose neighbour ids for the SelfCollideFilter test, packed like nbr_w but holding plain particle ids
     const uint32_t *restnear_w;  // [8][n], 0xffff = empty
     int restnear_ok;

@@ -141,6 +141,34 @@ def test_obj_mesh_cloth_bit_exact(gpu_required, tmp_path):
         ctx.close()
 
 
+def test_streaming_large_launch_uses_grid_form_bit_exact(gpu_required):
+    """A streaming launch of >= 96 x 4096 particles of grid cloths runs fs_k_iterate_grid (neighbour ids from the grid
+    coordinates, one-byte spring codes): 100 identical crumpling 64x64 episodes, first / middle / last equal the oracle."""
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    n_envs = 100
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=1)
+    orc = OracleSim()
+    params = cloth_params(64, 64, pos=(0.0, -0.12, 0.0))
+    orc.set_scene(params)
+    rng = np.random.RandomState(5)
+    p = orc.get_positions().reshape(-1, 4).copy()
+    p[:, :3] += (rng.randn(p.shape[0], 3) * 0.004).astype(np.float32)
+    p[:1500, :3] = (rng.rand(1500, 3) * [0.1, 0.06, 0.1] + [0, 0.03, 0]).astype(np.float32)  # a heap: real contacts
+    orc.set_positions(p.ravel())
+    for e in range(n_envs):
+        ctx.set_scene(e, params)
+        ctx.env(e).set_positions(p.ravel())
+    ctx.step(12)
+    orc.step(12)
+    for e in (0, 57, n_envs - 1):
+        _assert_state_equal(ctx.env(e), orc, "grid form, episode %d" % e)
+    co, lo = orc.get_last_neighbors()
+    assert co.max() > 8  # the contact path beyond the first trip is exercised
+    ctx.close()
+
+
 def test_batched_envs_match_single(gpu_required):
     """Episodes in one batched launch are independent: each equals the oracle run of its own seed."""
     from flingbot_amd import sim as fsim
