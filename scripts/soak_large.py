@@ -8,7 +8,8 @@ from conftest import cloth_params
 from flingbot_amd import sim as fsim
 from oracle import OracleSim
 # E identical episodes per launch: 1 -> the latency form of fs_k_iterate (uncompressed adjacency), 14 -> the throughput
-# form with one-byte spring codes (launches above 32 x 4096 particles); episodes 0 and E-1 are compared with the oracle
+# form with one-byte spring codes (launches above 32 x 4096 particles), 40 -> the grid form for the 104x104 case (launches of
+# 96 x 4096 particles and more); episodes 0 and E-1 are compared with the oracle
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 for case, (dx, dz) in enumerate([(104, 104), (90, 70), (72, 100)]):
     ctx = fsim.FlingSim(n_envs=E, solver=0)
