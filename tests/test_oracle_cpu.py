@@ -533,3 +533,23 @@ def test_load_cloth_matches_reference_on_quad_mesh(tmp_path):
     assert orc.n == 30
     orc.step(5)
     assert np.isfinite(orc.get_positions()).all()
+
+
+def test_observe_resize_agrees_with_an_independent_bilinear():
+    """The sampling convention of the restated cv2.resize (pixel centres: src = (dst + 0.5) * scale - 0.5, clamped) is the one
+    torch.nn.functional.interpolate(mode='bilinear', align_corners=False) uses: the float path agrees to the rounding of the tap fractions, the
+    8-bit fixed-point path to one grey level."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import observe as oo
+
+    rng = np.random.RandomState(3)
+    for src, dst in ((72, 40), (90, 90), (50, 77), (720, 400)):
+        d = rng.rand(src, src).astype(np.float32) * 2
+        ref = F.interpolate(torch.from_numpy(d)[None, None], size=(dst, dst), mode="bilinear", align_corners=False)[0, 0].numpy()
+        # (cv2 rounds the tap fraction to float32 from a double expression, torch evaluates it in float32: ~1e-5 apart)
+        assert np.abs(oo.resize_linear_f32(d, dst) - ref).max() < 5e-4, (src, dst)
+        img = rng.randint(0, 256, (src, src, 3)).astype(np.uint8)
+        reff = F.interpolate(torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None], size=(dst, dst), mode="bilinear",
+                             align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(oo.resize_linear_u8(img, dst).astype(np.float32) - reff).max() <= 1.0, (src, dst)
