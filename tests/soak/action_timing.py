@@ -1,6 +1,6 @@
 """Development helper: action selection at FlingBot size, host walk (numpy restatement of the reference) vs device."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 """Development helper: one movep call (lift by 0.25 m at 5e-3 per step = 50 simulation steps) driven (a) from Python
 through the pyflex-shaped accessors like the reference does, (b) by fs_movep on the device; 1 and 64 episodes."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from flingbot_amd import sim as fsim

@@ -1,7 +1,7 @@
 """Development helper: FlingSim.observe (fs_observe: render 720^2 -> resize -> cloth mask -> largest component -> bbox ->
 observation tensor, all on the device) against the host path over pyflex.render's download (numpy restatement)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import bench

@@ -2,7 +2,7 @@
 than the 16-bit rest-neighbour ids can address, so the search falls back to rest-position tests) -- streaming back-end vs the
 CPU oracle, bit for bit, a few steps of a released sheet with a crumpled corner."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import cloth_params

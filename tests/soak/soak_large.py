@@ -1,7 +1,7 @@
 """Development helper: bit-exactness of the streaming back-end on cloths larger than the fused kernel takes (up to 104x104)
 in a loose heap where neighbour lists reach the 96-entry cap; against the CPU oracle (slow: tens of seconds)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from conftest import cloth_params

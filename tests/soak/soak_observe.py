@@ -1,7 +1,7 @@
 """Development helper: fs_observe against oracle/observe.py on many random scenes (cloth sizes, crumple seeds, gripper
 spheres in view, render / observation sizes), bit for bit: observation tensor, largest-component mask, bounding box."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 """Development helper: randomized parity soak -- many seeds / cloth sizes / both back-ends against the CPU oracle,
 bit for bit (positions, velocities, neighbour lists).  Not part of the test-suite (minutes of oracle time)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import scenarios as sc

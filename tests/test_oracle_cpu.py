@@ -326,6 +326,11 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt and "flex_oracle" not in txt, f
+    # development helpers under scripts/ are not tests either: the ones that compare against the oracle live in tests/soak/
+    for f in os.listdir(os.path.join(ROOT, "scripts")):
+        if f.endswith(".py"):
+            txt = open(os.path.join(ROOT, "scripts", f), errors="ignore").read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
 
 
 # ---------------------------------------------------------------- picker / movep restatement vs the reference classes
