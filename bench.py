@@ -13,7 +13,8 @@ Workload (synthetic, seeded): every episode is a 64x64 grid cloth (scene_params 
 above the ground with a per-episode random perturbation and released, so the timed steps cover free fall, ground
 contact with friction and heavy self-collision while the sheet crumples.
 The JSON line carries `roofline` (algorithmic HBM bytes per launch / HIP-event kernel time vs the 8 TB/s peak) and, at
-N=1, `cpu_baseline` (the C oracle timed on one host core on one episode of the same workload).
+N=1, `cpu_baseline` (the C oracle on the host cores this process may use, one independent episode of the same workload per core,
+about 15 s) and `perception` (the value network's forward of one observation, measured after the timed region).
 """
 import argparse
 import json
