@@ -36,7 +36,9 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             return FS_ERR_STATE;
         }
     }
-    const dim3 grid((max_n + FS_TILE - 1) / FS_TILE, (unsigned)ids.size());
+    // XCD-affine 1-D launch (fs_stream_tile): gx workgroups per episode slot, slots rounded up to a multiple of 8
+    const int gx = (max_n + FS_TILE - 1) / FS_TILE, ne = (int)ids.size();
+    const dim3 grid((unsigned)(((ne + 7) / 8) * 8) * (unsigned)gx);
     const dim3 block(FS_TILE);
     // launches that cannot fill the chip are latency-bound: take the form of fs_k_iterate that requests everything up front
     const bool eager = (size_t)max_n * ids.size() <= (size_t)32 * 4096;
@@ -54,16 +56,16 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     hipStream_t st = ctx->stream;
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
-            hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, d_ids);
+            hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
             hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, ctx->d_envs, d_ids);
-            hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, d_ids);
-            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, d_ids);
+            hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
+            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
             for (int it = 0; it < iters; ++it) {
                 auto kern = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
                 if (grid_form) kern = fs_k_iterate_grid;
-                hipLaunchKernelGGL(kern, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1);
+                hipLaunchKernelGGL(kern, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1, gx, ne);
             }
-            hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1);
+            hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1, gx, ne);
         }
     }
     HIP_TRY(hipGetLastError());

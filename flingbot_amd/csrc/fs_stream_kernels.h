@@ -20,10 +20,24 @@ __device__ __forceinline__ int fs_stream_bucket(int cx, int cy, int cz) {
 #endif
 
 // ---- predict + cell histogram.  reference: gravity NvFlex.h:99, damping :117, invMass == 0 -> kinematic :545
-__global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *ids) {
-    if (ids[blockIdx.y] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[blockIdx.y]];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+// XCD-affine tile mapping.  Every per-particle kernel of the step is launched 1-D with ceil8(ne) * gx workgroups; the
+// dispatcher places workgroup n on XCD n % 8, so episode slot `by` runs entirely on XCD by % 8 -- in every kernel of the
+// step (fs_k_grid_scan's one workgroup per episode lands there too).  The per-XCD L2 keeps what the previous kernel wrote,
+// so an episode's positions and lists are L2 hits in the next kernel instead of round trips to the memory side (measured:
+// 104x104 x 16 episodes 1.18 -> 0.97 ms/step, crumpled 64x64 x 64 episodes 1.89 -> 1.64).
+__device__ __forceinline__ bool fs_stream_tile(int gx, int ne, int &bx, int &by) {
+    const int n = blockIdx.x, k = n >> 3;
+    by = (k / gx) * 8 + (n & 7);
+    bx = k - (k / gx) * gx;
+    return by < ne;
+}
+
+__global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *ids, int gx, int ne) {
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    if (ids[by] < 0) return;  // retired slot
+    const FsEnvDev &E = envs[ids[by]];
+    const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     const FsParams &p = E.p;
     const float h = p.dt / (float)p.numSubsteps;
@@ -80,10 +94,12 @@ __global__ __launch_bounds__(1024) void fs_k_grid_scan(const FsEnvDev *envs, con
 }
 
 // ---- scatter particle ids into buckets.  After this kernel cell_fill[b] == end of bucket b.
-__global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *envs, const int *ids) {
-    if (ids[blockIdx.y] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[blockIdx.y]];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+__global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *envs, const int *ids, int gx, int ne) {
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    if (ids[by] < 0) return;  // retired slot
+    const FsEnvDev &E = envs[ids[by]];
+    const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     const FsParams &p = E.p;
     const float inv = 1.0f / (p.radius + p.particleCollisionMargin);
@@ -103,11 +119,13 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 // the whole cloth is one phase), sorted duplicate-free insertion with the smallest ids (FS_NB_STAGED = 8) staged in registers.
 // A bucket spans [end[b-1], end[b]) of the sorted arrays (cell_fill holds the ends after the scatter).
 #define FS_STREAM_FINDQ 32
-__global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids) {
-    if (ids[blockIdx.y] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[blockIdx.y]];
+__global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids, int gx, int ne) {
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    if (ids[by] < 0) return;  // retired slot
+    const FsEnvDev &E = envs[ids[by]];
     __shared__ uint32_t queue_s[FS_STREAM_FINDQ][FS_TILE];
-    const int qs = blockIdx.x * FS_TILE + threadIdx.x;
+    const int qs = bx * FS_TILE + threadIdx.x;
     const int n = E.n;
     if (qs >= n) return;
     const FsParams &p = E.p;
@@ -404,13 +422,15 @@ __device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, cons
 }
 
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
-                                                             int sub, int flip) {
+                                                             int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[256];
-    const int e = ids[blockIdx.y];
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    const int e = ids[by];
     if (e < 0) return;  // retired slot
     const FsEnvDev &E = envs[e];
-    if (blockIdx.x * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+    if (bx * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
+    const int i = bx * FS_TILE + threadIdx.x;
     fs_iterate_particle_grid(E, shapes[e], i, i < E.n, sub, flip, sdict);
 }
 
@@ -427,35 +447,41 @@ __device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict)
 // throughput form (big launches): six springs in flight, later loads issued when needed (fewer live registers)
 template <bool CODED>
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
-                                                        int sub, int flip) {
+                                                        int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
-    const int e = ids[blockIdx.y];
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    const int e = ids[by];
     if (e < 0) return;  // retired slot
     const FsEnvDev &E = envs[e];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
-    if (blockIdx.x * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
+    const int i = bx * FS_TILE + threadIdx.x;
+    if (bx * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
     fs_stage_sdict<CODED>(E, sdict);
     if (i < E.n) fs_iterate_particle<FS_STREAM_CHUNK, false, CODED>(E, shapes[e], i, sub, flip, sdict);
 }
 // latency form (small launches)
 template <bool CODED>
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
-                                                              int sub, int flip) {
+                                                              int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
-    const int e = ids[blockIdx.y];
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    const int e = ids[by];
     if (e < 0) return;  // retired slot
     const FsEnvDev &E = envs[e];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
-    if (blockIdx.x * FS_TILE >= E.n) return;
+    const int i = bx * FS_TILE + threadIdx.x;
+    if (bx * FS_TILE >= E.n) return;
     fs_stage_sdict<CODED>(E, sdict);
     if (i < E.n) fs_iterate_particle<12, true, CODED>(E, shapes[e], i, sub, flip, sdict);
 }
 
 // ---- finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping (:110)
-__global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, const int *ids, int flip) {
-    if (ids[blockIdx.y] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[blockIdx.y]];
-    const int i = blockIdx.x * FS_TILE + threadIdx.x;
+__global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, const int *ids, int flip, int gx, int ne) {
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    if (ids[by] < 0) return;  // retired slot
+    const FsEnvDev &E = envs[ids[by]];
+    const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     const FsParams &p = E.p;
     const float h = p.dt / (float)p.numSubsteps;
