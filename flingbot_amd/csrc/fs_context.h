@@ -57,6 +57,7 @@ struct FsEnv {
     FsVec4 *d_snapshot = nullptr;  // [snapshot_n] positions kept by fs_snapshot_positions (SimEnv.preaction)
     int snapshot_n = 0;
     double picker_threshold = 0.005, particle_radius = 0.00625;
+    double picker_radius = -1.0;  // < 0: use the float32 radius of shape 0 (fs_picker_set_radius)
     bool picker_ready = false;
     FsCamera cam;
 };
@@ -67,6 +68,8 @@ struct fs_ctx {
     int solver = 0;
     bool force_ell_stream = false;     // FS_SOLVER_STREAM_ELL: streaming kernels with the uncompressed ELL adjacency
     bool force_generic_fused = false;  // FS_SOLVER_FUSED_GENERIC: fused kernel with the streamed ELL adjacency
+    bool fused_attr_set = false;       // hipFuncAttributeMaxDynamicSharedMemorySize applied on this context's device
+    int last_form = 0;                 // FS_FORM_* of the most recent solver launch (fs_last_kernel_form)
     hipStream_t stream = nullptr;
     std::vector<FsEnv> envs;
     FsEnvDev *d_envs = nullptr;       // [n_envs]

@@ -132,12 +132,27 @@ extern "C" int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, do
     if (!e->d_saved_w) HIP_TRY(hipMalloc((void **)&e->d_saved_w, sizeof(float) * e->host.n));
     e->picker_threshold = picker_threshold;
     e->particle_radius = particle_radius;
+    e->picker_radius = -1.0;  // until fs_picker_set_radius says otherwise: the (float32) radius of shape 0
     hipLaunchKernelGGL(fs_k_save_inv_mass, dim3((e->host.n + 255) / 256), dim3(256), 0, ctx->stream, e->dev.pos,
                        e->d_saved_w, e->host.n, e->d_picked);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     e->picker_ready = true;
     return FS_OK;
+}
+
+// Picker.picker_radius (flex_utils.py:57, used in the grasp threshold :154-155) is a python float: the double 0.02, not
+// the float32 radius pyflex.add_sphere stored.  Callers that know it pass it here so the threshold sum is the reference's.
+extern "C" int fs_picker_set_radius(fs_ctx *ctx, int env, double picker_radius) {
+    FsEnv *e = picker_env(ctx, env);
+    if (!e) return FS_ERR_ARG;
+    e->picker_radius = picker_radius;
+    return FS_OK;
+}
+
+static double picker_grasp_threshold(const FsEnv &e) {
+    const double r = e.picker_radius >= 0.0 ? e.picker_radius : (double)e.shapes.pos[0].w;
+    return e.picker_threshold + r + e.particle_radius;  // summed left to right like flex_utils.py:154-155
 }
 
 extern "C" int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints) {
@@ -255,6 +270,10 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
         if (!e->picker_ready) { fs_set_error("fs_movep: call fs_picker_reset first"); return FS_ERR_STATE; }
         if (S < 0) S = e->shapes.count;
         if (e->shapes.count != S || S <= 0) { fs_set_error("fs_movep: episodes need the same (non-zero) picker count"); return FS_ERR_STATE; }
+        if (picker_grasp_threshold(*e) != picker_grasp_threshold(ctx->envs[envs[0]])) {
+            fs_set_error("fs_movep: episodes moved together need the same grasp threshold (picker / particle radius)");
+            return FS_ERR_STATE;
+        }
         plans[a] = plan_movep(e->shapes, targets + (size_t)a * S * 3, grasp + (size_t)a * S, speed, limit, min_steps, eps,
                               f32_targets);
         if (iterations_out) iterations_out[a] = plans[a].iterations;
@@ -300,8 +319,7 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
         for (size_t s = 0; s < max_steps && rc == FS_OK; ++s) {
             const int cnt = h_count[s];
             std::vector<int> ids(h_ids.begin() + s * n, h_ids.begin() + s * n + cnt);
-            const double thr = ctx->envs[ids[0]].picker_threshold + (double)ctx->envs[ids[0]].shapes.pos[0].w +
-                               ctx->envs[ids[0]].particle_radius;
+            const double thr = picker_grasp_threshold(ctx->envs[ids[0]]);
             hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes,
                                d_ids + s * n, d_cmds + s * n, d_picked, d_saved, thr);
             rc = fs_step_ids(ctx, ids, 1, d_ids + s * n);

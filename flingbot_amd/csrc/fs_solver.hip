@@ -54,6 +54,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     }
     grid_form = grid_form && (size_t)max_n * ids.size() >= (size_t)96 * 4096;
     hipStream_t st = ctx->stream;
+    ctx->last_form = grid_form ? FS_FORM_STREAM_GRID
+                               : (eager ? FS_FORM_STREAM_EAGER : (coded ? FS_FORM_STREAM_CODED : FS_FORM_STREAM_ELL));
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
             hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
@@ -86,15 +88,15 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const i
         int rc = upload_ids(ctx, ids);
         if (rc != FS_OK) return rc;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the DEVICE's copy of the kernel: tracked per context (a context is bound to one device)
+    if (!ctx->fused_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<12>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     FS_FUSED_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     FS_FUSED_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     FS_FUSED_LDS_BYTES));
-        attr_set = true;
+        ctx->fused_attr_set = true;
     }
     // register-resident (dictionary-coded) adjacency when every episode of the launch has one
     int slots = ctx->force_generic_fused ? 0 : 12;
@@ -104,6 +106,7 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const i
         else if (e.host.max_deg > 12 && slots == 12) slots = 16;
     }
     const dim3 grid((unsigned)ids.size()), block(FS_FUSED_THREADS);
+    ctx->last_form = slots == 12 ? FS_FORM_FUSED_12 : (slots == 16 ? FS_FORM_FUSED_16 : FS_FORM_FUSED_GENERIC);
     if (slots == 12)
         hipLaunchKernelGGL(fs_k_fused_step<12>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,
                            d_ids, n_steps);

@@ -231,9 +231,10 @@ PYBIND11_MODULE(pyflex, m) {
     m.def("set_shape_color", &pyflex_set_shape_color, "Set the color of the shape");
 
     // ---- additive names: the reference's host loops around step(), run on the device ----------
-    m.def("picker_reset", [](double picker_threshold, double particle_radius) {
+    m.def("picker_reset", [](double picker_threshold, double particle_radius, double picker_radius) {
         if (fs_picker_reset(ctx(), 0, picker_threshold, particle_radius) != FS_OK) fail("pyflex.picker_reset");
-    }, py::arg("picker_threshold") = 0.005, py::arg("particle_radius") = 0.00625,
+        if (picker_radius >= 0.0 && fs_picker_set_radius(ctx(), 0, picker_radius) != FS_OK) fail("pyflex.picker_reset");
+    }, py::arg("picker_threshold") = 0.005, py::arg("particle_radius") = 0.00625, py::arg("picker_radius") = -1.0,
           "Picker.reset bookkeeping (flex_utils.py:85,99-101) for the spheres added with add_sphere");
     m.def("movep", [](py::array targets, py::array_t<int, py::array::c_style | py::array::forcecast> grasp, double speed,
                       int limit, py::object min_steps, double eps) {

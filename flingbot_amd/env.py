@@ -130,6 +130,9 @@ class BatchedFlingEnv:
             self.prim.sim_steps += sub.sim_steps
             for e in es:
                 self.prim.terminate[e] = self.prim.terminate[e] or sub.terminate[e]
+                # SimEnv keeps grasp_states across the handler: an early return (cloth not grasped, simEnv.py:306-308) leaves
+                # [p1_grasp, p2_grasp] set for postaction's reset_end_effectors / wait_until_stable
+                self.prim.grasp_states[e] = list(sub.grasp_states[e])
         self.prim.postaction(run)
         curr = np.array(self.sim.coverage())
         rewards = {}

@@ -76,6 +76,27 @@ class SpatialValueNet(nn.Module):
         self.steps = nn.parameter.Parameter(torch.tensor(steps), requires_grad=False)
         self._folded = None
         self._hip = None
+        self._fold_stale = False  # parameters may have changed since fold_batchnorm(): re-fold before the next eval forward
+        self._fold_hip = None     # the `hip` argument of the last fold_batchnorm() call
+
+    # The folded copies are derived data.  Everything that can change the parameters they were derived from marks them
+    # stale -- loading a state_dict (also through a parent module: nn.Module.load_state_dict calls this hook on every
+    # submodule), a train() phase (optimizer steps), .to() / .cuda() / .float() (which also moves nothing that is not
+    # registered) -- and the next eval-mode forward folds again.  Writing to `p.data` by hand in eval mode is the one case
+    # left to the caller: call fold_batchnorm() again.
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._fold_stale = True
+
+    def train(self, mode=True):
+        if mode:
+            self._fold_stale = True
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._fold_stale = True
+        return out
 
     def setup_net(self):
         blocks = [BasicBlock(self.input_channels, 16, 3, 1)]
@@ -99,6 +120,8 @@ class SpatialValueNet(nn.Module):
 
     def forward(self, obs):
         if self._folded is not None and not self.training:
+            if self._fold_stale:
+                self.fold_batchnorm(hip=self._fold_hip)
             if self._hip is not None and obs.is_cuda and obs.dim() == 4 and tuple(obs.shape[-2:]) == (64, 64):
                 return self._forward_hip(obs)
             return self._folded(self.preprocess_obs(obs).contiguous(memory_format=torch.channels_last))
@@ -155,6 +178,7 @@ class SpatialValueNet(nn.Module):
         observations of 64 x 64 pixels; default = whenever the parameters live on a GPU.  Call again after loading
         new weights."""
         self.eval()
+        self._fold_hip = hip
 
         def fold(conv, bn):
             out = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=True)
@@ -186,6 +210,7 @@ class SpatialValueNet(nn.Module):
         if hip is None:
             hip = dev.type == 'cuda'
         object.__setattr__(self, '_hip', self._pack_hip(folded, dev) if hip else None)
+        self._fold_stale = False
         return self
 
     def _pack_hip(self, folded, dev):

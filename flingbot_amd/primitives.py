@@ -48,7 +48,7 @@ class FlingPrimitives:
                 self.sim.add_sphere(e, r_p, c, [1, 0, 0, 0])
             self.sim.set_shape_states(e, self.sim.get_shape_states(e))
             self.sim.set_shape_states(e, np.array([np.hstack([c, c, [1, 0, 0, 0], [1, 0, 0, 0]]) for c in centres]))
-            self.sim.picker_reset(e, picker_threshold, particle_radius)
+            self.sim.picker_reset(e, picker_threshold, particle_radius, picker_radius=r_p)
         self.reset_end_effectors(self.envs)
         self.sim.step_list([int(e) for e in self.envs], 1)
         self.sim_steps += len(self.envs)
@@ -83,6 +83,7 @@ class FlingPrimitives:
         st = {}
         first_targets = []
         for e, gd in zip(envs, grasp_dist):
+            gd = np.float64(gd)
             left, right = self.picker_positions(e)
             left[1] = fling_height
             right[1] = fling_height
@@ -111,8 +112,12 @@ class FlingPrimitives:
                     continue
                 s["cloth_midpoint"] = new_cloth_midpoint
                 s["grasp_dist"] += increment_step
-                left = s["midpoint"] + s["direction"] * s["grasp_dist"] / 2
-                right = s["midpoint"] - s["direction"] * s["grasp_dist"] / 2
+                # float32 arrays meet the np.float64 scalar grasp_dist (np.linalg.norm's return type in every caller):
+                # float64 under NumPy >= 2 (NEP 50), which is what the goldens pin -- spelled out so the targets do not
+                # depend on the installed NumPy's promotion rules (NumPy 1.x would keep float32 here)
+                mid64, dir64 = s["midpoint"].astype(np.float64), s["direction"].astype(np.float64)
+                left = mid64 + dir64 * np.float64(s["grasp_dist"]) / 2
+                right = mid64 - dir64 * np.float64(s["grasp_dist"]) / 2
                 nxt.append(e)
                 targets.append([left, right])
             self.movep(nxt, targets, speed=5e-4)

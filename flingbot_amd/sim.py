@@ -13,6 +13,9 @@ from . import build as _build
 
 FS_SOLVER_AUTO, FS_SOLVER_STREAM, FS_SOLVER_FUSED = 0, 1, 2
 FS_SOLVER_FUSED_GENERIC, FS_SOLVER_STREAM_ELL = 3, 4  # test / comparison variants (include/flingsim.h)
+# fs_last_kernel_form (white box): which kernel form the last solver launch ran
+(FS_FORM_FUSED_12, FS_FORM_FUSED_16, FS_FORM_FUSED_GENERIC, FS_FORM_STREAM_EAGER, FS_FORM_STREAM_CODED, FS_FORM_STREAM_ELL,
+ FS_FORM_STREAM_GRID) = range(1, 8)
 
 _lib = None
 
@@ -54,6 +57,7 @@ def load_library(build_if_missing=True):
         "fs_n_envs": (ci, [vp]),
         "fs_set_solver": (ci, [vp, ci]),
         "fs_get_solver": (ci, [vp]),
+        "fs_last_kernel_form": (ci, [vp]),
         "fs_set_scene": (ci, [vp, ci, fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
         "fs_step": (ci, [vp, ci, ci]),
         "fs_step_list": (ci, [vp, ci, ip, ci]),
@@ -88,6 +92,7 @@ def load_library(build_if_missing=True):
         "fs_coverage": (ci, [vp, C.POINTER(C.c_double), ci]),
         "fs_step_timed": (ci, [vp, ci, ci, fp]),
         "fs_picker_reset": (ci, [vp, ci, C.c_double, C.c_double]),
+        "fs_picker_set_radius": (ci, [vp, ci, C.c_double]),
         "fs_picker_get_picked": (ci, [vp, ci, ip, ci]),
         "fs_movep": (ci, [vp, ci, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
@@ -177,6 +182,10 @@ class FlingSim:
     def set_solver(self, solver):
         self._ck(self.lib.fs_set_solver(self.h, int(solver)))
 
+    def last_kernel_form(self):
+        """FS_FORM_* of the most recent solver launch (white box for the parity tests)."""
+        return self._ck(self.lib.fs_last_kernel_form(self.h))
+
     def env(self, i=0):
         return EnvView(self, i)
 
@@ -208,8 +217,12 @@ class FlingSim:
         return float(ms.value)
 
     # ---- on-device picker / movep (include/flingsim.h)
-    def picker_reset(self, env, picker_threshold=0.005, particle_radius=0.00625):
+    def picker_reset(self, env, picker_threshold=0.005, particle_radius=0.00625, picker_radius=None):
+        """Picker.reset's bookkeeping.  picker_radius: the reference's python-float Picker.picker_radius, which enters the
+        grasp threshold as a double (flex_utils.py:154-155); None keeps the float32 radius of shape 0."""
         self._ck(self.lib.fs_picker_reset(self.h, int(env), float(picker_threshold), float(particle_radius)))
+        if picker_radius is not None:
+            self._ck(self.lib.fs_picker_set_radius(self.h, int(env), float(picker_radius)))
 
     def picked(self, env):
         out = np.full(self.n_shapes(env), -1, np.int32)

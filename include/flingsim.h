@@ -120,6 +120,16 @@ int fs_coverage(fs_ctx *ctx, double *out, int n_doubles);
 
 /* white-box access for tests: particle-contact candidate lists of the last substep, counts[N], lists[N*96] */
 int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
+/* white-box access for tests: which kernel form the most recent fs_step* launch of this context ran (0 = none yet).
+   The launch size selects the form (fs_solver.hip), so a parity test asserts that it compared the form it meant to. */
+#define FS_FORM_FUSED_12 1       /* fs_k_fused_step<12>: register-resident coded adjacency, <= 12 springs per particle */
+#define FS_FORM_FUSED_16 2       /* fs_k_fused_step<16>: the same with <= 16 springs per particle */
+#define FS_FORM_FUSED_GENERIC 3  /* fs_k_fused_step<0>: adjacency streamed from the ELL arrays */
+#define FS_FORM_STREAM_EAGER 4   /* fs_k_iterate_eager<false>: latency form of small launches */
+#define FS_FORM_STREAM_CODED 5   /* fs_k_iterate<true>: throughput form, one-byte spring codes */
+#define FS_FORM_STREAM_ELL 6     /* fs_k_iterate<false>: throughput form, uncompressed adjacency */
+#define FS_FORM_STREAM_GRID 7    /* fs_k_iterate_grid: neighbour ids from the grid coordinates (large launches) */
+int fs_last_kernel_form(const fs_ctx *ctx);
 /* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */
 void *fs_device_positions(fs_ctx *ctx, int env);
 
@@ -129,6 +139,10 @@ void *fs_device_positions(fs_ctx *ctx, int env);
    episode's kinematic spheres (fs_add_sphere); results are identical to driving fs_step through those Python classes. */
 /* Picker.reset bookkeeping (flex_utils.py:85,99-101): nothing held; remember every particle's inverse mass. */
 int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, double particle_radius);
+/* Picker.picker_radius (flex_utils.py:57) as the python float the reference adds into the grasp threshold
+   (flex_utils.py:154-155); without this call the threshold uses the float32 radius pyflex.add_sphere stored for shape 0.
+   fs_picker_reset clears it. */
+int fs_picker_set_radius(fs_ctx *ctx, int env, double picker_radius);
 /* picked particle index per picker (-1 = none) */
 int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
 /* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all

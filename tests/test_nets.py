@@ -60,6 +60,39 @@ def test_forward_matches_reference_cpu():
     assert list(pol.state_dict().keys()) == keys
 
 
+def test_folded_copy_follows_new_weights():
+    """The BatchNorm-folded inference copy is derived data: loading another checkpoint into an already folded policy (also
+    through the parent module), a train() phase, or .to() must not leave the OLD weights in the inference path."""
+    pol, g = _policy("cpu")
+    net = pol.value_nets["fling"]
+    obs = torch.from_numpy(g["obs"])
+    net.fold_batchnorm()
+    with torch.no_grad():
+        before = net(obs).clone()
+    torch.manual_seed(7)
+    sd = {k: (torch.randn_like(v) * 0.1 + (1.0 if k.endswith("running_var") else 0.0)).abs() if v.dtype.is_floating_point and v.dim() > 0
+          else v for k, v in pol.state_dict().items()}
+    pol.load_state_dict(sd, strict=True)          # parent load -> child hook
+    with torch.no_grad():
+        after = net(obs).clone()                   # eval mode, folded path (re-folded lazily)
+        object.__setattr__(net, "_folded", None)   # the module graph itself, same weights
+        plain = net(obs)
+    assert not torch.allclose(before, after)
+    assert (after - plain).abs().max() < 5 * TOL * max(1.0, float(plain.abs().max()))
+    # train() phase with a weight update, then eval(): folded again from the updated weights
+    net.fold_batchnorm()
+    net.train()
+    with torch.no_grad():
+        for p_ in net.net.parameters():
+            p_.mul_(0.5)
+    net.eval()
+    with torch.no_grad():
+        after2 = net(obs).clone()
+        object.__setattr__(net, "_folded", None)
+        plain2 = net(obs)
+    assert (after2 - plain2).abs().max() < 5 * TOL * max(1.0, float(plain2.abs().max()))
+
+
 def test_exploration_and_bookkeeping():
     from flingbot_amd import nets
 
