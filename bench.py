@@ -5,16 +5,20 @@ One bench "step" = one pyflex.step() (dt 1/100 s = 4 substeps x 30 solver iterat
 GPU: `--episodes` independent 64x64 cloth episodes per GPU (default 256 = one per CU), advanced by ONE launch of the
 fused LDS-resident solver kernel.  value = episode-steps/s summed over all GPUs (weak scaling: episodes per GPU fixed).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--episodes E]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--episodes E]      # N > 1: starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                               # or ranks started by torchrun
 
 Workload (synthetic, seeded): every episode is a 64x64 grid cloth (scene_params of BASELINE.md C2) hung vertically
-above the ground with a per-episode random perturbation and released, so the timed steps cover free fall, ground
-contact with friction and heavy self-collision while the sheet crumples.
-The JSON line carries `roofline` (algorithmic HBM bytes per launch / HIP-event kernel time vs the 8 TB/s peak) and, at
-N=1, `cpu_baseline` (the C oracle on the host cores this process may use, one independent episode of the same workload per core,
-about 15 s) and `perception` (the value network's forward of one observation, measured after the timed region).
+above the ground with a per-episode random perturbation and released; `--preroll` (60) untimed frames bring it to the
+state the timed window should see whatever --steps is: the sheet crumpled on the ground (ground friction + heavy
+self-collision, the expensive regime).
+The JSON line carries `roofline` (algorithmic HBM bytes per launch / HIP-event kernel time vs the 8 TB/s peak; `basis`
+and `limiter` say what that number is and what really bounds the LDS-resident kernel), `parity` (one episode of the
+batch that was timed, compared with the C oracle after the timed region), `configs` (the 64-episodes-per-GPU figure of
+BASELINE.json configs[2] / configs[3] next to the headline) and, at N=1, `cpu_baseline` (the C oracle on the host
+cores this process may use, one independent episode of the same workload per core, about 15 s) and `perception` (the
+value network's forward of one observation, measured after the timed region).
 """
 import argparse
 import json
@@ -114,19 +118,54 @@ def cpu_baseline(warmup, budget_s=15.0):
     total = sum(done)
     return {"value": total / dt, "unit": "sim steps/s", "cores": cores, "kind": "port",
             "sample": f"{cores} independent episodes (64x64 cloth, the GPU episodes' initial states 0..{cores - 1}), one per "
-                      f"host core, {total} pyflex.step() in {dt:.1f} s after {warmup} warm-up steps each, C oracle"}
+                      f"host core, {total} pyflex.step() in {dt:.1f} s after {warmup} untimed frames each (pre-roll + warm-up, as on the GPU), C oracle"}
 
 
 def traffic_from_profile(episodes):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or None."""
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), or (None, None).  NOT measured in this
+    run: it is the PMC pass of the same command (scripts/profile_bench.sh), scaled per episode; `traffic_source` says so."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
         per_ep = rec["bytes_per_launch"] / rec["episodes"]
-        return per_ep * episodes
+        return per_ep * episodes, f"profiles/hbm_traffic.json (rocprofv3 --pmc pass '{rec.get('tag', '?')}' of this command, " \
+                                  f"FETCH_SIZE x2 + WRITE_SIZE per launch at {rec['episodes']} episodes, scaled per episode)"
     except Exception:
-        return None
+        return None, None
+
+
+def limiter_from_profile():
+    """What the committed PMC counters say actually limits the fused kernel (it keeps the iterations in LDS, so the
+    contract's algorithmic-bytes `roofline` is an equivalent streamed bandwidth, not HBM traffic)."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+            c = rec["counters"]
+            valu = c["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] / c["SQ_WAVE_CYCLES"]["avg_per_launch"]
+            return {"bound": "valu-issue", "source": f"profiles/{tag}_pmc.json",
+                    "valu_active_per_wave_cycle": valu, "ceiling_per_wave_cycle": 1.0 / rec.get("waves_per_simd", 4),
+                    "frac": valu * rec.get("waves_per_simd", 4),
+                    "valu_instructions_per_launch": c["SQ_INSTS_VALU"]["avg_per_launch"],
+                    "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"]["total_corrected"],
+                    "hbm_gbs": rec["hbm_bytes_per_launch"]["total_corrected"] / (rec["average_us"] * 1e-6) / 1e9,
+                    "hbm_frac_of_peak": rec["hbm_bytes_per_launch"]["total_corrected"] / (rec["average_us"] * 1e-6) / 1e9
+                                        / HBM_PEAK_GBS}
+        except Exception:
+            continue
+    return None
+
+
+def oracle_trajectory(seed, steps):
+    """The checker: one episode of the workload on the C oracle, `steps` frames from the initial state."""
+    from oracle import OracleSim
+
+    o = OracleSim()
+    setup_episode(o, seed=seed)
+    o.step(steps)
+    return o.get_positions(), o.get_velocities()
 
 
 def perception_leg(device):
@@ -154,16 +193,73 @@ def perception_leg(device):
         return {"error": str(exc)[:200]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--episodes", type=int, default=256, help="cloth episodes per GPU")
-    ap.add_argument("--solver", type=int, default=2, help="2 fused LDS kernel (default), 1 streaming kernels")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def timed_batch(ctx, fdist, torch, steps, warmup, preroll):
+    """Pre-roll + warm-up (untimed), then `steps` frames of every episode of `ctx` bracketed by barrier + synchronize on
+    both sides.  Returns (wall seconds of the timed region, MAX over ranks; HIP-event kernel milliseconds of this rank)."""
+    def barrier():
+        fdist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
 
+    if preroll:
+        ctx.step(preroll)                  # bring the workload to its steady crumpled state (untimed, not warm-up)
+    for _ in range(warmup):
+        ctx.step(1)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()                      # HIP events on the stream the kernels are launched on
+    for _ in range(steps):
+        ctx.step(1)                        # fused: ONE launch advances every episode one frame
+    kern_ms_total = ctx.timer_stop()
+    # episode-batch gather of the coverage rewards (the only exchange step of the path, SURVEY.md 8e)
+    cov_all = fdist.gather_rewards(ctx.coverage(), device="cuda")
+    barrier()
+    elapsed = fdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    return elapsed, kern_ms_total, cov_all
+
+
+class ParityCheck:
+    """The checker after the timed region: episode `env` of the batch that was just timed against the C oracle.
+    Full trajectory from the initial state when that is affordable on one host core (the oracle then runs in a thread
+    while the bench goes on; `result()` joins it), else the state is handed to the oracle and both sides advance 5 more
+    frames (the GPU side as the same batched launch that was timed)."""
+
+    def __init__(self, ctx, env, seed, total_steps, max_oracle_steps=450):
+        import threading
+        from oracle import OracleSim
+
+        self.seed, self.thread, self.ref = int(seed), None, None
+        if total_steps <= max_oracle_steps:
+            self.mode = f"full trajectory, {total_steps} frames from the initial state"
+            self.gpu = (ctx.get_positions(env), ctx.get_velocities(env))
+            self.thread = threading.Thread(target=self._run, args=(seed, total_steps), daemon=True)
+            self.thread.start()
+        else:
+            self.mode = f"5 frames from the state after {total_steps} frames"
+            o = OracleSim()
+            setup_episode(o, seed=seed)
+            o.set_positions(ctx.get_positions(env))
+            o.set_velocities(ctx.get_velocities(env))
+            ctx.step(5)
+            o.step(5)
+            self.ref = (o.get_positions(), o.get_velocities())
+            self.gpu = (ctx.get_positions(env), ctx.get_velocities(env))
+
+    def _run(self, seed, steps):
+        self.ref = oracle_trajectory(seed, steps)
+
+    def result(self):
+        if self.thread is not None:
+            self.thread.join()
+        (ph, vh), (po, vo) = self.gpu, self.ref
+        exact = bool(np.array_equal(ph.view(np.uint32), po.view(np.uint32)) and
+                     np.array_equal(vh.view(np.uint32), vo.view(np.uint32)))
+        rel = float(np.abs(ph - po).max() / max(1.0, float(np.abs(po).max())))
+        return {"parity_checked": True, "bit_exact": exact, "max_rel_position_error": rel, "within_1e-4": rel <= 1e-4,
+                "episode": self.seed, "mode": self.mode, "checker": "oracle/flex_oracle.c"}
+
+
+def run_rank(args):
     import torch
 
     from flingbot_amd import distributed as fdist
@@ -171,9 +267,6 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_env != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     rank, local_rank, world = fdist.init_from_env("nccl")  # one process per GPU; "nccl" is RCCL on ROCm
 
@@ -182,31 +275,17 @@ def main():
     for e, g in enumerate(fdist.episode_range(rank, E)):
         setup_episode(ctx.env(e), seed=g)  # global episode id = seed
     ctx.sync()
+    elapsed, kern_ms_total, cov_all = timed_batch(ctx, fdist, torch, args.steps, args.warmup, args.preroll)
+    form = ctx.last_kernel_form()
 
-    def barrier():
-        fdist.barrier()
-        ctx.sync()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        ctx.step(1)
-    barrier()
-    t0 = time.perf_counter()
-    ctx.timer_start()                      # HIP events on the stream the kernels are launched on
-    for _ in range(args.steps):
-        ctx.step(1)                        # one launch of the fused kernel: every episode advances one frame
-    kern_ms_total = ctx.timer_stop()
-    # episode-batch gather of the coverage rewards (the only exchange step of the path)
-    cov_all = fdist.gather_rewards(ctx.coverage(), device="cuda")
-    barrier()
-    elapsed = fdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
-
+    out, parity_main, parity_2 = None, None, None
     if rank == 0:
         total_steps = E * world * args.steps
         value = total_steps / elapsed
         kern_ms = kern_ms_total / args.steps
         achieved = BYTES_PER_STEP * E / (kern_ms * 1e-3) / 1e9
-        traffic = traffic_from_profile(E)
+        traffic, traffic_source = traffic_from_profile(E)
+        fused = form in (fsim.FS_FORM_FUSED_12, fsim.FS_FORM_FUSED_16, fsim.FS_FORM_FUSED_GENERIC)
         out = {
             "metric": "sim steps/sec (64x64-particle cloth)",
             "value": value,
@@ -221,25 +300,96 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{E} x 64x64-particle cloth episodes per GPU (4096 particles, 23938 springs, "
-                                   f"self-collision + ground friction; vertical sheet released and crumpling), one "
-                                   f"pyflex.step() (4 substeps x 30 iterations) of every episode per bench step",
+                                   f"self-collision + ground friction; vertical sheet released, timed from frame "
+                                   f"{args.preroll + args.warmup} on: crumpled on the ground), one pyflex.step() (4 substeps x 30 "
+                                   f"iterations) of every episode per bench step",
                        "episodes_per_gpu": E, "cloth": "64x64", "substeps": SUBSTEPS, "iterations": ITERS,
-                       "solver": "fused-lds" if args.solver == 2 else "stream", "parallelism": f"episodes x{world}"},
+                       "preroll_frames": args.preroll,
+                       "solver": "fused-lds" if fused else "stream", "parallelism": f"episodes x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fs_k_fused_step" if args.solver == 2 else "fs_k_iterate (+stage kernels)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "basis": "equivalent streamed bandwidth: ALGORITHMIC bytes of SURVEY 8(d)'s streaming model per "
+                                  "launch / HIP-event kernel time; the fused kernel keeps the iterations in LDS, so its "
+                                  "HBM traffic (`traffic`) is far below this and `limiter` names what bounds it",
+                         "kernel": "fs_k_fused_step" if fused else "fs_k_iterate (+stage kernels)",
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_STEP * E},
             "mean_coverage": float(cov_all.mean().item()),
         }
+        if fused:
+            out["limiter"] = limiter_from_profile()
+        if not args.no_parity:
+            parity_main = ParityCheck(ctx, E // 2, E // 2, args.preroll + args.warmup + args.steps)
+    ctx.close()
+
+    # ---- secondary figure, every rank, after the headline's timed region: 64 episodes per GPU (BASELINE.json configs[2];
+    #      at 8 GPUs this is configs[3]: 512 episodes sharded 8 x 64 with the coverage gather over RCCL)
+    if not args.no_secondary:
+        E2, K2, W2 = 64, max(10, min(args.steps, 40)), max(3, min(args.warmup, 10))
+        ctx2 = fsim.FlingSim(n_envs=E2, device=local_rank, solver=fsim.FS_SOLVER_AUTO)
+        for e, g in enumerate(fdist.episode_range(rank, E2)):
+            setup_episode(ctx2.env(e), seed=g)
+        ctx2.sync()
+        el2, k2_ms, cov2 = timed_batch(ctx2, fdist, torch, K2, W2, args.preroll)
+        form2 = ctx2.last_kernel_form()
+        if rank == 0:
+            rate2 = E2 * world * K2 / el2
+            entry = {"name": "64 x 64x64 episodes per GPU" + (f", {E2 * world} episodes over {world} GPUs" if world > 1 else ""),
+                     "baseline_config": "configs[2]" + (" / configs[3] at 8 GPUs" if world == 8 else ""),
+                     "value": rate2, "unit": "sim steps/s", "episodes_per_gpu": E2, "steps": K2, "warmup": W2,
+                     "ms_per_step": el2 / K2 * 1e3, "gpu_ms_per_step": k2_ms / K2,
+                     "solver": "stream (AUTO)" if form2 >= fsim.FS_FORM_STREAM_EAGER else "fused (AUTO)",
+                     "kernel_form": int(form2),
+                     "roofline_frac_equivalent": BYTES_PER_STEP * E2 / (k2_ms / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "mean_coverage": float(cov2.mean().item())}
+            if not args.no_parity:
+                parity_2 = ParityCheck(ctx2, E2 // 2, E2 // 2, args.preroll + W2 + K2)
+            out["configs"] = [
+                {"name": f"{E} x 64x64 episodes per GPU (headline)", "value": out["value"], "unit": "sim steps/s",
+                 "episodes_per_gpu": E, "ms_per_step": out["ms_per_step"], "solver": out["config"]["solver"]},
+                entry]
+        ctx2.close()
+
+    if rank == 0:
+        if parity_main is not None:
+            out["parity"] = parity_main.result()
+            out["parity_checked"] = bool(out["parity"]["bit_exact"])
+        if parity_2 is not None:
+            out["configs"][1]["parity"] = parity_2.result()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.warmup)
-        if world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.preroll + args.warmup)
+        if world == 1 and not args.no_secondary:
             out["perception"] = perception_leg(torch.device("cuda", local_rank))
         print(json.dumps(out), flush=True)
     fdist.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
-    ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--episodes", type=int, default=256, help="cloth episodes per GPU")
+    ap.add_argument("--preroll", type=int, default=60,
+                    help="untimed frames before the warm-up: the timed window then sees the crumpled sheet whatever --steps is")
+    ap.add_argument("--solver", type=int, default=2, help="2 fused LDS kernel (default), 1 streaming kernels, 0 AUTO")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only: no 64-episode figure, no perception leg")
+    args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # nobody started the ranks for us: start them ourselves, one fresh interpreter per GPU, BEFORE this process has
+        # made any GPU call (it never makes one: flingbot_amd.launch is standard library only)
+        from flingbot_amd.launch import launch_local_ranks
+
+        sys.exit(launch_local_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if int(world_env or "1") != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run, or leave "
+                         f"WORLD_SIZE unset and bench.py starts the ranks itself")
+    run_rank(args)
 
 
 if __name__ == "__main__":

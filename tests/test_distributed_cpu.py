@@ -127,3 +127,65 @@ def test_sharded_evaluation_gathers_by_global_episode(tmp_path):
     for o in outs:
         assert o["world"] == 2 and o["n"] == 4
         assert np.allclose(o["all_init"], np.arange(8) * 0.01) and np.allclose(o["all_final"], np.arange(8) * 0.01 + 0.5)
+
+
+LAUNCHED_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["FS_ROOT"])
+import torch
+from flingbot_amd import distributed as fdist
+
+rank, local_rank, world = fdist.init_from_env("gloo")
+t = torch.tensor([float(rank + 1)])
+torch.distributed.all_reduce(t)
+with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as fh:
+    json.dump({"rank": rank, "local_rank": local_rank, "world": world, "sum": t.item(), "argv": sys.argv[2:]}, fh)
+fdist.barrier()
+torch.distributed.destroy_process_group()
+if "--fail-rank-1" in sys.argv and rank == 1:
+    sys.exit(7)
+"""
+
+
+def test_launcher_starts_ranks_that_rendezvous(tmp_path):
+    """flingbot_amd.launch.launch_local_ranks (what `python bench.py --gpus N` uses when nobody set WORLD_SIZE): N fresh
+    interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set find each other (gloo here, RCCL on the GPU node);
+    a failing rank's exit code comes back."""
+    import json
+    from flingbot_amd.launch import launch_local_ranks
+
+    script = tmp_path / "launched.py"
+    script.write_text(LAUNCHED_WORKER)
+    env = dict(os.environ, FS_ROOT=ROOT)
+    env.pop("WORLD_SIZE", None)
+    assert launch_local_ranks(2, str(script), [str(tmp_path), "--steps", "3"], env=env, timeout=180) == 0
+    recs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r, rec in enumerate(recs):
+        assert rec == {"rank": r, "local_rank": r, "world": 2, "sum": 3.0, "argv": ["--steps", "3"]}
+    assert launch_local_ranks(2, str(script), [str(tmp_path), "--fail-rank-1"], env=env, timeout=180) == 7
+
+
+def test_launcher_module_never_touches_the_gpu_runtime():
+    """The parent of the ranks may not initialise HIP: the launcher imports neither torch nor libflingsim."""
+    code = "import sys; sys.path.insert(0, %r); import flingbot_amd.launch; " \
+           "bad = [m for m in sys.modules if m.split('.')[0] in ('torch', 'numpy', 'ctypes')]; " \
+           "assert not [m for m in bad if m.startswith('torch')], bad; print('ok')" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_bench_starts_its_own_ranks_without_world_size():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent starts two ranks (which, on this GPU-less machine, each
+    stop with the no-CPU-fallback message) instead of refusing to run."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the launcher's happy path is exercised by bench.py itself")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("no HIP device visible") == 2, out.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in out.stderr

@@ -1,0 +1,192 @@
+"""GPU parity of the kernels that are SHIPPED AND TIMED, in the launch shapes they are timed in.
+
+tests/test_parity_gpu.py walks the physics (drop / crumple / fling / dense ball / tethers / phases) mostly one episode at
+a time; a one-episode launch, however, runs neither the bench configuration (256 episodes, one fused workgroup each,
+blockIdx > 0) nor the throughput forms of the streaming iterate kernel, which the launch size selects (fs_solver.hip).
+Here every form is launched at a size that selects it -- asserted through the white-box getter fs_last_kernel_form --
+on distinct-seed episodes, and sampled episodes are compared with the CPU oracle bit for bit:
+
+    fs_k_fused_step<12>   8 and 256 episodes of bench.py's own workload (BASELINE.json configs[1] / the bench line)
+    fs_k_fused_step<0>    FS_SOLVER_FUSED_GENERIC, 9 episodes
+    fs_k_fused_step<16>   a mesh cloth with 16 springs per particle, 3 episodes
+    fs_k_iterate<true>    64 x 64x64 episodes, AUTO (BASELINE.json configs[2] and configs[3]'s per-GPU share)
+    fs_k_iterate<false>   64 x 64x64 episodes, FS_SOLVER_STREAM_ELL
+    fs_k_iterate_eager    8 x 64x64 episodes
+    fs_k_iterate_grid     112 x 64x64 distinct episodes
+    fs_k_iterate<true>    16 x 104x104 episodes (the upper end of the reference's cloth sizes, environment/tasks.py:108-121)
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import bench
+from conftest import cloth_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_runs(setups, steps):
+    """Run one oracle episode per entry of `setups` (callables taking the OracleSim) for `steps` frames, in parallel
+    threads (ctypes releases the GIL around orc_step)."""
+    from oracle import OracleSim
+
+    sims = [OracleSim() for _ in setups]
+
+    def work(k):
+        setups[k](sims[k])
+        sims[k].step(steps)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(setups))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    return sims
+
+
+def _assert_bits(ctx, e, orc, what):
+    ph, po = ctx.get_positions(e), orc.get_positions()
+    vh, vo = ctx.get_velocities(e), orc.get_velocities()
+    assert np.isfinite(po).all()
+    scale = max(1.0, float(np.abs(po).max()))
+    assert np.abs(ph - po).max() <= 1e-4 * scale, f"{what}: positions outside north_star's 1e-4 bar"
+    assert np.array_equal(ph.view(np.uint32), po.view(np.uint32)), \
+        f"{what}: positions not bit-exact (max abs diff {np.abs(ph - po).max():.3e})"
+    assert np.array_equal(vh.view(np.uint32), vo.view(np.uint32)), \
+        f"{what}: velocities not bit-exact (max abs diff {np.abs(vh - vo).max():.3e})"
+
+
+def _bench_batch(n_envs, solver, steps, sample, expect_form):
+    from flingbot_amd import sim as fsim
+
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=solver)
+    for e in range(n_envs):
+        bench.setup_episode(ctx.env(e), seed=e)  # exactly the episodes bench.py times
+    ctx.step(steps)  # one launch (fused) / one launch sequence (streaming) for all episodes
+    assert ctx.last_kernel_form() == expect_form, ctx.last_kernel_form()
+    orcs = _oracle_runs([lambda o, s=s: bench.setup_episode(o, seed=s) for s in sample], steps)
+    for s, o in zip(sample, orcs):
+        _assert_bits(ctx, s, o, f"{n_envs} episodes, form {expect_form}, episode {s}")
+    co, _ = orcs[0].get_last_neighbors()
+    ctx.close()
+    return int(co.sum())
+
+
+@pytest.mark.parametrize("n_envs", [8, 256])
+def test_fused_kernel_bench_batch_bit_exact(gpu_required, n_envs):
+    """The bench configuration itself: `n_envs` distinct-seed 64x64 episodes of bench.py's workload in ONE launch of
+    fs_k_fused_step<12> (256 = one workgroup per CU); first, second, middle and last episode equal the oracle after 40
+    frames (free fall, ground contact with friction, the lower rows folding onto each other)."""
+    from flingbot_amd import sim as fsim
+
+    sample = sorted({0, 1, n_envs // 2, n_envs - 1})
+    contacts = _bench_batch(n_envs, fsim.FS_SOLVER_FUSED, 40, sample, fsim.FS_FORM_FUSED_12)
+    assert contacts > 50, "the sampled episode must have particle contacts"
+
+
+def test_fused_generic_kernel_batch_bit_exact(gpu_required):
+    """fs_k_fused_step<0> (adjacency streamed from the ELL arrays instead of the register-resident codes)."""
+    from flingbot_amd import sim as fsim
+
+    _bench_batch(9, fsim.FS_SOLVER_FUSED_GENERIC, 30, [0, 4, 8], fsim.FS_FORM_FUSED_GENERIC)
+
+
+def _deg16_mesh(nx, nz, sp=0.00625):
+    """Grid sheet through the MESH path of set_scene (softgym_cloth.h:69-132) with 3-hop springs added to the bend list:
+    4 stretch + 4 shear + 4 two-hop + 4 three-hop = 16 springs per interior particle."""
+    verts = np.array([[x * sp, 0.0, z * sp] for z in range(nz) for x in range(nx)], np.float32)
+    idx = lambda x, z: z * nx + x
+    faces, stretch, bend, shear = [], [], [], []
+    for z in range(nz):
+        for x in range(nx):
+            if x + 1 < nx: stretch.append((idx(x, z), idx(x + 1, z)))
+            if z + 1 < nz: stretch.append((idx(x, z), idx(x, z + 1)))
+            for hop in (2, 3):
+                if x + hop < nx: bend.append((idx(x, z), idx(x + hop, z)))
+                if z + hop < nz: bend.append((idx(x, z), idx(x, z + hop)))
+            if x + 1 < nx and z + 1 < nz:
+                shear.append((idx(x, z), idx(x + 1, z + 1)))
+                shear.append((idx(x + 1, z), idx(x, z + 1)))
+                faces.append((idx(x, z), idx(x + 1, z), idx(x + 1, z + 1)))
+                faces.append((idx(x, z), idx(x + 1, z + 1), idx(x, z + 1)))
+    return [verts.ravel()] + [np.array(a, np.int32).ravel() for a in (stretch, bend, shear, faces)]
+
+
+def test_fused_16_slot_kernel_bit_exact(gpu_required):
+    """fs_k_fused_step<16>: a cloth with 13..16 springs per particle keeps the coded adjacency in 16 register slots."""
+    from flingbot_amd import sim as fsim
+
+    mesh = _deg16_mesh(40, 36)
+    p = cloth_params(0, 0, pos=(0.0, -0.06, 0.0), mass=0.3)
+    n_envs = 3
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=fsim.FS_SOLVER_FUSED)
+
+    def setup(sim, seed):
+        sim.set_scene(p, *mesh)
+        rng = np.random.RandomState(seed)
+        pos = sim.get_positions().reshape(-1, 4).copy()
+        pos[:, :3] += (rng.rand(pos.shape[0], 3).astype(np.float32) - 0.5) * 0.004
+        pos[: 300, 1] += 0.02  # a flap above the sheet: falls onto it
+        pos[: 300, 0] += 0.05
+        sim.set_positions(pos.ravel())
+
+    for e in range(n_envs):
+        setup(ctx.env(e), e)
+    ctx.step(30)
+    assert ctx.last_kernel_form() == fsim.FS_FORM_FUSED_16
+    orcs = _oracle_runs([lambda o, s=s: setup(o, s) for s in range(n_envs)], 30)
+    for e in range(n_envs):
+        _assert_bits(ctx, e, orcs[e], f"16-slot fused kernel, episode {e}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("solver,form", [(0, "FS_FORM_STREAM_CODED"), (4, "FS_FORM_STREAM_ELL")])
+def test_streaming_64_episode_launch_bit_exact(gpu_required, solver, form):
+    """BASELINE.json configs[2] (and configs[3]'s per-GPU share): 64 distinct 64x64 episodes in one launch sequence.
+    AUTO routes that size to the streaming back-end's throughput form fs_k_iterate<true> (one-byte spring codes);
+    FS_SOLVER_STREAM_ELL runs fs_k_iterate<false> at the same size."""
+    from flingbot_amd import sim as fsim
+
+    contacts = _bench_batch(64, solver, 40, [0, 1, 31, 63], getattr(fsim, form))
+    assert contacts > 50
+
+
+def test_streaming_small_and_large_launch_forms_bit_exact(gpu_required):
+    """The other two forms the launch size selects, on distinct episodes: fs_k_iterate_eager (8 episodes) and
+    fs_k_iterate_grid (112 episodes >= 96 x 4096 particles)."""
+    from flingbot_amd import sim as fsim
+
+    _bench_batch(8, fsim.FS_SOLVER_STREAM, 40, [0, 7], fsim.FS_FORM_STREAM_EAGER)
+    _bench_batch(112, fsim.FS_SOLVER_STREAM, 30, [0, 55, 111], fsim.FS_FORM_STREAM_GRID)
+
+
+def test_large_cloth_104_batch_bit_exact(gpu_required):
+    """16 episodes of a 104x104 cloth (10 816 particles each: the upper end of the reference's task sizes,
+    environment/tasks.py:108-121), loose heaps so the neighbour lists are long; AUTO -> streaming, throughput form."""
+    from flingbot_amd import sim as fsim
+
+    n_envs, dim, steps = 16, 104, 10
+    p = cloth_params(dim, dim, pos=(0.0, -0.15, 0.0))
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=fsim.FS_SOLVER_AUTO)
+
+    def setup(sim, seed):
+        sim.set_scene(p)
+        rng = np.random.RandomState(100 + seed)
+        pos = sim.get_positions().reshape(-1, 4).copy()
+        pos[:, :3] += (rng.randn(pos.shape[0], 3) * 0.003).astype(np.float32)
+        k = 2500
+        pos[:k, :3] = (rng.rand(k, 3) * [0.12, 0.05, 0.12] + [0.0, 0.02, 0.0]).astype(np.float32)  # a heap on the ground
+        sim.set_positions(pos.ravel())
+
+    for e in range(n_envs):
+        setup(ctx.env(e), e)
+    ctx.step(steps)
+    assert ctx.last_kernel_form() == fsim.FS_FORM_STREAM_CODED
+    sample = [0, 9, 15]
+    orcs = _oracle_runs([lambda o, s=s: setup(o, s) for s in sample], steps)
+    for s, o in zip(sample, orcs):
+        _assert_bits(ctx, s, o, f"104x104 episode {s}")
+    co, _ = orcs[0].get_last_neighbors()
+    assert co.max() > 16, "the heap must produce long neighbour lists"
+    ctx.close()
