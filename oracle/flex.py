@@ -29,28 +29,36 @@ def oracle_lib_path():
     return os.path.join(_HERE, "liboracle_fma.so" if _cpu_has_fma() else "liboracle.so")
 
 
+# bounding builds of the same step (oracle/Makefile): plain IEEE arithmetic, and each arithmetic choice alone.  Tests use
+# them to measure how far the default oracle's spelled-out approximations move a step; they are never the parity oracle.
+VARIANTS = ("exact", "exact_rsqrt", "nofma")
+
+
 def build_oracle(force=False):
     """Compile liboracle.so (gcc) and, when /root/reference is present, oracle/_ref."""
     srcs = [os.path.join(_HERE, f) for f in ("flex_oracle.c", "flex_oracle.h", "raster_oracle.c", "Makefile")]
     lib = oracle_lib_path()
     stale = force or not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs)
+    stale = stale or any(not os.path.exists(os.path.join(_HERE, f"liboracle_{v}.so")) for v in VARIANTS)
     if stale:
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so", "liboracle_fma.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so", "liboracle_fma.so"] +
+                              [f"liboracle_{v}.so" for v in VARIANTS])
     if os.path.isdir("/root/reference/PyFlex/core") and os.path.exists(os.path.join(_HERE, "ref_camera_probe.cpp")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "_ref/camera_ref"])
     return lib
 
 
-_lib = None
+_libs = {}
 
 
-def _load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(oracle_lib_path()):
+def _load(variant=None):
+    if variant in _libs:
+        return _libs[variant]
+    assert variant is None or variant in VARIANTS, variant
+    path = oracle_lib_path() if variant is None else os.path.join(_HERE, f"liboracle_{variant}.so")
+    if not os.path.exists(path):
         build_oracle()
-    lib = C.CDLL(oracle_lib_path())
+    lib = C.CDLL(path)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
     lib.orc_create.restype = vp
     lib.orc_destroy.argtypes = [vp]
@@ -68,7 +76,7 @@ def _load():
     lib.orc_add_sphere.argtypes = [vp, C.c_float, fp, fp]
     lib.orc_clear_shapes.argtypes = [vp]
     lib.orc_get_last_neighbors.argtypes = [vp, ip, ip]
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
@@ -91,8 +99,9 @@ def _ip(a):
 class OracleSim:
     """One cloth episode on the CPU oracle, pyflex-shaped methods."""
 
-    def __init__(self):
-        self.lib = _load()
+    def __init__(self, variant=None):
+        """variant: None = THE oracle; "exact" / "exact_rsqrt" / "nofma" = the bounding builds (VARIANTS)."""
+        self.lib = _load(variant)
         self.h = self.lib.orc_create()
 
     def __del__(self):

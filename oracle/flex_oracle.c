@@ -399,22 +399,44 @@ static void find_neighbors(orc_sim *s) {
    approximation out in basic IEEE operations makes the result a pure function of mul/fma, identical on the CPU and on
    the GPU without libm square roots or divide sequences. */
 #include <stdint.h>
+/* Build switches for BOUNDING these two [I] arithmetic choices (tests/test_oracle_cpu.py::test_approximations_stay_within_1e-4
+   of exact math; never used as the parity oracle):
+     -DORC_EXACT_RSQRT  lengths through correctly rounded sqrtf() and IEEE divisions instead of the Newton reciprocal root
+     -DORC_NO_FMA       every multiply-add rounded twice (a*b, then +c), as a compiler without contraction emits it
+     -DORC_EXACT_MATH   both: the plain IEEE restatement of the same step */
+#ifdef ORC_EXACT_MATH
+#define ORC_EXACT_RSQRT 1
+#define ORC_NO_FMA 1
+#endif
+#ifdef ORC_NO_FMA
+#define ORC_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define ORC_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+#ifdef ORC_EXACT_RSQRT
+static inline float orc_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#define ORC_LEN(l2, inv) ((void)(inv), sqrtf(l2))            /* |e| */
+#define ORC_OVER_LEN(a, len, inv) ((void)(inv), (a) / (len)) /* a / |e| */
+#else
 static inline float orc_rsqrt(float x) {
     union { float f; uint32_t u; } v;
     v.f = x;
     v.u = 0x5f3759dfu - (v.u >> 1);
     float y = v.f;
     const float xh = 0.5f * x;
-    y = y * fmaf(-(xh * y), y, 1.5f);
-    y = y * fmaf(-(xh * y), y, 1.5f);
-    y = y * fmaf(-(xh * y), y, 1.5f);
+    y = y * ORC_FMA(-(xh * y), y, 1.5f);
+    y = y * ORC_FMA(-(xh * y), y, 1.5f);
+    y = y * ORC_FMA(-(xh * y), y, 1.5f);
     return y;
 }
+#define ORC_LEN(l2, inv) ((l2) * (inv))
+#define ORC_OVER_LEN(a, len, inv) ((a) * (inv))
+#endif
 
 /* a . b with two fused multiply-adds -- the constraint sweeps use fmaf exactly where the specification says so (the
    build keeps -ffp-contract=off, so nothing else is ever fused); the HIP kernels use v_fma_f32 at the same places. */
 static inline float dot3(float ax, float ay, float az, float bx, float by, float bz) {
-    return fmaf(az, bz, fmaf(ay, by, ax * bx));
+    return ORC_FMA(az, bz, ORC_FMA(ay, by, ax * bx));
 }
 
 /* friction on a contact: t = tangential relative displacement since substep start (length tl = tl2 * inv_tl),
@@ -423,7 +445,7 @@ static inline float dot3(float ax, float ay, float az, float bx, float by, float
 static inline float friction_scale(float tl, float inv_tl, float pen, float mu_s, float mu_k) {
     if (tl < mu_s * pen) return 1.0f;
     float lim = mu_k * pen;
-    return (tl > lim) ? lim * inv_tl : 1.0f;
+    return (tl > lim) ? ORC_OVER_LEN(lim, tl, inv_tl) : 1.0f;
 }
 
 static void substep(orc_sim *s, int sub, float h, float inv_h) {
@@ -483,14 +505,14 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
                 float l2 = dot3(ex, ey, ez, ex, ey, ez);
                 float inv_len = orc_rsqrt(l2);
-                float len = l2 * inv_len;
+                float len = ORC_LEN(l2, inv_len);
                 if (!(len > 0.0f)) continue;
                 float C = len - s->slen[e];
                 float k = s->sk[e];
                 if (k < 0.0f) { if (!(C > 0.0f)) continue; k = -k; } /* tether: unilateral */
                 float ratio = wi / (wi + wj);
-                float sc_ = (k * ratio) * (C * inv_len);
-                d0 = fmaf(-ex, sc_, d0); d1 = fmaf(-ey, sc_, d1); d2 = fmaf(-ez, sc_, d2);
+                float sc_ = (k * ratio) * ORC_OVER_LEN(C, len, inv_len);
+                d0 = ORC_FMA(-ex, sc_, d0); d1 = ORC_FMA(-ey, sc_, d1); d2 = ORC_FMA(-ez, sc_, d2);
                 cnt++;
             }
             /* 4b. particle-particle contacts (NvFlex.h:101 solidRestDistance, :107 particleFriction, :108 inelastic) */
@@ -502,9 +524,9 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float l2 = dot3(ex, ey, ez, ex, ey, ez);
                 if (!(l2 < restd2)) continue;
                 float inv = orc_rsqrt(l2);
-                float dist = l2 * inv;
+                float dist = ORC_LEN(l2, inv);
                 float nx, ny, nz;
-                if (dist > 0.0f) { nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
                 else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
                 float pen = restd - dist;
                 float ratio = wi / (wi + wj);
@@ -515,13 +537,13 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                     float ry = ri1 - (xp[4 * j + 1] - x0[4 * j + 1]);
                     float rz = ri2 - (xp[4 * j + 2] - x0[4 * j + 2]);
                     float rn = dot3(rx, ry, rz, nx, ny, nz);
-                    float tx = fmaf(-nx, rn, rx), ty = fmaf(-ny, rn, ry), tz = fmaf(-nz, rn, rz);
+                    float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
                     float tl2 = dot3(tx, ty, tz, tx, ty, tz);
                     if (tl2 > 0.0f) {
                         float inv_tl = orc_rsqrt(tl2);
-                        float tl = tl2 * inv_tl;
+                        float tl = ORC_LEN(tl2, inv_tl);
                         float fs = friction_scale(tl, inv_tl, pen, p->particleFriction, p->particleFriction) * ratio;
-                        c0 = fmaf(-tx, fs, c0); c1 = fmaf(-ty, fs, c1); c2 = fmaf(-tz, fs, c2);
+                        c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
                     }
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
@@ -535,13 +557,13 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float pen = cd - sdist;
                 float c0 = pl[0] * pen, c1 = pl[1] * pen, c2 = pl[2] * pen;
                 float rn = dot3(ri0, ri1, ri2, pl[0], pl[1], pl[2]);
-                float tx = fmaf(-pl[0], rn, ri0), ty = fmaf(-pl[1], rn, ri1), tz = fmaf(-pl[2], rn, ri2);
+                float tx = ORC_FMA(-pl[0], rn, ri0), ty = ORC_FMA(-pl[1], rn, ri1), tz = ORC_FMA(-pl[2], rn, ri2);
                 float tl2 = dot3(tx, ty, tz, tx, ty, tz);
                 if (tl2 > 0.0f) {
                     float inv_tl = orc_rsqrt(tl2);
-                    float tl = tl2 * inv_tl;
+                    float tl = ORC_LEN(tl2, inv_tl);
                     float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
-                    c0 = fmaf(-tx, fs, c0); c1 = fmaf(-ty, fs, c1); c2 = fmaf(-tz, fs, c2);
+                    c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
                 cnt++;
@@ -553,21 +575,21 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
                 float lim = s->sh_radius[q] + cd;
                 if (!(l2 < lim * lim)) continue;
                 float inv = orc_rsqrt(l2);
-                float dist = l2 * inv;
+                float dist = ORC_LEN(l2, inv);
                 float nx, ny, nz;
-                if (dist > 0.0f) { nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
                 else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
                 float pen = lim - dist;
                 float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
                 float rx = ri0 - sd[q][0], ry = ri1 - sd[q][1], rz = ri2 - sd[q][2];
                 float rn = dot3(rx, ry, rz, nx, ny, nz);
-                float tx = fmaf(-nx, rn, rx), ty = fmaf(-ny, rn, ry), tz = fmaf(-nz, rn, rz);
+                float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
                 float tl2 = dot3(tx, ty, tz, tx, ty, tz);
                 if (tl2 > 0.0f) {
                     float inv_tl = orc_rsqrt(tl2);
-                    float tl = tl2 * inv_tl;
+                    float tl = ORC_LEN(tl2, inv_tl);
                     float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
-                    c0 = fmaf(-tx, fs, c0); c1 = fmaf(-ty, fs, c1); c2 = fmaf(-tz, fs, c2);
+                    c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
                 }
                 d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
                 cnt++;
@@ -575,7 +597,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
             /* 4e. applyDeltas, eNvFlexRelaxationLocal: delta / constraint count * relaxationFactor */
             if (cnt > 0) {
                 float sc_ = p->relaxationFactor / (float)cnt;
-                xn[4 * i] = fmaf(d0, sc_, xi0); xn[4 * i + 1] = fmaf(d1, sc_, xi1); xn[4 * i + 2] = fmaf(d2, sc_, xi2);
+                xn[4 * i] = ORC_FMA(d0, sc_, xi0); xn[4 * i + 1] = ORC_FMA(d1, sc_, xi1); xn[4 * i + 2] = ORC_FMA(d2, sc_, xi2);
             } else { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; }
             xn[4 * i + 3] = wi;
         }
