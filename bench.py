@@ -285,7 +285,7 @@ def run_rank(args):
         kern_ms = kern_ms_total / args.steps
         achieved = BYTES_PER_STEP * E / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source = traffic_from_profile(E)
-        fused = form in (fsim.FS_FORM_FUSED_12, fsim.FS_FORM_FUSED_16, fsim.FS_FORM_FUSED_GENERIC)
+        fused = form in (fsim.FS_FORM_FUSED_12, fsim.FS_FORM_FUSED_16, fsim.FS_FORM_FUSED_GENERIC, fsim.FS_FORM_FUSED_GRID64)
         out = {
             "metric": "sim steps/sec (64x64-particle cloth)",
             "value": value,
@@ -311,7 +311,8 @@ def run_rank(args):
                          "basis": "equivalent streamed bandwidth: ALGORITHMIC bytes of SURVEY 8(d)'s streaming model per "
                                   "launch / HIP-event kernel time; the fused kernel keeps the iterations in LDS, so its "
                                   "HBM traffic (`traffic`) is far below this and `limiter` names what bounds it",
-                         "kernel": "fs_k_fused_step" if fused else "fs_k_iterate (+stage kernels)",
+                         "kernel": ("fs_k_fused_grid64" if form == fsim.FS_FORM_FUSED_GRID64 else "fs_k_fused_step") if fused
+                                   else "fs_k_iterate (+stage kernels)",
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_STEP * E},
             "mean_coverage": float(cov_all.mean().item()),
         }
@@ -337,7 +338,7 @@ def run_rank(args):
                      "baseline_config": "configs[2]" + (" / configs[3] at 8 GPUs" if world == 8 else ""),
                      "value": rate2, "unit": "sim steps/s", "episodes_per_gpu": E2, "steps": K2, "warmup": W2,
                      "ms_per_step": el2 / K2 * 1e3, "gpu_ms_per_step": k2_ms / K2,
-                     "solver": "stream (AUTO)" if form2 >= fsim.FS_FORM_STREAM_EAGER else "fused (AUTO)",
+                     "solver": "stream (AUTO)" if fsim.FS_FORM_STREAM_EAGER <= form2 <= fsim.FS_FORM_STREAM_GRID else "fused (AUTO)",
                      "kernel_form": int(form2),
                      "roofline_frac_equivalent": BYTES_PER_STEP * E2 / (k2_ms / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "mean_coverage": float(cov2.mean().item())}

@@ -1,0 +1,590 @@
+// fs_fused_grid_kernel.h -- fused LDS-resident solver, specialised for grid cloths that are 64 particles wide.
+//
+// Same frame structure, same arithmetic and the same bits as fs_k_fused_step (fs_fused_kernel.h: one 1024-thread
+// workgroup per episode, predict -> hash -> two-phase neighbour search -> contact set -> 30 Jacobi iterations ->
+// finalize, everything resident in LDS); what changes is how the SPRINGS of an iteration are evaluated -- 2/3 of the
+// VALU instructions of the frame.  A 64-wide grid maps one cloth ROW onto one wavefront (lane = column), and the
+// reference's task sizes make the 64 x 64 cloth the one that fits this kernel (environment/tasks.py:108-121: sides
+// 64..104), so that case gets its own code:
+//
+//   * No adjacency.  The neighbour of slot s is (column + dx_s, row + dz_s) of the canonical CreateSpringGrid list
+//     (FS_G64_DX_LIST / FS_G64_DZ_LIST, helpers.h:838-924; the host verifies the cloth against it): dz is an IMMEDIATE
+//     offset of the LDS read, dx one of five address registers.  The 24 adjacency dwords per particle and iteration,
+//     their registers and their address arithmetic are gone.
+//   * Positions are SoA planes in LDS (x | y | z | invMass, 16 KiB each).  The thread's particles are rows w, w+16,
+//     w+32, w+48; rows 16 apart are 16 x 256 B apart, so ONE ds_read2st64_b32 returns the same neighbour slot of TWO
+//     of the thread's particles in a register PAIR -- the operand shape of the packed-fp32 VALU instructions.
+//   * Two particles per trip on v_pk_add/mul/fma_f32: the whole spring (difference, length^2, the spelled-out
+//     reciprocal root, scale, accumulation) is evaluated for both at once, bit for bit the operations of fs_spring in
+//     the same order per particle.  A packed instruction costs ~1.6 scalar ones on this part (scripts/ubench), and two
+//     slots are interleaved per scheduling region to cover its latency.
+//   * No per-spring bookkeeping.  A slot that leaves the grid gets stiffness 0 (its scale becomes +-0, which leaves
+//     the accumulators untouched), the constraint count of a particle is its number of in-grid slots, and the
+//     `length > 0` test of fs_spring -- false only for coincident particles -- is a minimum over the squared lengths
+//     checked once per pair; if it ever fires, or a wave sees a neighbour of different mass (picked particle), the pair
+//     takes the exact general path (ELL adjacency, fs_spring).
+// Rest lengths: x-direction slots depend on the column only (4 registers per thread), z-direction ones on the row only
+// (a 1 KiB LDS table), shear ones per particle (16 registers, loaded once per launch) -- verified by the host
+// (build_grid64) because CreateSpringGrid takes them from the fp32 particle positions.
+#pragma once
+#include "fs_fused_kernel.h"
+
+#define FG_PLANE (FS_FUSED_MAX_PARTICLES * 4)  // bytes of one coordinate plane
+#define FG_PAD 1024                            // rows -2, -1 of the gathers of the first cloth rows land here (finite zeros)
+#define FG_OFF_XX FG_PAD
+#define FG_OFF_X0 (FG_OFF_XX + 4 * FG_PLANE)   // X0x | X0y | X0z (bucket-ordered predicted positions during the search)
+#define FG_OFF_CUR (FG_OFF_X0 + 3 * FG_PLANE)
+#define FG_OFF_ITEMS (FG_OFF_CUR + FS_FUSED_BUCKETS * 4)
+#define FG_OFF_SCAN (FG_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
+#define FG_OFF_CSET (FG_OFF_SCAN + 64)
+#define FG_OFF_CACC (FG_OFF_CSET + FS_FUSED_CSET_CAP * 2)
+#define FG_OFF_CHIST (FG_OFF_CACC + FS_FUSED_CSET_CAP * 16)
+#define FG_OFF_ROWL (FG_OFF_CHIST + 512)       // float[4][64]: rest length of the z-direction slots 8..11 per row
+#define FG_OFF_COLL (FG_OFF_ROWL + 1024)       // float[4][64]: rest length of the x-direction slots 0, 1, 4, 5 per column
+#define FG_LDS_BYTES (FG_OFF_COLL + 1024)
+#define FG_PREFETCH_CAND 2                     // contact candidates of a particle fetched ahead (inline path; the heavy
+                                               // particles are in the contact set and finished by pass 2)
+
+struct FgAcc2 {
+    fs_f2 d0, d1, d2;
+    float m0, m1;  // running minimum of the squared lengths (all slots: a slot outside the grid reads unrelated finite
+                   // data, which at worst sends a pair down the exact path for nothing)
+};
+
+// One canonical slot for the pair (P = row r, Q = row r + 16) of the thread: three ds_read2st64_b32, each returning the
+// P and Q halves of one coordinate in a register pair.  `a` = LDS byte address of (row r - 2, column + dx) in the x
+// plane; rows and planes are immediates (offsets count 64 floats = one row; the x | y | z planes are 64 rows apart).
+// Written as inline assembly because the compiler's load merger, given plain loads, pairs whatever two loads it meets
+// first (neighbouring columns, the rows of two different slots) and then shuffles the halves back with v_mov.  The
+// compiler does not know these are LDS reads, so FG_WAIT -- through which the loaded registers are routed, making every
+// consumer depend on it -- carries the s_waitcnt: lgkmcnt(N) with N = number of reads issued AFTER the ones awaited
+// (LDS returns in order, so any further outstanding operation only makes the wait longer, never shorter).
+template <int DZ>
+__device__ __forceinline__ void fg_load_slot(unsigned a, fs_f2 &x0, fs_f2 &x1, fs_f2 &x2) {
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x0) : "v"(a), "n"(DZ + 2), "n"(DZ + 2 + 16) : "memory");
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x1) : "v"(a), "n"(DZ + 2 + 64), "n"(DZ + 2 + 16 + 64) : "memory");
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x2) : "v"(a), "n"(DZ + 2 + 128), "n"(DZ + 2 + 16 + 128) : "memory");
+}
+// (value of row r, value of row r + 16) of a [.][64] table: one ds_read2_b32
+__device__ __forceinline__ fs_f2 fg_load_rows(unsigned a) {
+    fs_f2 r;
+    asm volatile("ds_read2_b32 %0, %1 offset1:16" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ float fg_load1(unsigned a) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
+#define FG_WAIT(N, A0, A1, A2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A0), "+v"(A1), "+v"(A2))
+
+// fs_spring_fast for one canonical slot of both particles of the pair (two independent scalar streams: .x = P, .y = Q).
+// kh = stiffness / 2, or 0 for a slot outside the grid: the scale then is +-0 and the accumulators stay as they are.
+// (A packed version on v_pk_add/mul/fma_f32 -- the (P, Q) register pairs are exactly its operand shape -- was built and
+// measured: bit-identical, 14 % SLOWER.  On this part a packed fp32 instruction occupies the VALU for as long as two
+// scalar ones, so packing buys no throughput and lengthens the dependent chains)
+__device__ __forceinline__ void fg_spring_pq(FgAcc2 &acc, fs_f2 xi0, fs_f2 xi1, fs_f2 xi2, fs_f2 xj0, fs_f2 xj1, fs_f2 xj2, float LP,
+                                             float LQ, float kP, float kQ) {
+    const float ex = xi0.x - xj0.x, fx = xi0.y - xj0.y;
+    const float ey = xi1.x - xj1.x, fy = xi1.y - xj1.y;
+    const float ez = xi2.x - xj2.x, fz = xi2.y - xj2.y;
+    const float l2 = fs_dot3(ex, ey, ez, ex, ey, ez), m2 = fs_dot3(fx, fy, fz, fx, fy, fz);
+    const float inv = fs_rsqrt(l2), jnv = fs_rsqrt(m2);
+    const float len = l2 * inv, men = m2 * jnv;
+    const float C = len - LP, D = men - LQ;
+    const float sc = kP * (C * inv), sd = kQ * (D * jnv);
+    acc.d0.x = FS_FMA(-ex, sc, acc.d0.x); acc.d0.y = FS_FMA(-fx, sd, acc.d0.y);
+    acc.d1.x = FS_FMA(-ey, sc, acc.d1.x); acc.d1.y = FS_FMA(-fy, sd, acc.d1.y);
+    acc.d2.x = FS_FMA(-ez, sc, acc.d2.x); acc.d2.y = FS_FMA(-fz, sd, acc.d2.y);
+    acc.m0 = fminf(acc.m0, l2);
+    acc.m1 = fminf(acc.m1, m2);
+}
+
+__global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEnvDev *__restrict__ envs,
+                                                                      const FsShapesDev *__restrict__ shapes, const int *ids,
+                                                                      int n_steps) {
+    static_assert(FS_FUSED_THREADS == 1024 && FS_FUSED_PPT == 4, "grid-64 kernel: 16 waves x 4 rows");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Xx = (float *)(smem + FG_OFF_XX);
+    float *Xy = Xx + FS_FUSED_MAX_PARTICLES, *Xz = Xy + FS_FUSED_MAX_PARTICLES, *Xw = Xz + FS_FUSED_MAX_PARTICLES;
+    float *X0x = (float *)(smem + FG_OFF_X0);
+    float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
+    float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
+    int *cursor = (int *)(smem + FG_OFF_CUR);
+    unsigned short *items = (unsigned short *)(smem + FG_OFF_ITEMS);
+    int *wave_tot = (int *)(smem + FG_OFF_SCAN);
+    float *rowL = (float *)(smem + FG_OFF_ROWL);
+
+#ifdef FS_TIMING  // developer build: per-section shader-clock totals of block 0's waves, printed at the end (FS_TS)
+    unsigned long long ts_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#endif
+    const int e = ids[blockIdx.x];
+    if (e < 0) return;  // slot retired by a device-side loop (fs_wait_until_stable)
+    const FsEnvDev &E = envs[e];
+    const FsShapesDev &sh = shapes[e];
+    const FsFusedConsts c = fs_fused_consts(E, sh);
+    const int n = c.n;
+    const unsigned un = (unsigned)n;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int dimz = n >> 6;
+
+    FsVec4 *const g_pos = E.pos, *const g_vel = E.vel;
+    const FsVec4 *const g_rest = E.rest;
+    const fs_gci g_phase = (fs_gci)E.phase;
+    const fs_gi g_nlist = (fs_gi)E.nlist, g_ncount = (fs_gi)E.ncount;
+    const fs_gci g_ell_j = (fs_gci)E.ell_j;
+    const fs_gcf g_ell_len = (fs_gcf)E.ell_len, g_ell_k = (fs_gcf)E.ell_k;
+    const fs_gcf g_L = (fs_gcf)E.g64_L;
+    const int max_deg = E.max_deg;
+    const fs_gcu g_near = (fs_gcu)E.restnear_w;
+
+    // one phase for the whole cloth? (see fs_k_fused_step)
+    int find_mode = 0;
+    {
+        const int ph0 = g_phase[0];
+        int differs = 0;
+        for (int i = t; i < n; i += FS_FUSED_THREADS) differs |= (g_phase[i] != ph0);
+        if (t == 0) wave_tot[0] = 0;
+        __syncthreads();
+        if (differs) atomicOr(&wave_tot[0], 1);
+        __syncthreads();
+        const int mixed = wave_tot[0];
+        __syncthreads();
+        if (!mixed) {
+            if (!(ph0 & FS_PHASE_SELF_COLLIDE)) find_mode = 3;
+            else if (!(ph0 & FS_PHASE_SELF_COLLIDE_FILTER)) find_mode = 2;
+            else if (E.restnear_ok) find_mode = 1;
+        }
+    }
+    // Everything a gather can touch holds finite numbers from here on: pad, the four planes (rows past the cloth stay 0).
+    for (int q = t; q < FG_OFF_X0 / 4; q += FS_FUSED_THREADS) ((float *)smem)[q] = 0.0f;
+    __syncthreads();
+    for (int i = t; i < n; i += FS_FUSED_THREADS) {
+        const FsVec4 p = fs_ld4(g_pos, i);
+        Xx[i] = p.x; Xy[i] = p.y; Xz[i] = p.z; Xw[i] = p.w;
+        X0x[i] = p.x; X0y[i] = p.y; X0z[i] = p.z;
+    }
+    // rest lengths.  z-direction slots 8..11 per row -> LDS (taken from column 2, valid for every in-grid slot)
+    if (t < 256) {
+        const int r = t & 63, s = 8 + (t >> 6);
+        rowL[t] = r < dimz ? g_L[(unsigned)s * un + (unsigned)(r * 64 + 2)] : 0.0f;
+    }
+    // x-direction slots 0, 1, 4, 5 per column (taken from row 2; 0 where the column lacks the slot) -> LDS
+    constexpr int XS_SLOT[4] = {0, 1, 4, 5}, XS_DX[4] = {-1, -2, +1, +2};
+    constexpr int SH_SLOT[4] = {2, 3, 6, 7}, SH_DX[4] = {+1, -1, -1, +1}, SH_DZ[4] = {-1, -1, +1, +1};
+    constexpr int ZS_DZ[4] = {-1, -2, +1, +2};
+    float *colL = (float *)(smem + FG_OFF_COLL);
+    if (t < 256) {
+        const int col = t & 63, q = t >> 6;
+        const int dxq = q == 0 ? -1 : (q == 1 ? -2 : (q == 2 ? +1 : +2)), sq = q == 0 ? 0 : (q == 1 ? 1 : (q == 2 ? 4 : 5));
+        colL[t] = (unsigned)(col + dxq) < 64u ? g_L[(unsigned)sq * un + (unsigned)(2 * 64 + col)] : 0.0f;
+    }
+    // stiffness / 2 per slot (wave-uniform)
+    float khv[FS_G64_SLOTS];
+#pragma unroll
+    for (int q = 0; q < FS_G64_SLOTS; ++q) khv[q] = E.g64_kh[q];
+    // number of in-grid slots of each of the thread's particles (8 bits per particle)
+    unsigned nvalid = 0u;
+#pragma unroll
+    for (int k = 0; k < FS_FUSED_PPT; ++k) {
+        const int row = w + 16 * k;
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cnt += ((unsigned)(lane + XS_DX[q]) < 64u) ? 1 : 0;
+            cnt += ((unsigned)(lane + SH_DX[q]) < 64u && (unsigned)(row + SH_DZ[q]) < (unsigned)dimz) ? 1 : 0;
+            cnt += ((unsigned)(row + ZS_DZ[q]) < (unsigned)dimz) ? 1 : 0;
+        }
+        nvalid |= (unsigned)cnt << (8 * k);
+    }
+    __syncthreads();
+    // bit k: every lane's particle k of this wave is dynamic and all its in-grid neighbours carry its own inverse mass
+    // (constant for the launch) -> the packed spring form applies
+    unsigned fastmask = 0u;
+    {
+        constexpr int cdx[FS_G64_SLOTS] = FS_G64_DX_LIST, cdz[FS_G64_SLOTS] = FS_G64_DZ_LIST;
+#pragma unroll
+        for (int k = 0; k < FS_FUSED_PPT; ++k) {
+            const int row = w + 16 * k, i = row * 64 + lane;
+            bool differs = false;
+            if (i < n) {
+                const float wi = Xw[i];
+                differs = !(wi > 0.0f);
+#pragma unroll
+                for (int q = 0; q < FS_G64_SLOTS; ++q) {
+                    const bool in = (unsigned)(lane + cdx[q]) < 64u && (unsigned)(row + cdz[q]) < (unsigned)dimz;
+                    if (in) differs |= Xw[i + cdz[q] * 64 + cdx[q]] != wi;
+                }
+            }
+            if (i < n && __builtin_amdgcn_ballot_w64(differs) == 0ull) fastmask |= 1u << k;
+        }
+    }
+
+    FS_TS(0)
+#pragma unroll 1
+    for (int frame = 0; frame < n_steps; ++frame) {
+#pragma unroll 1
+        for (int sub = 0; sub < c.substeps; ++sub) {
+            // ---- predict from (X0, vel); build the spatial hash (XS = bucket-ordered copy in the X0 region)
+            for (int q = t; q < FS_FUSED_BUCKETS; q += FS_FUSED_THREADS) cursor[q] = 0;
+            FsVec4 xp[FS_FUSED_PPT];
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                const int i = t + k * FS_FUSED_THREADS;
+                xp[k] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (i < n) {
+                    const FsVec4 p0 = FsVec4{X0x[i], X0y[i], X0z[i], Xw[i]};
+                    xp[k] = fs_fused_predict(c, p0, fs_ld4(g_vel, i));
+                    fs_st4(E.x0, i, p0);
+                }
+            }
+            __syncthreads();
+            fs_fused_build_grid(c, xp, cursor, items, wave_tot, X0x, X0y, X0z);
+            FS_TS(1)
+            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode};
+#pragma unroll 1
+            for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
+                const int i = items[qs];
+                FsNearWords near;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
+                const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};
+                g_ncount[i] = find_mode == 3 ? 0
+                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lci)cursor, (fs_lcus)items, g_phase,
+                                                                       g_rest, g_nlist, near,
+                                                                       (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
+            }
+            FS_TS(2)
+            __syncthreads();  // every wave is done with XS, the hash and the queues (which covered the planes)
+            FS_TS(3)
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                const int i = t + k * FS_FUSED_THREADS;
+                if (i < n) {
+                    Xx[i] = xp[k].x; Xy[i] = xp[k].y; Xz[i] = xp[k].z; Xw[i] = xp[k].w;
+                    const FsVec4 p0 = fs_ld4(E.x0, i);
+                    X0x[i] = p0.x; X0y[i] = p0.y; X0z[i] = p0.z;
+                } else {
+                    Xx[i] = 0.0f; Xy[i] = 0.0f; Xz[i] = 0.0f; Xw[i] = 0.0f;  // rows past the cloth: finite again
+                }
+            }
+
+            // ---- contact set (see fs_k_fused_step)
+            unsigned short *cset = (unsigned short *)(smem + FG_OFF_CSET);
+            FsVec4 *cacc = (FsVec4 *)(smem + FG_OFF_CACC);
+            int *chist = (int *)(smem + FG_OFF_CHIST);
+            if (t < 128) chist[t] = 0;
+            __syncthreads();
+            int ccls[FS_FUSED_PPT];
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                const int i = t + k * FS_FUSED_THREADS;
+                int cc = 0;
+                if (i < n && Xw[i] > 0.0f) cc = g_ncount[i];
+                ccls[k] = cc > 96 ? 96 : cc;
+                if (ccls[k] > 0) atomicAdd(&chist[ccls[k]], 1);
+            }
+            __syncthreads();
+            if (t == 0) {
+                int run = 0;
+                for (int q = 96; q >= 1; --q) { const int hq = chist[q]; chist[q] = run; run += hq; }
+                chist[0] = run;
+            }
+            __syncthreads();
+            unsigned long long slotpack = ~0ull;
+#pragma unroll
+            for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                if (ccls[k] > 0) {
+                    const int pos = atomicAdd(&chist[ccls[k]], 1);
+                    if (pos < FS_FUSED_CSET_CAP) {
+                        cset[pos] = (unsigned short)(t + k * FS_FUSED_THREADS);
+                        slotpack = (slotpack & ~(0xffffull << (16 * k))) | ((unsigned long long)pos << (16 * k));
+                    }
+                }
+            }
+            __syncthreads();
+            const int csize = chist[0] < FS_FUSED_CSET_CAP ? chist[0] : FS_FUSED_CSET_CAP;
+            const int i2 = t < csize ? (int)cset[t] : -1;
+            int cnt2 = 0, cj2[FS_FUSED_PREFETCH_CAND];
+#pragma unroll
+            for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = 0;
+            if (i2 >= 0) {
+                cnt2 = g_ncount[i2];
+#pragma unroll
+                for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = g_nlist[(unsigned)q * un + (unsigned)i2];
+            }
+
+            FS_TS(4)
+            // ---- Jacobi iterations
+#pragma unroll 1
+            for (int it = 0; it < c.iters; ++it) {
+                // candidate count + list head of the pair's two particles, requested one pair ahead
+                int cntP, cntQ, cjP[FG_PREFETCH_CAND], cjQ[FG_PREFETCH_CAND];
+                {
+                    unsigned i0 = t < n ? (unsigned)t : 0u, i1 = t + 1024 < n ? (unsigned)(t + 1024) : 0u;
+                    asm volatile("" : "+v"(i0), "+v"(i1));  // keep these iteration-invariant loads inside the loop
+                    cntP = g_ncount[i0];
+                    cntQ = g_ncount[i1];
+#pragma unroll
+                    for (int q = 0; q < FG_PREFETCH_CAND; ++q) {
+                        cjP[q] = g_nlist[(unsigned)q * un + i0];
+                        cjQ[q] = g_nlist[(unsigned)q * un + i1];
+                    }
+                }
+                float rx[FS_FUSED_PPT], ry[FS_FUSED_PPT], rz[FS_FUSED_PPT];  // rotating register file, statically indexed
+#pragma unroll
+                for (int q = 0; q < FS_FUSED_PPT; ++q) { rx[q] = 0.0f; ry[q] = 0.0f; rz[q] = 0.0f; }
+#pragma unroll 1
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int rowP = w + 32 * pr;                  // wave-uniform
+                    const int iP_raw = rowP * 64 + lane, iQ_raw = iP_raw + 1024;
+                    const bool haveP = rowP < dimz, haveQ = rowP + 16 < dimz;
+                    const int iP = haveP ? iP_raw : 0, iQ = haveQ ? iQ_raw : 0;
+                    const bool fast = haveQ && ((fastmask >> (2 * pr)) & 3u) == 3u;
+                    // own positions of the pair
+                    const fs_f2 xi0 = fs_f2{Xx[iP], Xx[iQ]}, xi1 = fs_f2{Xy[iP], Xy[iQ]}, xi2 = fs_f2{Xz[iP], Xz[iQ]};
+                    const fs_f2 wi = fs_f2{Xw[iP], Xw[iQ]};
+                    FsAcc aP = {0.0f, 0.0f, 0.0f, 0}, aQ = {0.0f, 0.0f, 0.0f, 0};
+                    bool exact = !fast;
+                    if (fast) {
+                        // LDS byte address of (row P - 2, column + dx) in the x plane for dx = -2..2
+                        const unsigned am2 = (unsigned)(FG_OFF_XX + ((rowP - 2) * 64 + lane - 2) * 4);
+                        const unsigned am1 = am2 + 4u, a00 = am2 + 8u, ap1 = am2 + 12u, ap2 = am2 + 16u;
+                        // which of the z-reaching slots stay inside the grid, per half (wave-uniform)
+                        const bool zP[4] = {rowP - 1 >= 0, rowP - 2 >= 0, rowP + 1 < dimz, rowP + 2 < dimz};
+                        const bool zQ[4] = {true, true, rowP + 17 < dimz, rowP + 18 < dimz};  // row Q - 2 >= 14
+                        // shear rest lengths of the two particles (per particle: from L2, well ahead of slots 2, 3, 6, 7)
+                        float sLP[4], sLQ[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            sLP[q] = g_L[(unsigned)SH_SLOT[q] * un + (unsigned)iP];
+                            sLQ[q] = g_L[(unsigned)SH_SLOT[q] * un + (unsigned)iQ];
+                        }
+                        // z-direction rest lengths of rows P, Q and x-direction ones of this column: LDS tables, issued
+                        // first so that they are older than every gather below
+                        fs_f2 zL[4];
+                        float cL[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            zL[q] = fg_load_rows((unsigned)(FG_OFF_ROWL + (q * 64 + rowP) * 4));
+                            cL[q] = fg_load1((unsigned)(FG_OFF_COLL + (q * 64 + lane) * 4));
+                        }
+                        // stiffness of the slots that need the column / row to have them (0 = outside the grid)
+#define FG_KX(q) ((unsigned)(lane + XS_DX[q]) < 64u ? khv[XS_SLOT[q]] : 0.0f)
+#define FG_KSP(q) (((unsigned)(lane + SH_DX[q]) < 64u && zP[SH_DZ[q] < 0 ? 0 : 2]) ? khv[SH_SLOT[q]] : 0.0f)
+#define FG_KSQ(q) (((unsigned)(lane + SH_DX[q]) < 64u && zQ[SH_DZ[q] < 0 ? 0 : 2]) ? khv[SH_SLOT[q]] : 0.0f)
+#define FG_KZP(q) (zP[q] ? khv[8 + q] : 0.0f)
+#define FG_KZQ(q) (zQ[q] ? khv[8 + q] : 0.0f)
+                        FgAcc2 a = {(fs_f2)(0.0f), (fs_f2)(0.0f), (fs_f2)(0.0f), 1.0f, 1.0f};
+                        fs_f2 u0, u1, u2, v0, v1, v2;
+                        // canonical order; the gathers of slot s + 1 are issued before the arithmetic of slot s
+                        fg_load_slot<0>(am1, u0, u1, u2);                                   // s0 (-1, 0)
+                        fg_load_slot<0>(am2, v0, v1, v2);                                   // s1 (-2, 0)
+                        FG_WAIT(3, u0, u1, u2);
+                        asm volatile("" : "+v"(zL[0]), "+v"(zL[1]), "+v"(zL[2]), "+v"(zL[3]), "+v"(cL[0]), "+v"(cL[1]), "+v"(cL[2]),
+                                     "+v"(cL[3]));  // the tables (older than s0) are complete as well
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, cL[0], cL[0], FG_KX(0), FG_KX(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<-1>(ap1, u0, u1, u2);                                  // s2 (+1, -1)
+                        FG_WAIT(3, v0, v1, v2);
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, cL[1], cL[1], FG_KX(1), FG_KX(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<-1>(am1, v0, v1, v2);                                  // s3 (-1, -1)
+                        FG_WAIT(3, u0, u1, u2);
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, sLP[0], sLQ[0], FG_KSP(0), FG_KSQ(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<0>(ap1, u0, u1, u2);                                   // s4 (+1, 0)
+                        FG_WAIT(3, v0, v1, v2);
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, sLP[1], sLQ[1], FG_KSP(1), FG_KSQ(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<0>(ap2, v0, v1, v2);                                   // s5 (+2, 0)
+                        FG_WAIT(3, u0, u1, u2);
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, cL[2], cL[2], FG_KX(2), FG_KX(2));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<+1>(am1, u0, u1, u2);                                  // s6 (-1, +1)
+                        FG_WAIT(3, v0, v1, v2);
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, cL[3], cL[3], FG_KX(3), FG_KX(3));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<+1>(ap1, v0, v1, v2);                                  // s7 (+1, +1)
+                        FG_WAIT(3, u0, u1, u2);
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, sLP[2], sLQ[2], FG_KSP(2), FG_KSQ(2));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<-1>(a00, u0, u1, u2);                                  // s8 (0, -1)
+                        FG_WAIT(3, v0, v1, v2);
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, sLP[3], sLQ[3], FG_KSP(3), FG_KSQ(3));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<-2>(a00, v0, v1, v2);                                  // s9 (0, -2)
+                        FG_WAIT(3, u0, u1, u2);
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, zL[0].x, zL[0].y, FG_KZP(0), FG_KZQ(0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<+1>(a00, u0, u1, u2);                                  // s10 (0, +1)
+                        FG_WAIT(3, v0, v1, v2);
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, zL[1].x, zL[1].y, FG_KZP(1), FG_KZQ(1));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fg_load_slot<+2>(a00, v0, v1, v2);                                  // s11 (0, +2)
+                        FG_WAIT(3, u0, u1, u2);
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, zL[2].x, zL[2].y, FG_KZP(2), FG_KZQ(2));
+                        __builtin_amdgcn_sched_barrier(0);
+                        FG_WAIT(0, v0, v1, v2);
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, zL[3].x, zL[3].y, FG_KZP(3), FG_KZQ(3));
+                        __builtin_amdgcn_sched_barrier(0);
+#undef FG_KX
+#undef FG_KSP
+#undef FG_KSQ
+#undef FG_KZP
+#undef FG_KZQ
+                        // a coincident pair of particles (squared length 0) takes the exact path instead
+                        exact = __builtin_amdgcn_ballot_w64(a.m0 == 0.0f || a.m1 == 0.0f) != 0ull;
+                        aP = FsAcc{a.d0.x, a.d1.x, a.d2.x, (int)((nvalid >> (16 * pr)) & 0xffu)};
+                        aQ = FsAcc{a.d0.y, a.d1.y, a.d2.y, (int)((nvalid >> (16 * pr + 8)) & 0xffu)};
+                    }
+                    if (exact) {  // general form: the particle's ELL adjacency, fs_spring (any masses, zero lengths)
+                        aP = FsAcc{0.0f, 0.0f, 0.0f, 0};
+                        aQ = FsAcc{0.0f, 0.0f, 0.0f, 0};
+                        if (haveP && wi.x > 0.0f)
+                            for (int s = 0; s < max_deg; ++s) {
+                                const int j = g_ell_j[(unsigned)s * un + (unsigned)iP];
+                                if (j < 0) break;
+                                fs_spring(aP, xi0.x, xi1.x, xi2.x, wi.x, FsVec4{Xx[j], Xy[j], Xz[j], Xw[j]},
+                                          g_ell_len[(unsigned)s * un + (unsigned)iP], g_ell_k[(unsigned)s * un + (unsigned)iP]);
+                            }
+                        if (haveQ && wi.y > 0.0f)
+                            for (int s = 0; s < max_deg; ++s) {
+                                const int j = g_ell_j[(unsigned)s * un + (unsigned)iQ];
+                                if (j < 0) break;
+                                fs_spring(aQ, xi0.y, xi1.y, xi2.y, wi.y, FsVec4{Xx[j], Xy[j], Xz[j], Xw[j]},
+                                          g_ell_len[(unsigned)s * un + (unsigned)iQ], g_ell_k[(unsigned)s * un + (unsigned)iQ]);
+                            }
+                    }
+                    FS_TS(5)
+                    // candidate heads of the NEXT pair, requested now that the spring block's registers are dead
+                    int cntP_n, cntQ_n, cjP_n[FG_PREFETCH_CAND], cjQ_n[FG_PREFETCH_CAND];
+                    {
+                        const unsigned i0 = iP_raw + 2048 < n ? (unsigned)(iP_raw + 2048) : 0u;
+                        const unsigned i1 = iQ_raw + 2048 < n ? (unsigned)(iQ_raw + 2048) : 0u;
+                        cntP_n = g_ncount[i0];
+                        cntQ_n = g_ncount[i1];
+#pragma unroll
+                        for (int q = 0; q < FG_PREFETCH_CAND; ++q) {
+                            cjP_n[q] = g_nlist[(unsigned)q * un + i0];
+                            cjQ_n[q] = g_nlist[(unsigned)q * un + i1];
+                        }
+                    }
+                    // ---- the rest of the particle (contacts, plane, spheres, applyDeltas) for P, then Q
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = h == 0 ? iP : iQ;
+                        const bool have = h == 0 ? haveP : haveQ;
+                        const float xi0s = h == 0 ? xi0.x : xi0.y, xi1s = h == 0 ? xi1.x : xi1.y, xi2s = h == 0 ? xi2.x : xi2.y;
+                        const float wis = h == 0 ? wi.x : wi.y;
+                        FsAcc a = h == 0 ? aP : aQ;
+                        int cnt = h == 0 ? cntP : cntQ;
+                        int cj[FG_PREFETCH_CAND];
+#pragma unroll
+                        for (int q = 0; q < FG_PREFETCH_CAND; ++q) cj[q] = h == 0 ? cjP[q] : cjQ[q];
+                        float nx = xi0s, ny = xi1s, nz = xi2s;
+                        const unsigned myslot = (unsigned)(slotpack >> (16 * (2 * pr + h))) & 0xffffu;
+                        if (wis > 0.0f && myslot != 0xffffu && have) {
+                            cacc[myslot] = FsVec4{a.d0, a.d1, a.d2, __int_as_float(a.cnt)};  // pass 2 finishes this particle
+                        } else if (wis > 0.0f) {
+                            const float ri0 = xi0s - X0x[i], ri1 = xi1s - X0y[i], ri2 = xi2s - X0z[i];
+#pragma unroll 1
+                            for (int q = 0; q < FG_PREFETCH_CAND && q < cnt; ++q) {
+                                const int j = cj[0];
+#pragma unroll
+                                for (int r = 0; r + 1 < FG_PREFETCH_CAND; ++r) cj[r] = cj[r + 1];
+                                const FsVec4 xj = FsVec4{Xx[j], Xy[j], Xz[j], Xw[j]};
+                                fs_particle_contact(a, xi0s, xi1s, xi2s, wis, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
+                                                    xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+                            }
+                            if (cnt > FG_PREFETCH_CAND) {
+#pragma unroll 1
+                                for (int sq = FG_PREFETCH_CAND; sq < cnt; ++sq) {
+                                    const int j = g_nlist[(unsigned)sq * un + (unsigned)i];
+                                    const FsVec4 xj = FsVec4{Xx[j], Xy[j], Xz[j], Xw[j]};
+                                    fs_particle_contact(a, xi0s, xi1s, xi2s, wis, ri0, ri1, ri2, xj, xj.x - X0x[j],
+                                                        xj.y - X0y[j], xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+                                }
+                            }
+                            fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0s, xi1s, xi2s, ri0, ri1, ri2);
+                            fs_apply(a, c.relax, nx, ny, nz);
+                        }
+#pragma unroll
+                        for (int q = FS_FUSED_PPT - 1; q > 0; --q) { rx[q] = rx[q - 1]; ry[q] = ry[q - 1]; rz[q] = rz[q - 1]; }
+                        rx[0] = nx; ry[0] = ny; rz[0] = nz;
+                    }
+                    FS_TS(6)
+                    cntP = cntP_n;
+                    cntQ = cntQ_n;
+#pragma unroll
+                    for (int q = 0; q < FG_PREFETCH_CAND; ++q) { cjP[q] = cjP_n[q]; cjQ[q] = cjQ_n[q]; }
+                }
+                __syncthreads();
+                FS_TS(7)
+                // ---- pass 2: finish the contact-set particle of this thread
+                float n2x = 0.0f, n2y = 0.0f, n2z = 0.0f;
+                if (i2 >= 0) {
+                    const float xi0 = Xx[i2], xi1 = Xy[i2], xi2 = Xz[i2], wi = Xw[i2];
+                    const FsVec4 pa = cacc[t];
+                    FsAcc a = {pa.x, pa.y, pa.z, __float_as_int(pa.w)};
+                    const float ri0 = xi0 - X0x[i2], ri1 = xi1 - X0y[i2], ri2 = xi2 - X0z[i2];
+                    int cjt[FS_FUSED_PREFETCH_CAND];
+#pragma unroll
+                    for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cj2[q];
+                    for (int s0 = 0; s0 < cnt2; s0 += FS_FUSED_PREFETCH_CAND) {
+                        int cn[FS_FUSED_PREFETCH_CAND];
+#pragma unroll
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) {
+                            const int sn = s0 + FS_FUSED_PREFETCH_CAND + q;
+                            cn[q] = sn < cnt2 ? g_nlist[(unsigned)sn * un + (unsigned)i2] : 0;
+                        }
+#pragma unroll 1
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND && s0 + q < cnt2; ++q) {
+                            const int j = cjt[0];
+#pragma unroll
+                            for (int r = 0; r + 1 < FS_FUSED_PREFETCH_CAND; ++r) cjt[r] = cjt[r + 1];
+                            const FsVec4 xj = FsVec4{Xx[j], Xy[j], Xz[j], Xw[j]};
+                            fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j],
+                                                xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
+                        }
+#pragma unroll
+                        for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cn[q];
+                    }
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    n2x = xi0; n2y = xi1; n2z = xi2;
+                    fs_apply(a, c.relax, n2x, n2y, n2z);
+                }
+                FS_TS(8)
+                __syncthreads();  // every read of the old iterate is done
+                FS_TS(9)
+#pragma unroll
+                for (int q = 0; q < FS_FUSED_PPT; ++q) {  // particle q of the thread sits in slot PPT-1-q
+                    const int i = t + q * FS_FUSED_THREADS;
+                    const bool in_set = ((unsigned)(slotpack >> (16 * q)) & 0xffffu) != 0xffffu;
+                    if (i < n && !in_set) { Xx[i] = rx[FS_FUSED_PPT - 1 - q]; Xy[i] = ry[FS_FUSED_PPT - 1 - q]; Xz[i] = rz[FS_FUSED_PPT - 1 - q]; }
+                }
+                if (i2 >= 0) { Xx[i2] = n2x; Xy[i2] = n2y; Xz[i2] = n2z; }
+                __syncthreads();
+                FS_TS(10)
+            }
+            // ---- finalize
+            for (int i = t; i < n; i += FS_FUSED_THREADS) {
+                const FsVec4 xf = FsVec4{Xx[i], Xy[i], Xz[i], Xw[i]};
+                FsVec4 p0 = FsVec4{X0x[i], X0y[i], X0z[i], xf.w};
+                FsVec4 v = fs_ld4(g_vel, i);
+                fs_fused_finalize(c, p0, v, xf);
+                fs_st4(g_vel, i, v);
+                X0x[i] = p0.x; X0y[i] = p0.y; X0z[i] = p0.z;
+            }
+        }
+    }
+    for (int i = t; i < n; i += FS_FUSED_THREADS) fs_st4(g_pos, i, FsVec4{X0x[i], X0y[i], X0z[i], Xw[i]});
+#ifdef FS_TIMING
+    FS_TS(11)
+    if (blockIdx.x == 0 && (t & 63) == 0)
+        printf("TS wave %2d: init %llu grid %llu find %llu findwait %llu cset %llu springs %llu rest %llu bar1 %llu pass2 %llu bar2 %llu publish %llu final %llu\n",
+               t >> 6, ts_acc[0], ts_acc[1], ts_acc[2], ts_acc[3], ts_acc[4], ts_acc[5], ts_acc[6], ts_acc[7], ts_acc[8],
+               ts_acc[9], ts_acc[10], ts_acc[11]);
+#endif
+}

@@ -32,7 +32,7 @@
 //   X0   float[3][4096] substep-start position (own displacement + neighbours' for friction);
 //                       bucket-ordered predicted positions XS while the search runs                  48 KiB
 //   HASH cursor int[4096] | items u16[4096] | scan int[16]   (neighbour search only)           24 KiB
-//   contact set: cset u16[1024] | cacc float4[1024] | chist int[128]                           18.5 KiB
+//   contact set: cset u16[CAP] | cacc float4[CAP] | chist int[128], CAP = min(1024, threads)   18.5 KiB
 // The next iterate needs no LDS: each thread carries its four new positions in a rotating set of registers.
 // (DICT and X sit below 64 KiB so their bases fold into the 16-bit offset field of the ds_read instructions; the gather
 // addresses are then just the 16-bit halves of the packed adjacency words)
@@ -44,7 +44,7 @@
 #define FS_FUSED_OFF_SCAN (FS_FUSED_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
 // contact set (rebuilt every substep, used by the iterations): ids of up to 1024 particles that have contact candidates,
 // ordered by descending candidate count | their spring accumulators float4[1024] | count histogram / cursors int[128]
-#define FS_FUSED_CSET_CAP 1024
+#define FS_FUSED_CSET_CAP (FS_FUSED_THREADS < 1024 ? FS_FUSED_THREADS : 1024)  // pass 2: thread e finishes cset[e]
 #define FS_FUSED_OFF_CSET (FS_FUSED_OFF_SCAN + 64)
 #define FS_FUSED_OFF_CACC (FS_FUSED_OFF_CSET + FS_FUSED_CSET_CAP * 2)
 #define FS_FUSED_OFF_CHIST (FS_FUSED_OFF_CACC + FS_FUSED_CSET_CAP * 16)
@@ -475,6 +475,13 @@ __device__ __forceinline__ void fs_fused_spring_block(FsAcc &a, const char *smem
     }
 }
 
+// word of the 16-bit slot pack that holds particle k of the thread (k is a run-time value in the rolled particle loop)
+#if FS_FUSED_PPT <= 4
+#define FS_SLOTWORD(sp, k) ((sp)[0])
+#else
+#define FS_SLOTWORD(sp, k) (((k) >> 2) ? (sp)[1] : (sp)[0])
+#endif
+
 // SLOTS > 0: packed (dictionary-coded) adjacency with that many slots (12 or 16); SLOTS == 0: plain ELL adjacency.
 //
 // Register discipline (1024 threads => 128 VGPRs, and every attempt to keep per-particle state of the thread's four
@@ -671,14 +678,18 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 chist[0] = run;
             }
             __syncthreads();
-            unsigned long long slotpack = ~0ull;  // 16-bit set slot of each of the thread's particles, 0xffff = not in the set
+            // 16-bit set slot of each of the thread's particles (four per word), 0xffff = not in the set
+            unsigned long long slotpack[(FS_FUSED_PPT + 3) / 4];
+#pragma unroll
+            for (int q = 0; q < (FS_FUSED_PPT + 3) / 4; ++q) slotpack[q] = ~0ull;
 #pragma unroll
             for (int k = 0; k < FS_FUSED_PPT; ++k) {
                 if (ccls[k] > 0) {
                     const int pos = atomicAdd(&chist[ccls[k]], 1);
                     if (pos < FS_FUSED_CSET_CAP) {
                         cset[pos] = (unsigned short)(t + k * FS_FUSED_THREADS);
-                        slotpack = (slotpack & ~(0xffffull << (16 * k))) | ((unsigned long long)pos << (16 * k));
+                        slotpack[k >> 2] = (slotpack[k >> 2] & ~(0xffffull << (16 * (k & 3)))) |
+                                           ((unsigned long long)pos << (16 * (k & 3)));
                     }
                 }
             }
@@ -760,7 +771,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
                     }
-                    const unsigned myslot = (unsigned)(slotpack >> (16 * k)) & 0xffffu;
+                    const unsigned myslot = (unsigned)(FS_SLOTWORD(slotpack, k) >> (16 * (k & 3))) & 0xffffu;
                     if (xi.w > 0.0f && myslot != 0xffffu && i_raw < n) {
                         cacc[myslot] = FsVec4{a.d0, a.d1, a.d2, __int_as_float(a.cnt)};  // pass 2 finishes this particle
                     } else if (xi.w > 0.0f) {
@@ -845,7 +856,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                 for (int q = 0; q < FS_FUSED_PPT; ++q) {  // particle q of the thread sits in slot PPT-1-q
                     const int i = t + q * FS_FUSED_THREADS;
-                    const bool in_set = ((unsigned)(slotpack >> (16 * q)) & 0xffffu) != 0xffffu;
+                    const bool in_set = ((unsigned)(slotpack[q >> 2] >> (16 * (q & 3))) & 0xffffu) != 0xffffu;
                     if (i < n && !in_set) { FsVec4 &d = X[i]; d.x = rx[FS_FUSED_PPT - 1 - q]; d.y = ry[FS_FUSED_PPT - 1 - q]; d.z = rz[FS_FUSED_PPT - 1 - q]; }
                 }
                 if (i2 >= 0) { FsVec4 &d = X[i2]; d.x = n2x; d.y = n2y; d.z = n2z; }

@@ -249,6 +249,49 @@ void build_grid_pattern(FsHostScene &s, int dimx, int dimz) {
     s.gp_count = cdeg;
 }
 
+// Tables of the grid-64 fused kernel, or g64_ok = 0 when the cloth does not have that structure (see fs_scene.h).
+void build_grid64(FsHostScene &s) {
+    s.g64_ok = 0;
+    s.g64_L.clear();
+    static const int cdx[FS_G64_SLOTS] = FS_G64_DX_LIST, cdz[FS_G64_SLOTS] = FS_G64_DZ_LIST;
+    if (s.gp_count != FS_G64_SLOTS || s.gp_dimx != 64 || s.gp_dimz < 5 || s.gp_dimz > 64) return;
+    for (int q = 0; q < FS_G64_SLOTS; ++q)
+        if (s.gp_dx[q] != cdx[q] || s.gp_dz[q] != cdz[q]) return;
+    const int n = s.n, dimz = s.gp_dimz;
+    std::vector<float> L(size_t(FS_G64_SLOTS) * n, 0.0f);
+    bool have_k[FS_G64_SLOTS] = {false};
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    for (int i = 0; i < n; ++i) {
+        const int ix = i % 64, iz = i / 64;
+        int a = s.adj_off[i];
+        for (int q = 0; q < FS_G64_SLOTS; ++q) {
+            const int jx = ix + cdx[q], jz = iz + cdz[q];
+            if (jx < 0 || jx >= 64 || jz < 0 || jz >= dimz) continue;
+            // build_grid_pattern has verified that adjacency entry `a` is exactly this neighbour
+            const float k = s.adj_k[a];
+            if (!(k > 0.0f) || (k * 0.5f) * 2.0f != k) return;          // tethers / non-halvable stiffness: coded kernel
+            if (have_k[q] && bits(s.g64_k[q]) != bits(k)) return;       // one stiffness per slot
+            s.g64_k[q] = k; have_k[q] = true;
+            L[size_t(q) * n + i] = s.adj_len[a];
+            ++a;
+        }
+    }
+    for (int q = 0; q < FS_G64_SLOTS; ++q)
+        if (!have_k[q]) return;
+    // x-direction slots: one rest length per column (taken from row 2 by the kernel); z-direction slots: one per row
+    for (int i = 0; i < n; ++i) {
+        const int ix = i % 64, iz = i / 64;
+        for (int q = 0; q < FS_G64_SLOTS; ++q) {
+            const int jx = ix + cdx[q], jz = iz + cdz[q];
+            if (jx < 0 || jx >= 64 || jz < 0 || jz >= dimz) continue;
+            if (cdz[q] == 0 && bits(L[size_t(q) * n + i]) != bits(L[size_t(q) * n + 2 * 64 + ix])) return;
+            if (cdx[q] == 0 && bits(L[size_t(q) * n + i]) != bits(L[size_t(q) * n + iz * 64 + 2])) return;
+        }
+    }
+    s.g64_L.swap(L);
+    s.g64_ok = 1;
+}
+
 // Rest-near sets with exactly the device's fp32 test: e = rest_i - rest_j, e.x*e.x + e.y*e.y + e.z*e.z < r*r.
 void build_restnear(FsHostScene &s) {
     const int n = s.n;
@@ -401,6 +444,7 @@ std::string fs_build_scene(FsHostScene &s, const float *sp, int n_params, const 
     build_compact_adjacency(s);
     build_stream_codes(s);
     build_grid_pattern(s, nv > 0 ? 0 : dimx, nv > 0 ? 0 : dimz);
+    build_grid64(s);
     build_restnear(s);
     build_vertex_triangles(s);
     return "";

@@ -56,6 +56,14 @@ struct FsHostScene {
     // no adjacency load in front of them.  gp_count = 0 when the pattern does not hold (meshes, tiny grids).
     int gp_count = 0, gp_dimx = 0, gp_dimz = 0;
     int gp_dx[16] = {0}, gp_dz[16] = {0};
+    // grid-64 form (fused kernel): a dimx == 64 grid cloth (<= 64 rows) whose springs follow the canonical list
+    // FS_G64_DX_LIST / FS_G64_DZ_LIST with a positive, exactly halvable stiffness per slot, whose x-direction rest
+    // lengths (slots with dz == 0) depend on the column only and whose z-direction ones (dx == 0) on the row only --
+    // what lower + spacing * (x, 0, z) in fp32 produces (helpers.h:852).  g64_L: rest lengths [12][n] in canonical slot
+    // order; g64_k: stiffness per slot.
+    int g64_ok = 0;
+    std::vector<float> g64_L;
+    float g64_k[FS_G64_SLOTS] = {0};
     // rest-pose neighbours for the SelfCollideFilter test (NvFlex.h:166,564-565): ids of the particles closer than the
     // interaction radius in the rest pose, 16 slots of 16 bits packed two per word, [8][n], 0xffff = empty.
     // restnear_ok = 0 when some particle has more than 16 of them or n > 65535 (the kernels then test rest positions).

@@ -4,6 +4,7 @@
 #include "../../include/flingsim.h"
 #include "fs_context.h"
 #include "fs_fused_kernel.h"
+#include "fs_fused_grid_kernel.h"
 #include "fs_stream_kernels.h"
 
 #define HIP_TRY(call)                                     \
@@ -96,6 +97,8 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const i
                                     FS_FUSED_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     FS_FUSED_LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_fused_grid64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    FG_LDS_BYTES));
         ctx->fused_attr_set = true;
     }
     // register-resident (dictionary-coded) adjacency when every episode of the launch has one
@@ -105,7 +108,17 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const i
         if (e.dev.dict_size <= 0 || e.host.max_deg > 16) slots = 0;
         else if (e.host.max_deg > 12 && slots == 12) slots = 16;
     }
+    // 64-wide grid cloths (the 64 x 64 cloth of the headline metric): packed two-particle spring form without adjacency
+    bool grid64 = !ctx->force_generic_fused && !ctx->force_coded_fused && slots == 12;
+    for (int id : ids) grid64 = grid64 && ctx->envs[id].dev.g64_ok && ctx->envs[id].dev.p.numPlanes == 1;
     const dim3 grid((unsigned)ids.size()), block(FS_FUSED_THREADS);
+    if (grid64) {
+        ctx->last_form = FS_FORM_FUSED_GRID64;
+        hipLaunchKernelGGL(fs_k_fused_grid64, grid, block, FG_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes, d_ids,
+                           n_steps);
+        HIP_TRY(hipGetLastError());
+        return FS_OK;
+    }
     ctx->last_form = slots == 12 ? FS_FORM_FUSED_12 : (slots == 16 ? FS_FORM_FUSED_16 : FS_FORM_FUSED_GENERIC);
     if (slots == 12)
         hipLaunchKernelGGL(fs_k_fused_step<12>, grid, block, FS_FUSED_LDS_BYTES, ctx->stream, ctx->d_envs, ctx->d_shapes,

@@ -30,6 +30,14 @@ struct FsParams {
     int maxNeighbors, maxContacts, relaxationMode;
 };
 
+// Canonical incident-spring list of an interior particle of CreateSpringGrid (helpers.h:838-924), in spring-id order:
+// row-major pass [stretch x-1, bend x-2, shear (x+1,z-1), shear (x-1,z-1)] seen from both ends, then the column pass
+// [stretch z-1, bend z-2].  The grid-64 fused kernel (fs_fused_grid_kernel.h) hard-wires this order (the dz of a slot
+// is an immediate offset of its LDS gathers); the host verifies that a cloth follows it before selecting that kernel.
+#define FS_G64_SLOTS 12
+#define FS_G64_DX_LIST {-1, -2, +1, -1, +1, +2, -1, +1, 0, 0, 0, 0}
+#define FS_G64_DZ_LIST {0, 0, -1, -1, 0, 0, +1, +1, -1, -2, +1, +2}
+
 struct FsVec4 { float x, y, z, w; };
 struct FsU32x4 { uint32_t x, y, z, w; };
 
@@ -83,6 +91,11 @@ struct FsEnvDev {
     // grid pattern (fs_scene.h): canonical (dx, dz) offsets of a particle's springs in spring-id order; gp_count = 0 = none
     int gp_count, gp_dimx, gp_dimz, gp_pad;
     int gp_dx[16], gp_dz[16];
+    // grid-64 form (fused kernel for dimx == 64 grid cloths, fs_scene.h): rest lengths in canonical slot order,
+    // slot-major [12][n] (0 where the slot leaves the grid), and the per-slot stiffness halved; g64_ok = 0 = unavailable
+    const float *g64_L;
+    float g64_kh[FS_G64_SLOTS];
+    int g64_ok, g64_pad;
     // rest-pose neighbour ids for the SelfCollideFilter test, packed like nbr_w but holding plain particle ids
     const uint32_t *restnear_w;  // [8][n], 0xffff = empty
     int restnear_ok;

@@ -11,7 +11,7 @@ E = 256
 def timed(ctx, n):
     ctx.sync(); ctx.timer_start(); ctx.step(n); return ctx.timer_stop() / n
 
-ctx = fsim.FlingSim(n_envs=E, solver=2)
+ctx = fsim.FlingSim(n_envs=E, solver=int(os.environ.get("FS_SOLVER", "2")))
 for e in range(E):
     env = ctx.env(e); env.set_scene(bench.scene_params())
     w = env.get_positions().reshape(-1, 4)[0, 3]

@@ -7,7 +7,7 @@ import bench
 from flingbot_amd import sim as fsim
 
 E = 256
-ctx = fsim.FlingSim(n_envs=E, solver=2)
+ctx = fsim.FlingSim(n_envs=E, solver=int(os.environ.get("FS_SOLVER", "2")))
 for e in range(E):
     bench.setup_episode(ctx.env(e), e)
 os.environ["FS_QUIET"] = "1"

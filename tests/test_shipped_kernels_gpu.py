@@ -6,7 +6,10 @@ blockIdx > 0) nor the throughput forms of the streaming iterate kernel, which th
 Here every form is launched at a size that selects it -- asserted through the white-box getter fs_last_kernel_form --
 on distinct-seed episodes, and sampled episodes are compared with the CPU oracle bit for bit:
 
-    fs_k_fused_step<12>   8 and 256 episodes of bench.py's own workload (BASELINE.json configs[1] / the bench line)
+    fs_k_fused_grid64     8 and 256 episodes of bench.py's own workload (BASELINE.json configs[1] / the bench line):
+                          what AUTO / FUSED run for 64-wide grid cloths; plus its general path (picked particles,
+                          coincident particles), fewer than 64 rows, and per-type stiffnesses
+    fs_k_fused_step<12>   the same batches with FS_SOLVER_FUSED_CODED (every other cloth that fits the fused kernel)
     fs_k_fused_step<0>    FS_SOLVER_FUSED_GENERIC, 9 episodes
     fs_k_fused_step<16>   a mesh cloth with 16 springs per particle, 3 episodes
     fs_k_iterate<true>    64 x 64x64 episodes, AUTO (BASELINE.json configs[2] and configs[3]'s per-GPU share)
@@ -74,15 +77,100 @@ def _bench_batch(n_envs, solver, steps, sample, expect_form):
 
 
 @pytest.mark.parametrize("n_envs", [8, 256])
-def test_fused_kernel_bench_batch_bit_exact(gpu_required, n_envs):
-    """The bench configuration itself: `n_envs` distinct-seed 64x64 episodes of bench.py's workload in ONE launch of
-    fs_k_fused_step<12> (256 = one workgroup per CU); first, second, middle and last episode equal the oracle after 40
-    frames (free fall, ground contact with friction, the lower rows folding onto each other)."""
+@pytest.mark.parametrize("solver,form", [("FS_SOLVER_FUSED", "FS_FORM_FUSED_GRID64"), ("FS_SOLVER_FUSED_CODED", "FS_FORM_FUSED_12")])
+def test_fused_kernel_bench_batch_bit_exact(gpu_required, n_envs, solver, form):
+    """The bench configuration itself: `n_envs` distinct-seed 64x64 episodes of bench.py's workload in ONE launch of the
+    fused kernel (256 = one workgroup per CU) -- fs_k_fused_grid64, the form a 64-wide grid cloth gets, and
+    fs_k_fused_step<12>, the dictionary-coded form of every other cloth; first, second, middle and last episode equal the
+    oracle after 40 frames (free fall, ground contact with friction, the lower rows folding onto each other)."""
     from flingbot_amd import sim as fsim
 
     sample = sorted({0, 1, n_envs // 2, n_envs - 1})
-    contacts = _bench_batch(n_envs, fsim.FS_SOLVER_FUSED, 40, sample, fsim.FS_FORM_FUSED_12)
+    contacts = _bench_batch(n_envs, getattr(fsim, solver), 40, sample, getattr(fsim, form))
     assert contacts > 50, "the sampled episode must have particle contacts"
+
+
+def test_grid64_kernel_general_paths_bit_exact(gpu_required):
+    """fs_k_fused_grid64 beyond the free sheet: (a) a two-picker fling of a 64x64 cloth -- picked particles have inverse
+    mass 0, so the waves around them leave the equal-mass spring form for the general one (ELL adjacency) while the rest
+    of the cloth stays on the fast one; (b) two particles placed on EXACTLY the same point (squared spring length 0: the
+    spring is skipped and not counted, fs_spring's `length > 0`), which the fast form detects and hands to the general
+    path; (c) a 64 x 40 cloth (rows past the cloth, the pairs whose second row does not exist) with different stretch /
+    bend / shear stiffnesses."""
+    import scenarios as sc
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    # (a)
+    ctx = fsim.FlingSim(n_envs=1, solver=fsim.FS_SOLVER_FUSED)
+    hip, orc = ctx.env(0), OracleSim()
+    ph = sc.scenario_fling(hip, 64, 64, settle_steps=10)
+    assert ctx.last_kernel_form() == fsim.FS_FORM_FUSED_GRID64
+    po = sc.scenario_fling(orc, 64, 64, settle_steps=10)
+    assert ph.picked == po.picked
+    _assert_bits(ctx, 0, orc, "grid64, fling with pickers")
+    ctx.close()
+    # (b)
+    ctx = fsim.FlingSim(n_envs=2, solver=fsim.FS_SOLVER_FUSED)
+    orcs = [OracleSim(), OracleSim()]
+    p = cloth_params(64, 64, pos=(0.0, -0.1, 0.0))
+    for e in range(2):
+        for s_ in (ctx.env(e), orcs[e]):
+            s_.set_scene(p)
+            pos = s_.get_positions().reshape(-1, 4).copy()
+            i = 64 * (20 + 17 * e) + 31
+            pos[i + 1, :3] = pos[i, :3]          # stretch neighbours (i, i+1) coincide
+            pos[i + 64, :3] = pos[i, :3]         # and a z-direction neighbour as well
+            s_.set_positions(pos.ravel())
+    ctx.step(6)
+    assert ctx.last_kernel_form() == fsim.FS_FORM_FUSED_GRID64
+    for e in range(2):
+        orcs[e].step(6)
+        _assert_bits(ctx, e, orcs[e], f"grid64, coincident particles, episode {e}")
+    ctx.close()
+    # (c)
+    ctx = fsim.FlingSim(n_envs=3, solver=fsim.FS_SOLVER_AUTO)
+    ctx.set_solver(fsim.FS_SOLVER_FUSED)
+    orcs = [OracleSim() for _ in range(3)]
+    p = cloth_params(64, 40, pos=(0.1, -0.08, -0.2), stiff=(0.8, 1.0, 0.6), mass=0.3)
+    for e in range(3):
+        rng = np.random.RandomState(40 + e)
+        for s_ in (ctx.env(e), orcs[e]):
+            s_.set_scene(p)
+        pos = orcs[e].get_positions().reshape(-1, 4).copy()
+        pos[:, :3] += (rng.rand(pos.shape[0], 3).astype(np.float32) - 0.5) * 0.004
+        pos[: 64 * 6, 1] += 0.008            # the first six rows lie 8 mm above rows 8..13: particle contacts from
+        pos[: 64 * 6, 2] += 8 * 0.00625      # the first substep on (not rest neighbours: eight rows apart)
+        for s_ in (ctx.env(e), orcs[e]):
+            s_.set_positions(pos.ravel())
+    ctx.step(1)
+    orcs[0].step(1)
+    co, _ = orcs[0].get_last_neighbors()
+    assert co.sum() > 50, "the two layers must be in contact while they are pushed apart"
+    _assert_bits(ctx, 0, orcs[0], "grid64, 64 x 40 cloth, first frame")
+    ctx.step(29)
+    orcs[0].step(29)
+    assert ctx.last_kernel_form() == fsim.FS_FORM_FUSED_GRID64
+    for e in range(3):
+        if e:
+            orcs[e].step(30)
+        _assert_bits(ctx, e, orcs[e], f"grid64, 64 x 40 cloth, episode {e}")
+    ctx.close()
+
+
+def test_grid64_eligibility(gpu_required):
+    """Cloths the grid-64 form must NOT take: tethers (negative stiffness), other widths, meshes -> coded kernel."""
+    from flingbot_amd import sim as fsim
+
+    cases = [(cloth_params(64, 64, stiff=(0.9, -0.6, 0.9)), fsim.FS_FORM_FUSED_12),
+             (cloth_params(32, 64), fsim.FS_FORM_FUSED_12), (cloth_params(63, 64), fsim.FS_FORM_FUSED_12),
+             (cloth_params(64, 64), fsim.FS_FORM_FUSED_GRID64), (cloth_params(64, 5), fsim.FS_FORM_FUSED_GRID64)]
+    for p, form in cases:
+        ctx = fsim.FlingSim(n_envs=1, solver=fsim.FS_SOLVER_FUSED)
+        ctx.set_scene(0, p)
+        ctx.step(1)
+        assert ctx.last_kernel_form() == form, (p[3:8], ctx.last_kernel_form())
+        ctx.close()
 
 
 def test_fused_generic_kernel_batch_bit_exact(gpu_required):
