@@ -41,9 +41,12 @@
 #define FG_OFF_CHIST (FG_OFF_CACC + FS_FUSED_CSET_CAP * 16)
 #define FG_OFF_ROWL (FG_OFF_CHIST + 512)       // float[4][64]: rest length of the z-direction slots 8..11 per row
 #define FG_OFF_COLL (FG_OFF_ROWL + 1024)       // float[4][64]: rest length of the x-direction slots 0, 1, 4, 5 per column
-#define FG_LDS_BYTES (FG_OFF_COLL + 1024)
+#define FG_OFF_RCNT (FG_OFF_COLL + 1024)       // float[128]: relaxationFactor / count, the IEEE quotient fs_apply computes
+#define FG_LDS_BYTES (FG_OFF_RCNT + 512)
+#ifndef FG_PREFETCH_CAND
 #define FG_PREFETCH_CAND 2                     // contact candidates of a particle fetched ahead (inline path; the heavy
                                                // particles are in the contact set and finished by pass 2)
+#endif
 
 struct FgAcc2 {
     fs_f2 d0, d1, d2;
@@ -84,7 +87,7 @@ __device__ __forceinline__ float fg_load1(unsigned a) {
 // measured: bit-identical, 14 % SLOWER.  On this part a packed fp32 instruction occupies the VALU for as long as two
 // scalar ones, so packing buys no throughput and lengthens the dependent chains)
 __device__ __forceinline__ void fg_spring_pq(FgAcc2 &acc, fs_f2 xi0, fs_f2 xi1, fs_f2 xi2, fs_f2 xj0, fs_f2 xj1, fs_f2 xj2, float LP,
-                                             float LQ, float kP, float kQ) {
+                                             float LQ, float kP, float kQ, fs_f2 &lprev, bool fold) {
     const float ex = xi0.x - xj0.x, fx = xi0.y - xj0.y;
     const float ey = xi1.x - xj1.x, fy = xi1.y - xj1.y;
     const float ez = xi2.x - xj2.x, fz = xi2.y - xj2.y;
@@ -96,8 +99,21 @@ __device__ __forceinline__ void fg_spring_pq(FgAcc2 &acc, fs_f2 xi0, fs_f2 xi1, 
     acc.d0.x = FS_FMA(-ex, sc, acc.d0.x); acc.d0.y = FS_FMA(-fx, sd, acc.d0.y);
     acc.d1.x = FS_FMA(-ey, sc, acc.d1.x); acc.d1.y = FS_FMA(-fy, sd, acc.d1.y);
     acc.d2.x = FS_FMA(-ez, sc, acc.d2.x); acc.d2.y = FS_FMA(-fz, sd, acc.d2.y);
-    acc.m0 = fminf(acc.m0, l2);
-    acc.m1 = fminf(acc.m1, m2);
+    // running minimum of the squared lengths, folded every second slot (one v_min3 per half and two slots)
+    if (fold) {
+        acc.m0 = fminf(fminf(acc.m0, lprev.x), l2);
+        acc.m1 = fminf(fminf(acc.m1, lprev.y), m2);
+    } else {
+        lprev = fs_f2{l2, m2};
+    }
+}
+
+// fs_apply with the quotient relaxationFactor / count from the LDS table (the same IEEE division, done once per launch)
+__device__ __forceinline__ void fg_apply(const FsAcc &a, float relax, const float *rcnt, float &x0, float &x1, float &x2) {
+    if (a.cnt > 0) {
+        const float sc = a.cnt < 128 ? rcnt[a.cnt] : relax / (float)a.cnt;
+        x0 = FS_FMA(a.d0, sc, x0); x1 = FS_FMA(a.d1, sc, x1); x2 = FS_FMA(a.d2, sc, x2);
+    }
 }
 
 __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEnvDev *__restrict__ envs,
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
     float *rowL = (float *)(smem + FG_OFF_ROWL);
 
 #ifdef FS_TIMING  // developer build: per-section shader-clock totals of block 0's waves, printed at the end (FS_TS)
-    unsigned long long ts_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ts_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #endif
     const int e = ids[blockIdx.x];
@@ -180,6 +196,10 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
         const int dxq = q == 0 ? -1 : (q == 1 ? -2 : (q == 2 ? +1 : +2)), sq = q == 0 ? 0 : (q == 1 ? 1 : (q == 2 ? 4 : 5));
         colL[t] = (unsigned)(col + dxq) < 64u ? g_L[(unsigned)sq * un + (unsigned)(2 * 64 + col)] : 0.0f;
     }
+    // applyDeltas' relaxationFactor / count for every count a particle can reach (12 springs + 96 contacts + planes +
+    // spheres < 128): the correctly rounded quotient, computed once instead of once per particle and iteration
+    float *rcnt = (float *)(smem + FG_OFF_RCNT);
+    if (t < 128) rcnt[t] = t > 0 ? c.relax / (float)t : 0.0f;
     // stiffness / 2 per slot (wave-uniform)
     float khv[FS_G64_SLOTS];
 #pragma unroll
@@ -335,7 +355,11 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                 float rx[FS_FUSED_PPT], ry[FS_FUSED_PPT], rz[FS_FUSED_PPT];  // rotating register file, statically indexed
 #pragma unroll
                 for (int q = 0; q < FS_FUSED_PPT; ++q) { rx[q] = 0.0f; ry[q] = 0.0f; rz[q] = 0.0f; }
+#ifdef FG_UNROLL_PAIRS
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
                 for (int pr = 0; pr < 2; ++pr) {
                     const int rowP = w + 32 * pr;                  // wave-uniform
                     const int iP_raw = rowP * 64 + lane, iQ_raw = iP_raw + 1024;
@@ -377,57 +401,57 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #define FG_KZP(q) (zP[q] ? khv[8 + q] : 0.0f)
 #define FG_KZQ(q) (zQ[q] ? khv[8 + q] : 0.0f)
                         FgAcc2 a = {(fs_f2)(0.0f), (fs_f2)(0.0f), (fs_f2)(0.0f), 1.0f, 1.0f};
-                        fs_f2 u0, u1, u2, v0, v1, v2;
+                        fs_f2 u0, u1, u2, v0, v1, v2, lp;
                         // canonical order; the gathers of slot s + 1 are issued before the arithmetic of slot s
                         fg_load_slot<0>(am1, u0, u1, u2);                                   // s0 (-1, 0)
                         fg_load_slot<0>(am2, v0, v1, v2);                                   // s1 (-2, 0)
                         FG_WAIT(3, u0, u1, u2);
                         asm volatile("" : "+v"(zL[0]), "+v"(zL[1]), "+v"(zL[2]), "+v"(zL[3]), "+v"(cL[0]), "+v"(cL[1]), "+v"(cL[2]),
                                      "+v"(cL[3]));  // the tables (older than s0) are complete as well
-                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, cL[0], cL[0], FG_KX(0), FG_KX(0));
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, cL[0], cL[0], FG_KX(0), FG_KX(0), lp, false);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<-1>(ap1, u0, u1, u2);                                  // s2 (+1, -1)
                         FG_WAIT(3, v0, v1, v2);
-                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, cL[1], cL[1], FG_KX(1), FG_KX(1));
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, cL[1], cL[1], FG_KX(1), FG_KX(1), lp, true);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<-1>(am1, v0, v1, v2);                                  // s3 (-1, -1)
                         FG_WAIT(3, u0, u1, u2);
-                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, sLP[0], sLQ[0], FG_KSP(0), FG_KSQ(0));
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, sLP[0], sLQ[0], FG_KSP(0), FG_KSQ(0), lp, false);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<0>(ap1, u0, u1, u2);                                   // s4 (+1, 0)
                         FG_WAIT(3, v0, v1, v2);
-                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, sLP[1], sLQ[1], FG_KSP(1), FG_KSQ(1));
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, sLP[1], sLQ[1], FG_KSP(1), FG_KSQ(1), lp, true);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<0>(ap2, v0, v1, v2);                                   // s5 (+2, 0)
                         FG_WAIT(3, u0, u1, u2);
-                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, cL[2], cL[2], FG_KX(2), FG_KX(2));
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, cL[2], cL[2], FG_KX(2), FG_KX(2), lp, false);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<+1>(am1, u0, u1, u2);                                  // s6 (-1, +1)
                         FG_WAIT(3, v0, v1, v2);
-                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, cL[3], cL[3], FG_KX(3), FG_KX(3));
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, cL[3], cL[3], FG_KX(3), FG_KX(3), lp, true);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<+1>(ap1, v0, v1, v2);                                  // s7 (+1, +1)
                         FG_WAIT(3, u0, u1, u2);
-                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, sLP[2], sLQ[2], FG_KSP(2), FG_KSQ(2));
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, sLP[2], sLQ[2], FG_KSP(2), FG_KSQ(2), lp, false);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<-1>(a00, u0, u1, u2);                                  // s8 (0, -1)
                         FG_WAIT(3, v0, v1, v2);
-                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, sLP[3], sLQ[3], FG_KSP(3), FG_KSQ(3));
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, sLP[3], sLQ[3], FG_KSP(3), FG_KSQ(3), lp, true);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<-2>(a00, v0, v1, v2);                                  // s9 (0, -2)
                         FG_WAIT(3, u0, u1, u2);
-                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, zL[0].x, zL[0].y, FG_KZP(0), FG_KZQ(0));
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, zL[0].x, zL[0].y, FG_KZP(0), FG_KZQ(0), lp, false);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<+1>(a00, u0, u1, u2);                                  // s10 (0, +1)
                         FG_WAIT(3, v0, v1, v2);
-                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, zL[1].x, zL[1].y, FG_KZP(1), FG_KZQ(1));
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, zL[1].x, zL[1].y, FG_KZP(1), FG_KZQ(1), lp, true);
                         __builtin_amdgcn_sched_barrier(0);
                         fg_load_slot<+2>(a00, v0, v1, v2);                                  // s11 (0, +2)
                         FG_WAIT(3, u0, u1, u2);
-                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, zL[2].x, zL[2].y, FG_KZP(2), FG_KZQ(2));
+                        fg_spring_pq(a, xi0, xi1, xi2, u0, u1, u2, zL[2].x, zL[2].y, FG_KZP(2), FG_KZQ(2), lp, false);
                         __builtin_amdgcn_sched_barrier(0);
                         FG_WAIT(0, v0, v1, v2);
-                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, zL[3].x, zL[3].y, FG_KZP(3), FG_KZQ(3));
+                        fg_spring_pq(a, xi0, xi1, xi2, v0, v1, v2, zL[3].x, zL[3].y, FG_KZP(3), FG_KZQ(3), lp, true);
                         __builtin_amdgcn_sched_barrier(0);
 #undef FG_KX
 #undef FG_KSP
@@ -471,6 +495,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                             cjQ_n[q] = g_nlist[(unsigned)q * un + i1];
                         }
                     }
+                    FS_TS(12)
                     // ---- the rest of the particle (contacts, plane, spheres, applyDeltas) for P, then Q
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -508,11 +533,12 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                                 }
                             }
                             fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0s, xi1s, xi2s, ri0, ri1, ri2);
-                            fs_apply(a, c.relax, nx, ny, nz);
+                            fg_apply(a, c.relax, rcnt, nx, ny, nz);
                         }
 #pragma unroll
                         for (int q = FS_FUSED_PPT - 1; q > 0; --q) { rx[q] = rx[q - 1]; ry[q] = ry[q - 1]; rz[q] = rz[q - 1]; }
                         rx[0] = nx; ry[0] = ny; rz[0] = nz;
+                        if (h == 0) { FS_TS(13) }
                     }
                     FS_TS(6)
                     cntP = cntP_n;
@@ -553,7 +579,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                     }
                     fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
                     n2x = xi0; n2y = xi1; n2z = xi2;
-                    fs_apply(a, c.relax, n2x, n2y, n2z);
+                    fg_apply(a, c.relax, rcnt, n2x, n2y, n2z);
                 }
                 FS_TS(8)
                 __syncthreads();  // every read of the old iterate is done
@@ -583,8 +609,8 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #ifdef FS_TIMING
     FS_TS(11)
     if (blockIdx.x == 0 && (t & 63) == 0)
-        printf("TS wave %2d: init %llu grid %llu find %llu findwait %llu cset %llu springs %llu rest %llu bar1 %llu pass2 %llu bar2 %llu publish %llu final %llu\n",
-               t >> 6, ts_acc[0], ts_acc[1], ts_acc[2], ts_acc[3], ts_acc[4], ts_acc[5], ts_acc[6], ts_acc[7], ts_acc[8],
-               ts_acc[9], ts_acc[10], ts_acc[11]);
+        printf("TS wave %2d: init %llu grid %llu find %llu findwait %llu cset %llu springs %llu rest %llu bar1 %llu pass2 %llu bar2 %llu publish %llu final %llu | exact+prefetch %llu tailP %llu tailQ %llu\n",
+               t >> 6, ts_acc[0], ts_acc[1], ts_acc[2], ts_acc[3], ts_acc[4], ts_acc[5], ts_acc[6] + ts_acc[12] + ts_acc[13], ts_acc[7], ts_acc[8],
+               ts_acc[9], ts_acc[10], ts_acc[11], ts_acc[12], ts_acc[13], ts_acc[6]);
 #endif
 }
