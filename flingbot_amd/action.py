@@ -81,6 +81,33 @@ def pixel_to_3d(depth_im, x, y, pose_matrix, fov=39.5978, depth_scale=1):
     return target_position
 
 
+def pixels_to_3d_positions(pixels, scale, rotation, pretransform_depth, transformed_depth, pose_matrix=None,
+                           pretransform_pix_only=False, **kwargs):
+    """environment/utils.py:232-276: network pixels -> pretransform pixels -> world points (same return dictionary)."""
+    mat = get_transform_matrix(original_dim=pretransform_depth.shape[0], resized_dim=transformed_depth.shape[0],
+                               rotation=-rotation,  # the reference's sign ("TODO bug", environment/utils.py:244), kept
+                               scale=scale)
+    pixels = np.concatenate((pixels, np.array([[1], [1]])), axis=1)
+    pixels = np.matmul(pixels, mat)[:, :2].astype(int)
+    pix_1, pix_2 = pixels
+    max_idx = pretransform_depth.shape[0]
+    if (pixels < 0).any() or (pixels >= max_idx).any():
+        return {'valid_action': False, 'p1': None, 'p2': None, 'pretransform_pixels': np.array([pix_1, pix_2])}
+    if pretransform_pix_only:
+        return {'valid_action': True, 'pretransform_pixels': np.array([pix_1, pix_2])}
+    x, y = pix_1  # "this order of x, y is not a bug"
+    p1 = pixel_to_3d(depth_im=pretransform_depth, x=x, y=y, pose_matrix=pose_matrix)
+    x, y = pix_2
+    p2 = pixel_to_3d(depth_im=pretransform_depth, x=x, y=y, pose_matrix=pose_matrix)
+    return {'valid_action': p1 is not None and p2 is not None, 'p1': p1, 'p2': p2,
+            'pretransform_pixels': np.array([pix_1, pix_2])}
+
+
+def preprocess_obs(rgb, d):
+    """environment/utils.py:579-582 on the host (the device path produces the same tensor inside fs_observe)."""
+    return torch.cat((torch.tensor(rgb).float() / 255, torch.tensor(d).unsqueeze(dim=2).float()), dim=2).permute(2, 0, 1)
+
+
 def get_action_params(action_primitive, max_indices, pix_grasp_dist, pix_drag_dist, pix_place_dist):
     """simEnv.py:517-537"""
     x, y, z = max_indices
@@ -134,16 +161,12 @@ class ActionSelector:
         rotation_idx = x // num_scales
         scale_idx = x - rotation_idx * num_scales
         scale, rotation = scales[scale_idx], self.rotations[rotation_idx]
-        mat = get_transform_matrix(original_dim=depth.shape[0], resized_dim=self.obs_dim, rotation=-rotation, scale=scale)
-        pixels = np.concatenate((np.array([p1, p2]), np.array([[1], [1]])), axis=1)
-        pixels = np.matmul(pixels, mat)[:, :2].astype(int)
-        pix_1, pix_2 = pixels
-        if (pixels < 0).any() or (pixels >= depth.shape[0]).any():
+        r3d = pixels_to_3d_positions(pixels=np.array([p1, p2]), scale=scale, rotation=rotation, pretransform_depth=depth,
+                                     transformed_depth=np.empty((self.obs_dim, 0)), pose_matrix=self.pose)
+        if not r3d['valid_action']:
             return None
-        xx, yy = pix_1
-        P1 = pixel_to_3d(depth_im=depth.copy(), x=xx, y=yy, pose_matrix=self.pose)
-        xx, yy = pix_2
-        P2 = pixel_to_3d(depth_im=depth.copy(), x=xx, y=yy, pose_matrix=self.pose)
+        P1, P2 = r3d['p1'], r3d['p2']
+        pix_1, pix_2 = r3d['pretransform_pixels']
 
         def reach(base, pos):
             return np.linalg.norm(base - pos) < self.reach_distance_limit

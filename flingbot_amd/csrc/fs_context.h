@@ -74,6 +74,7 @@ struct fs_ctx {
     bool force_coded_fused = false;    // FS_SOLVER_FUSED_CODED: never the grid-64 form (dictionary-coded adjacency kernel)
     bool fused_attr_set = false;       // hipFuncAttributeMaxDynamicSharedMemorySize applied on this context's device
     int last_form = 0;                 // FS_FORM_* of the most recent solver launch (fs_last_kernel_form)
+    long long last_movep_steps = 0;    // simulation steps of the most recent fs_movep* call, all episodes (fs_last_movep_steps)
     hipStream_t stream = nullptr;
     std::vector<FsEnv> envs;
     FsEnvDev *d_envs = nullptr;       // [n_envs]

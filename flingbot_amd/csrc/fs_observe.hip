@@ -106,9 +106,12 @@ __global__ __launch_bounds__(256) void fs_k_obs_resize(const unsigned char *__re
 }
 
 // one pass of min-label propagation over the 8-neighbourhood + pointer jumping; labels only ever decrease
+// (blockIdx.y = observation of a batch: its labels / counts / result follow the first one's at a stride of S * S / 1)
 __global__ __launch_bounds__(256) void fs_k_obs_ccl(int S, int *label, FsObsResult *res) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= S * S) return;
+    label += (size_t)blockIdx.y * S * S;
+    res += blockIdx.y;
     const int own = label[idx];
     if (own < 0) return;
     const int y = idx / S, x = idx % S;
@@ -137,6 +140,8 @@ __global__ __launch_bounds__(256) void fs_k_obs_ccl(int S, int *label, FsObsResu
 
 __global__ __launch_bounds__(256) void fs_k_obs_count(int S, const int *__restrict__ label, int *count) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    label += (size_t)blockIdx.y * S * S;
+    count += (size_t)blockIdx.y * S * S;
     const int l = idx < S * S ? label[idx] : -1;
     // a wavefront's pixels mostly share one root: one atomic per distinct root and wavefront instead of one per pixel
     bool todo = l >= 0;
@@ -153,6 +158,8 @@ __global__ __launch_bounds__(256) void fs_k_obs_count(int S, const int *__restri
 __global__ __launch_bounds__(256) void fs_k_obs_best(int S, const int *__restrict__ count, FsObsResult *res) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= S * S) return;
+    count += (size_t)blockIdx.y * S * S;
+    res += blockIdx.y;
     const int c = count[idx];
     if (c > 0) atomicMax(&res->best, ((unsigned long long)c << 32) | (unsigned long long)(0xffffffffu - (unsigned)idx));
 }
@@ -161,6 +168,9 @@ __global__ __launch_bounds__(256) void fs_k_obs_bbox(int S, const int *__restric
                                                      unsigned char *__restrict__ mask) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= S * S) return;
+    label += (size_t)blockIdx.y * S * S;
+    res += blockIdx.y;
+    if (mask) mask += (size_t)blockIdx.y * S * S;
     const unsigned long long best = res->best;
     const int root = best ? (int)(0xffffffffu - (unsigned)(best & 0xffffffffull)) : -2;
     const bool in = label[idx] == root;
@@ -223,6 +233,69 @@ int fs_observe(fs_ctx *ctx, int env, int image_dim, float *d_obs, unsigned char 
     bbox[0] = n_px ? h->xmin : -1; bbox[1] = n_px ? h->xmax : -1;
     bbox[2] = n_px ? h->ymin : -1; bbox[3] = n_px ? h->ymax : -1;
     bbox[4] = n_px;
+    return FS_OK;
+}
+
+// fs_observe for n episodes with the host round trips of ONE: every episode is rendered and resized in turn (the frame
+// buffer is shared), then the labelling passes, the component count and the bounding boxes run for all of them per launch
+// (blockIdx.y = observation) and the convergence flags / results come back in one copy per round.  Extra passes over
+// labels that have converged change nothing, so each result equals the single call's.
+//   d_obs [n][4][S][S], d_mask [n][S][S] or null, bbox [n][5], d_work: n * fs_observe_work_bytes(S) bytes.
+int fs_observe_batch(fs_ctx *ctx, int n, const int *envs, int image_dim, float *d_obs, unsigned char *d_mask, int *bbox,
+                     void *d_work) {
+    if (!ctx || n <= 0 || !envs || image_dim <= 0 || image_dim > 4096 || !d_obs || !bbox || !d_work) {
+        fs_set_error("fs_observe_batch: bad arguments");
+        return FS_ERR_ARG;
+    }
+    for (int k = 0; k < n; ++k)
+        if (envs[k] < 0 || envs[k] >= ctx->n_envs || !ctx->envs[envs[k]].has_scene) {
+            fs_set_error("fs_observe_batch: bad episode");
+            return FS_ERR_ARG;
+        }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int S = image_dim;
+    const size_t px = size_t(S) * S;
+    int *label = (int *)d_work, *count = label + px * n;
+    FsObsResult *res = (FsObsResult *)(count + px * n);
+    hipStream_t st = ctx->stream;
+    FsObsResult *h = (FsObsResult *)fs_stage(ctx, sizeof(FsObsResult) * n);
+    if (!h) return FS_ERR_HIP;
+    for (int k = 0; k < n; ++k) {
+        h[k].best = 0; h[k].xmin = h[k].ymin = 0x7fffffff; h[k].xmax = h[k].ymax = -1; h[k].changed = 0; h[k].pad = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(res, h, sizeof(FsObsResult) * n, hipMemcpyHostToDevice, st));
+    const dim3 grid1((unsigned)((px + 255) / 256)), gridn((unsigned)((px + 255) / 256), (unsigned)n), block(256);
+    for (int k = 0; k < n; ++k) {
+        unsigned char *d_rgba = nullptr;
+        float *d_depth = nullptr;
+        int rc = fs_render_device(ctx, envs[k], &d_rgba, &d_depth);
+        if (rc != FS_OK) return rc;
+        const FsEnv &e = ctx->envs[envs[k]];
+        hipLaunchKernelGGL(fs_k_obs_resize, grid1, block, 0, st, d_rgba, d_depth, e.cam.width, e.cam.height, S,
+                           d_obs + size_t(4) * px * k, label + px * k, count + px * k);
+    }
+    for (int round = 0; round < 4096; ++round) {
+        for (int q = 0; q < 7; ++q) hipLaunchKernelGGL(fs_k_obs_ccl, gridn, block, 0, st, S, label, res);
+        for (int k = 0; k < n; ++k) HIP_TRY(hipMemsetAsync(&res[k].changed, 0, sizeof(int), st));
+        hipLaunchKernelGGL(fs_k_obs_ccl, gridn, block, 0, st, S, label, res);
+        HIP_TRY(hipMemcpyAsync(h, res, sizeof(FsObsResult) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool any = false;
+        for (int k = 0; k < n; ++k) any = any || h[k].changed;
+        if (!any) break;
+    }
+    hipLaunchKernelGGL(fs_k_obs_count, gridn, block, 0, st, S, label, count);
+    hipLaunchKernelGGL(fs_k_obs_best, gridn, block, 0, st, S, count, res);
+    hipLaunchKernelGGL(fs_k_obs_bbox, gridn, block, 0, st, S, label, res, d_mask);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h, res, sizeof(FsObsResult) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < n; ++k) {
+        const int n_px = (int)(h[k].best >> 32);
+        bbox[5 * k + 0] = n_px ? h[k].xmin : -1; bbox[5 * k + 1] = n_px ? h[k].xmax : -1;
+        bbox[5 * k + 2] = n_px ? h[k].ymin : -1; bbox[5 * k + 3] = n_px ? h[k].ymax : -1;
+        bbox[5 * k + 4] = n_px;
+    }
     return FS_OK;
 }
 

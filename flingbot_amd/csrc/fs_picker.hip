@@ -141,6 +141,10 @@ extern "C" int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, do
     return FS_OK;
 }
 
+// simulation steps (summed over the episodes) the most recent fs_movep* call executed: a movep iteration that finds the
+// pickers on their targets (min_steps) takes none (flex_utils.py:231-233), so this is <= the sum of the iteration counts
+extern "C" long long fs_last_movep_steps(const fs_ctx *ctx) { return ctx ? ctx->last_movep_steps : -1; }
+
 // Picker.picker_radius (flex_utils.py:57, used in the grasp threshold :154-155) is a python float: the double 0.02, not
 // the float32 radius pyflex.add_sphere stored.  Callers that know it pass it here so the threshold sum is the reference's.
 extern "C" int fs_picker_set_radius(fs_ctx *ctx, int env, double picker_radius) {
@@ -281,6 +285,8 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
     }
     bool any_limit = false;
     for (auto &p : plans) any_limit = any_limit || p.limit_hit;
+    ctx->last_movep_steps = 0;
+    for (auto &p : plans) ctx->last_movep_steps += (long long)p.cmds.size();
     if (max_steps > 0) {
         // per step: the ids of the episodes still moving + their commands, all uploaded once
         std::vector<int> h_ids(max_steps * n, 0), h_count(max_steps, 0);

@@ -52,22 +52,24 @@ class BatchedFlingEnv:
 
     # ---- SimEnv.reset for a batch of tasks (entry e of `tasks` becomes episode e)
     def reset(self, tasks):
-        self.envs = load_tasks(self.sim, tasks)
+        self.attach(load_tasks(self.sim, tasks))
         for e in self.envs:
             cp = self.sim.get_camera_params(e)
             self.sim.set_camera_params(e, [*cp[2:8], self.render_dim, self.render_dim])
+        return self.observe()
+
+    def attach(self, envs):
+        """What SimEnv.reset does once the scene and state of the episodes are in place (simEnv.py:674-681): initial
+        coverage, the two pickers at [0.2, 0.5, 0.0], reset_end_effectors, one simulation step, grasp off, counters."""
+        self.envs = [int(e) for e in envs]
         self.init_coverage = np.array(self.sim.coverage())
         self.prim = FlingPrimitives(self.sim, self.envs, **self._prim_kwargs)
         self.prim.setup_pickers()
         self.timestep = {e: 0 for e in self.envs}
         self.terminate = {e: False for e in self.envs}
-        return self.observe()
 
-    def get_obs(self, e):
-        """SimEnv.get_obs (simEnv.py:710-737): render, resize to image_dim, cloth mask -> adaptive scale factors,
-        preprocess_obs -- all in fs_observe; returns float32 [4, S, S] on the device."""
-        obs, bbox = self.sim.observe(e, self.image_dim)
-        self.pretransform_depth[e] = obs[3].cpu().numpy()
+    def _adaptive_factors(self, bbox):
+        """simEnv.py:722-731: scale factors shrunk to the cloth's bounding box (with some breathing room)."""
         factors = self.scale_factors.copy()
         if self.use_adaptive_scaling and bbox[4] > 0:
             dim = self.image_dim  # dimx == dimy
@@ -76,7 +78,25 @@ class BatchedFlingEnv:
             crop = int(max(cropx, cropy) * 1.5)  # some breathing room
             if crop < dim:
                 factors *= crop / dim
-        self.adaptive_scale_factors[e] = factors
+        return factors
+
+    def get_obs(self, e):
+        """SimEnv.get_obs (simEnv.py:710-737): render, resize to image_dim, cloth mask -> adaptive scale factors,
+        preprocess_obs -- all in fs_observe; returns float32 [4, S, S] on the device."""
+        obs, bbox = self.sim.observe(e, self.image_dim)
+        self.pretransform_depth[e] = obs[3].cpu().numpy()
+        self.adaptive_scale_factors[e] = self._adaptive_factors(bbox)
+        return obs
+
+    def get_obs_batch(self, envs):
+        """get_obs for several episodes: one fs_observe_batch call (the labelling rounds of all episodes share their host
+        round trips) and ONE download of the depth planes the host side of the action selection reads."""
+        envs = [int(e) for e in envs]
+        obs, bbox = self.sim.observe_batch(envs, self.image_dim)
+        depth = obs[:, 3].cpu().numpy() if envs else None
+        for k, e in enumerate(envs):
+            self.pretransform_depth[e] = depth[k]
+            self.adaptive_scale_factors[e] = self._adaptive_factors(bbox[k])
         return obs
 
     def get_transformations(self, e):
@@ -84,12 +104,9 @@ class BatchedFlingEnv:
 
     def observe(self):
         """{episode: transformed observation [T, 4, D, D] (CUDA)} for the episodes that are still running."""
-        out = {}
-        for e in self.envs:
-            if not self.terminate[e]:
-                obs = self.get_obs(e)
-                out[e] = nets.prepare_image(obs, self.get_transformations(e), self.obs_dim)
-        return out
+        run = [e for e in self.envs if not self.terminate[e]]
+        obs = self.get_obs_batch(run)
+        return {e: nets.prepare_image(obs[k], self.get_transformations(e), self.obs_dim) for k, e in enumerate(run)}
 
     def _on_cloth(self, depth, pix):
         yy, xx = np.ogrid[:depth.shape[0], :depth.shape[1]]
@@ -104,8 +121,7 @@ class BatchedFlingEnv:
         run = [e for e in self.envs if not self.terminate[e] and e in value_maps]
         if not run:
             return {}, {}, dict(self.terminate), {}
-        self.prim.preaction(run)
-        prev = np.array(self.sim.coverage())
+        # the reference takes the snapshot and the coverage BEFORE selecting (simEnv.py:477-485); selection reads neither
         chosen = {}
         for e in run:
             action, params = self.selector.select(value_maps[e], self.adaptive_scale_factors[e], self.pretransform_depth[e])
@@ -114,6 +130,18 @@ class BatchedFlingEnv:
                 params["p1_grasp_cloth"] = self._on_cloth(d, (pix[0][1], pix[0][0]))
                 params["p2_grasp_cloth"] = self._on_cloth(d, (pix[1][1], pix[1][0]))
                 chosen[e] = (action, params)
+        rewards, acted = self.step_actions(run, chosen)
+        return self.observe(), rewards, dict(self.terminate), acted
+
+    def step_actions(self, run, chosen):
+        """SimEnv.step (simEnv.py:477-515) for the episodes `run` once the actions are known: chosen[e] = (primitive,
+        {'p1', 'p2', 'p1_grasp_cloth', 'p2_grasp_cloth'}); an episode missing from `chosen` found no valid action.
+        preaction -> coverage -> one batched primitive call per action type -> postaction (reset_end_effectors,
+        wait_until_stable, "the cloth did not move" -> terminate) -> coverage -> timestep / episode_length.
+        Returns ({episode: reward}, {episode: primitive or None})."""
+        run = [int(e) for e in run]
+        self.prim.preaction(run)
+        prev = np.array(self.sim.coverage())
         for action in self.actions:  # one batched primitive call per action type
             es = [e for e in run if e in chosen and chosen[e][0] == action]
             if not es:
@@ -140,4 +168,4 @@ class BatchedFlingEnv:
             self.timestep[e] += 1
             self.terminate[e] = self.prim.terminate[e] or self.timestep[e] >= self.episode_length
             rewards[e] = float(curr[e] - prev[e])
-        return self.observe(), rewards, dict(self.terminate), {e: chosen.get(e, (None, None))[0] for e in run}
+        return rewards, {e: chosen.get(e, (None, None))[0] for e in run}

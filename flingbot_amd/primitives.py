@@ -61,8 +61,8 @@ class FlingPrimitives:
             return
         speed = 0.1 if speed is None else speed  # dump_visualizations is off in batch mode (simEnv.py:740-744)
         grasp = [self.grasp_states[e] for e in envs]
-        iters = self.sim.movep(envs, np.array(targets), grasp, speed=speed, limit=limit, min_steps=min_steps)
-        self.sim_steps += int(np.sum(iters))
+        self.sim.movep(envs, np.array(targets), grasp, speed=speed, limit=limit, min_steps=min_steps)
+        self.sim_steps += int(self.sim.last_movep_steps)  # iterations that find the pickers on target take no step
 
     def set_grasp(self, envs, grasp):
         for e in envs:

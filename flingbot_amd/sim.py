@@ -93,6 +93,7 @@ def load_library(build_if_missing=True):
         "fs_step_timed": (ci, [vp, ci, ci, fp]),
         "fs_picker_reset": (ci, [vp, ci, C.c_double, C.c_double]),
         "fs_picker_set_radius": (ci, [vp, ci, C.c_double]),
+        "fs_last_movep_steps": (C.c_longlong, [vp]),
         "fs_picker_get_picked": (ci, [vp, ci, ip, ci]),
         "fs_movep": (ci, [vp, ci, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
@@ -112,6 +113,7 @@ def load_library(build_if_missing=True):
                                   C.c_double, C.POINTER(C.c_longlong), fp, vp, vp]),
         "fs_observe_work_bytes": (C.c_size_t, [ci]),
         "fs_observe": (ci, [vp, ci, ci, vp, vp, ip, vp]),
+        "fs_observe_batch": (ci, [vp, ci, ip, ci, vp, vp, ip, vp]),
         "fs_value_net_param_floats": (C.c_size_t, []),
         "fs_value_net_work_bytes": (C.c_size_t, [ci, ci]),
         "fs_value_net_pack": (ci, [ci, fp, fp, fp, fp, fp, fp, fp, fp]),
@@ -248,6 +250,7 @@ class FlingSim:
             tg = np.ascontiguousarray(arr.astype(np.float64).reshape(ids.size, -1, 3))
             rc = self.lib.fs_movep_batch(self.h, ids.size, _ip(ids), tg.ctypes.data_as(C.POINTER(C.c_double)), _ip(gr),
                                          float(speed), int(limit), ms, float(eps), _ip(iters))
+        self.last_movep_steps = int(self.lib.fs_last_movep_steps(self.h))  # simulation steps (<= iterations), all episodes
         if rc == -4:
             raise MoveLimitError(self.lib.fs_last_error().decode())
         self._ck(rc)
@@ -437,6 +440,29 @@ class FlingSim:
         self._ck(self.lib.fs_observe(self.h, int(env), s_, C.c_void_p(obs.data_ptr()),
                                      C.c_void_p(mask.data_ptr()) if want_mask else None, _ip(bbox),
                                      C.c_void_p(work.data_ptr())))
+        return (obs, bbox, mask) if want_mask else (obs, bbox)
+
+    def observe_batch(self, envs, image_dim, want_mask=False):
+        """observe() for several episodes with the host round trips of one call (fs_observe_batch): returns
+        (obs float32 CUDA [n, 4, S, S], bbox int32 [n, 5][, mask uint8 CUDA [n, S, S]])."""
+        import torch
+        ids = _i(envs)
+        n, s_ = int(ids.size), int(image_dim)
+        dev = torch.device("cuda", self.device)
+        obs = torch.empty((n, 4, s_, s_), dtype=torch.float32, device=dev)
+        mask = torch.empty((n, s_, s_), dtype=torch.uint8, device=dev) if want_mask else None
+        bbox = np.zeros((n, 5), np.int32)
+        if n == 0:
+            return (obs, bbox, mask) if want_mask else (obs, bbox)
+        nbytes = int(self.lib.fs_observe_work_bytes(s_)) * n
+        work = getattr(self, "_observe_work", None)
+        if work is None or work.numel() < nbytes:
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._observe_work = work
+        torch.cuda.current_stream(dev).synchronize()  # the buffers above may still be in use on torch's stream
+        self._ck(self.lib.fs_observe_batch(self.h, n, _ip(ids), s_, C.c_void_p(obs.data_ptr()),
+                                           C.c_void_p(mask.data_ptr()) if want_mask else None, _ip(bbox),
+                                           C.c_void_p(work.data_ptr())))
         return (obs, bbox, mask) if want_mask else (obs, bbox)
 
     def get_last_neighbors(self, env=0):

@@ -145,6 +145,9 @@ int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, double partic
    (flex_utils.py:154-155); without this call the threshold uses the float32 radius pyflex.add_sphere stored for shape 0.
    fs_picker_reset clears it. */
 int fs_picker_set_radius(fs_ctx *ctx, int env, double picker_radius);
+/* simulation steps, summed over the episodes, that the most recent fs_movep / fs_movep_batch* call executed (movep
+   iterations that find the pickers on their targets do not step the simulation, flex_utils.py:231-233) */
+long long fs_last_movep_steps(const fs_ctx *ctx);
 /* picked particle index per picker (-1 = none) */
 int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
 /* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all
@@ -245,6 +248,11 @@ int fs_select_action(const float *d_values, int n_primitives, const int *primiti
    unpinned: cv2 is absent from the build image). */
 size_t fs_observe_work_bytes(int image_dim);
 int fs_observe(fs_ctx *ctx, int env, int image_dim, float *d_obs, unsigned char *d_mask, int *bbox, void *d_work);
+/* fs_observe for n episodes with the host round trips of one call (the labelling rounds and the results of all
+   episodes come back together).  d_obs [n][4][S][S], d_mask [n][S][S] or NULL, bbox [n][5],
+   d_work: n * fs_observe_work_bytes(image_dim) bytes.  Every result equals the single call's. */
+int fs_observe_batch(fs_ctx *ctx, int n, const int *envs, int image_dim, float *d_obs, unsigned char *d_mask, int *bbox,
+                     void *d_work);
 
 /* ---- value network forward ------------------------------------------------------------------
    SpatialValueNet.forward (learning/nets.py:81-141) in eval mode for size x size = 64 x 64 observations (the

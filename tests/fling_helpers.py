@@ -21,11 +21,11 @@ class OracleBatch:
     """The slice of the FlingSim interface FlingPrimitives uses, on N independent CPU oracles + the numpy restatement of
     the reference picker (oracle/picker.py).  The reductions are the reference's own numpy expressions."""
 
-    def __init__(self, n, scene_params, init_pos):
+    def __init__(self, n, scene_params, init_pos, pickers=True):
         from oracle import OracleSim
         from oracle.picker import OraclePicker
 
-        self.sims, self.tools = [], []
+        self.sims, self.tools, self.snap = [], [], {}
         for _ in range(n):
             o = OracleSim()
             o.set_scene(scene_params)
@@ -33,14 +33,52 @@ class OracleBatch:
             o.set_positions(init_pos.ravel())
             o.set_velocities(np.zeros(3 * init_pos.shape[0], np.float32))
             t = OraclePicker(o)
-            t.reset(picker_centres())
+            if pickers:
+                t.reset(picker_centres())
             self.sims.append(o)
             self.tools.append(t)
 
+    # ---- what FlingPrimitives.setup_pickers / BatchedFlingEnv.step_actions need beyond the primitives
+    def add_sphere(self, e, radius, pos, quat):
+        self.sims[e].add_sphere(radius, pos, quat)
+
+    def set_shape_states(self, e, s):
+        self.sims[e].set_shape_states(s)
+
+    def picker_reset(self, e, picker_threshold=0.005, particle_radius=0.00625, picker_radius=None):
+        t = self.tools[e]
+        t.picker_threshold, t.particle_radius = picker_threshold, particle_radius
+        if picker_radius is not None:
+            t.picker_radius = picker_radius
+        t.picked_particles = [None] * t.num_picker
+        t.particle_inv_mass = self.sims[e].get_positions().reshape(-1, 4)[:, 3]
+
+    def step_list(self, envs, n_steps=1):
+        for e in envs:
+            self.sims[e].step(n_steps)
+
+    def coverage(self):
+        from oracle.coverage import covered_area
+
+        return [covered_area(s.get_positions()) for s in self.sims]
+
+    def snapshot_positions(self, envs):
+        for e in envs:
+            self.snap[e] = self.sims[e].get_positions().reshape(-1, 4)[:, :3].copy()  # SimEnv.preaction
+
+    def max_displacement(self, envs):
+        out = []
+        for e in envs:
+            post = self.sims[e].get_positions().reshape(-1, 4)[:, :3]
+            out.append(np.linalg.norm(np.abs(post - self.snap[e]), axis=1).max())  # simEnv.py:470-472
+        return np.array(out, np.float32)
+
     def movep(self, envs, targets, grasp, speed=0.1, limit=1000, min_steps=None, eps=1e-4):
         targets = np.asarray(targets)
-        return np.array([self.tools[e].movep(targets[k], [bool(g) for g in grasp[k]], speed=speed, limit=limit,
-                                             min_steps=min_steps, eps=eps) for k, e in enumerate(envs)], np.int32)
+        iters = np.array([self.tools[e].movep(targets[k], [bool(g) for g in grasp[k]], speed=speed, limit=limit,
+                                              min_steps=min_steps, eps=eps) for k, e in enumerate(envs)], np.int32)
+        self.last_movep_steps = sum(self.tools[e].last_sim_steps for e in envs)
+        return iters
 
     def get_shape_states(self, e):
         return self.sims[e].get_shape_states()
@@ -212,3 +250,58 @@ def check_tasks_against_golden(make_sim):
             assert abs(task["initial_coverage"] - float(g[f"t{ci}_initial_coverage"])) <= 1e-12
             results[ci] = task
     return results
+
+
+def load_step_golden():
+    return np.load(os.path.join(GOLD, "step_golden.npz"))
+
+
+def run_step_golden(make_sim, get_positions, get_shapes):
+    """SimEnv.step's bookkeeping (tests/golden/step_golden.npz, recorded from the reference's own SimEnv.step with the action
+    selection scripted) through BatchedFlingEnv.step_actions on a simulator made by make_sim(n): every case is its own
+    episode, all advanced together step by step; rewards, termination, timesteps, simulation-step counts, grasp flags,
+    particle positions and picker states must be reproduced exactly."""
+    from flingbot_amd.env import BatchedFlingEnv
+
+    g = load_step_golden()
+    n = int(g["n_cases"])
+    sim = make_sim(n)
+    env = BatchedFlingEnv.__new__(BatchedFlingEnv)  # host bookkeeping only: no selector / CUDA pieces are touched
+    env.sim = sim
+    env.actions = ["fling", "stretchdrag", "drag", "place"]
+    env._prim_kwargs = dict(grasp_height=0.02, fling_speed=6e-3, stretchdrag_dist=0.3)
+    env.episode_length = 0
+    env.attach(range(n))
+    lengths = {c: int(g[f"c{c}_episode_length"]) for c in range(n)}
+    for c in range(n):
+        assert abs(env.init_coverage[c] - float(g[f"c{c}_init_coverage"])) <= 1e-15
+    max_steps = max(len(g[f"c{c}_terminate"]) for c in range(n))
+    for k in range(max_steps):
+        run = [c for c in range(n) if k < len(g[f"c{c}_terminate"])]
+        chosen = {}
+        for c in run:
+            prim = str(g[f"c{c}_prim"][k])
+            if prim != "None":
+                chosen[c] = (prim, dict(p1=g[f"c{c}_p1"][k].copy(), p2=g[f"c{c}_p2"][k].copy(),
+                                        p1_grasp_cloth=bool(g[f"c{c}_g1"][k]), p2_grasp_cloth=bool(g[f"c{c}_g2"][k])))
+        before = env.prim.sim_steps
+        # episode_length differs per case: evaluate the termination rule per episode
+        rewards, acted = {}, {}
+        for length in sorted(set(lengths[c] for c in run)):
+            sub = [c for c in run if lengths[c] == length]
+            env.episode_length = length
+            r, a = env.step_actions(sub, chosen)
+            rewards.update(r)
+            acted.update(a)
+        for c in run:
+            assert rewards[c] == float(g[f"c{c}_reward"][k]), (c, k, rewards[c], float(g[f"c{c}_reward"][k]))
+            assert env.terminate[c] == bool(g[f"c{c}_terminate"][k]), (c, k)
+            assert env.timestep[c] == int(g[f"c{c}_timestep"][k]), (c, k)
+            assert [bool(x) for x in env.prim.grasp_states[c]] == [bool(x) for x in g[f"c{c}_grasp"][k]], (c, k)
+            assert np.array_equal(get_positions(sim, c).view(np.uint32), g[f"c{c}_pos"][k].view(np.uint32)), (c, k)
+            assert np.array_equal(np.asarray(get_shapes(sim, c), np.float32).view(np.uint32),
+                                  g[f"c{c}_shapes"][k].view(np.uint32)), (c, k)
+            assert acted[c] == (None if str(g[f"c{c}_prim"][k]) == "None" else str(g[f"c{c}_prim"][k]))
+        assert env.prim.sim_steps - before == sum(int(g[f"c{c}_sim_steps"][k]) for c in run), k
+    assert any(bool(g[f"c{c}_terminate"][-1]) and int(g[f"c{c}_timestep"][-1]) < lengths[c] for c in range(n))
+    return env

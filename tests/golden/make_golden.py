@@ -133,6 +133,261 @@ def nets_vectors():
     print("nets:", len(sd), "state_dict entries; out", tuple(out.shape))
 
 
+def _import_reference_env_utils():
+    """environment/utils.py of the reference with every absent third-party module stubbed (cv2, trimesh, OpenEXR, ...)."""
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, name): return _Any()
+
+    def anystub(name):
+        m = types.ModuleType(name)
+
+        def _ga(attr):
+            if attr.startswith("__"):
+                raise AttributeError(attr)
+            return _Any()
+        m.__getattr__ = _ga
+        m.__path__ = []
+        m.__file__ = "<stub %s>" % name
+        sys.modules[name] = m
+        return m
+
+    for name in ("h5py", "filelock", "imageio", "trimesh", "OpenEXR", "Imath", "cv2", "PIL", "skimage", "skimage.morphology",
+                 "matplotlib", "matplotlib.pyplot", "ray", "pyflex"):
+        if name != "pyflex":
+            try:
+                __import__(name)
+                continue
+            except Exception:
+                pass
+        anystub(name)
+    sys.modules["ray"].remote = lambda f: f
+    for m in [k for k in sys.modules if k == "environment" or k.startswith("environment.") or k in ("flex_utils", "nets")]:
+        del sys.modules[m]
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from environment import utils as ref_utils
+    return ref_utils
+
+
+def envutils_vectors():
+    """environment/utils.py:161-276, 579-582 -- compute_pose, compute_intrinsics, pixel_to_3d, get_transform_matrix,
+    pixels_to_3d_positions, preprocess_obs -- run here on seeded inputs.  The product's host mirror
+    (flingbot_amd/action.py) has to reproduce every output bit for bit (float64)."""
+    U = _import_reference_env_utils()
+    rng = np.random.default_rng(11)
+    out = {}
+    poses = [([0, 2, 0], [0, 0, 0], [0, 0, 1]), ([0.3, 1.5, -0.2], [0.1, 0.0, 0.05], [0, 0, 1]),
+             ([1.0, 1.0, 1.0], [0, 0.2, 0], [0, 1, 0])]
+    out["pose_in"] = np.array(poses, np.float64)
+    out["pose_out"] = np.stack([U.compute_pose(pos=p, lookat=l, up=u) for p, l, u in poses])
+    out["intrinsics_in"] = np.array([[39.5978, 400], [39.5978, 720], [60.0, 97]], np.float64)
+    out["intrinsics_out"] = np.stack([U.compute_intrinsics(f, s) for f, s in out["intrinsics_in"]])
+    tm = [(400, 64, -30.0, 1.5), (400, 64, 90.0, 0.75), (720, 64, 16.363636363636363, 2.75), (100, 32, 0.0, 1.0),
+          (60, 24, -180.0, 2.0), (97, 33, 49.09090909090909, 1.25)]
+    out["tm_in"] = np.array(tm, np.float64)
+    out["tm_out"] = np.stack([U.get_transform_matrix(original_dim=int(a), resized_dim=int(b), rotation=r, scale=s)
+                              for a, b, r, s in tm])
+    # pixel_to_3d: float32 depth image like the renderer's, several pixels, two poses (the function scales the depth
+    # value it reads IN PLACE -- `click_z *= depth_scale` on a numpy scalar copy -- so the image itself stays untouched)
+    depth = (2.0 - rng.random((96, 96)) * 0.4).astype(np.float32)
+    pts = np.array([[0, 0], [95, 95], [48, 47], [10, 80], [77, 3], [31, 64]])
+    out["p3d_depth"] = depth
+    out["p3d_xy"] = pts
+    out["p3d_out"] = np.stack([np.stack([U.pixel_to_3d(depth.copy(), int(x), int(y), pose_matrix=out["pose_out"][k])
+                                         for x, y in pts]) for k in range(2)])
+    out["p3d_scaled"] = U.pixel_to_3d(depth.copy(), 20, 30, pose_matrix=out["pose_out"][0], fov=50.0, depth_scale=0.5)
+    # pixels_to_3d_positions: in bounds, out of bounds, pretransform_pix_only
+    big = (2.0 - rng.random((120, 120)) * 0.3).astype(np.float32)
+    cases = [(np.array([[10, 12], [20, 12]]), 1.5, 30.0, False), (np.array([[16, 16], [16, 24]]), 1.0, -90.0, False),
+             (np.array([[2, 2], [29, 29]]), 2.75, 73.63636363636364, False), (np.array([[5, 27], [13, 27]]), 0.75, 0.0, True),
+             (np.array([[0, 0], [31, 31]]), 3.5, 45.0, False)]
+    out["pp_depth"] = big
+    for k, (pix, scale, rot, only) in enumerate(cases):
+        r = U.pixels_to_3d_positions(pixels=pix, scale=scale, rotation=rot, pretransform_depth=big.copy(),
+                                     transformed_depth=np.zeros((32, 32), np.float32), pose_matrix=out["pose_out"][0],
+                                     pretransform_pix_only=only)
+        out[f"pp{k}_in"] = np.array([*pix.ravel(), scale, rot, float(only)], np.float64)
+        out[f"pp{k}_valid"] = np.array(bool(r["valid_action"]))
+        out[f"pp{k}_pixels"] = np.asarray(r["pretransform_pixels"])
+        out[f"pp{k}_has_points"] = np.array(r.get("p1") is not None)
+        if r.get("p1") is not None:
+            out[f"pp{k}_p1"], out[f"pp{k}_p2"] = np.asarray(r["p1"]), np.asarray(r["p2"])
+    out["pp_n"] = np.array(len(cases))
+    # preprocess_obs
+    rgb = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    d = (2.0 - rng.random((40, 40)) * 0.5).astype(np.float32)
+    out["obs_rgb"], out["obs_d"] = rgb, d
+    out["obs_out"] = U.preprocess_obs(rgb.copy(), d.copy()).numpy()
+    np.savez_compressed(os.path.join(HERE, "envutils_golden.npz"), **out)
+    print("envutils:", {k: getattr(v, "shape", None) for k, v in out.items() if k.endswith("_out")},
+          "pixel_to_3d(d=2, 300, 200) =", U.pixel_to_3d(np.full((400, 400), 2.0, np.float32), 300, 200, out["pose_out"][0]))
+
+
+def step_vectors():
+    """The reference's SimEnv.step (environment/simEnv.py:464-515: preaction, coverage before, action handler, postaction =
+    reset_end_effectors + wait_until_stable + the "cloth did not move -> end early" test, coverage after, timestep /
+    episode_length termination, reward) executed by the reference's own code on the oracle-backed `pyflex` stub, with the
+    action selection scripted (get_max_value_valid_action returns a prepared (primitive, action) per step) and get_obs /
+    prepare_image / episode memory / reset stubbed -- what is pinned is the bookkeeping around the primitives, which
+    tests/golden/fling_golden.npz pins separately.  Before the first step the episode is brought up exactly like
+    SimEnv.reset does after set_scene (simEnv.py:674-681)."""
+    sys.path.insert(0, ROOT)
+    from oracle import OracleSim
+
+    if not hasattr(np, "alltrue"):
+        np.alltrue = np.all
+    import torch  # noqa: F401
+    import scipy.ndimage  # noqa: F401
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, name): return _Any()
+
+    def anystub(name):
+        m = types.ModuleType(name)
+
+        def _ga(attr):
+            if attr.startswith("__"):
+                raise AttributeError(attr)
+            return _Any()
+        m.__getattr__ = _ga
+        m.__path__ = []
+        m.__file__ = "<stub %s>" % name
+        sys.modules[name] = m
+        return m
+
+    for name in ("h5py", "filelock", "imageio", "trimesh", "OpenEXR", "Imath", "cv2", "PIL", "skimage", "skimage.morphology",
+                 "matplotlib", "matplotlib.pyplot", "ray", "pyflex"):
+        if name not in ("pyflex",):
+            try:
+                __import__(name)
+                continue
+            except Exception:
+                pass
+        anystub(name)
+    sys.modules["ray"].remote = lambda f: f
+    orc_box = {}
+    pf = sys.modules["pyflex"]
+    for name in ("get_positions", "set_positions", "get_velocities", "set_velocities", "get_shape_states",
+                 "set_shape_states", "add_sphere", "get_phases", "set_phases"):
+        setattr(pf, name, (lambda nm: lambda *a, **k: getattr(orc_box["o"], nm)(*a, **k))(name))
+    counter = {"steps": 0}
+
+    def _step(*a, **k):
+        counter["steps"] += 1
+        orc_box["o"].step(1)
+    pf.step = _step
+    for m in [k for k in sys.modules if k == "environment" or k.startswith("environment.") or k in ("flex_utils", "nets")]:
+        del sys.modules[m]
+    sys.path.insert(0, REF)
+    from environment import simEnv as ref_simenv
+    from environment import flex_utils as ref_fu
+    ref_simenv.prepare_image = lambda *a, **k: "transformed_obs"
+    SimEnv = ref_simenv.SimEnv
+
+    sp = np.array([0, 0.2, 0, 32, 32, 0.9, 0.9, 0.9, 2, 0, 2, 0, np.pi / 2, -np.pi / 2, 0, 720, 720, 0.3, 0])
+    dim = 32
+    xs = (np.arange(dim) - (dim - 1) / 2) * 0.00625
+    xx, zz = np.meshgrid(xs, xs)
+    corner = dict(p1=[xs[0], 0.0, xs[0]], p2=[xs[-1], 0.0, xs[0]])
+    miss = dict(p1=[xs[0] - 0.05, 0.0, xs[0] - 0.05], p2=[xs[-1] + 0.05, 0.0, xs[0] - 0.05])
+    # (episode_length, [(primitive or None, p1, p2, p1_grasp_cloth, p2_grasp_cloth), ...])
+    cases = [
+        (5, [("fling", corner["p1"], corner["p2"], True, True), (None, None, None, None, None)]),  # fling, then nothing moves
+        (1, [("fling", [xs[3], 0.0, xs[20]], [xs[-4], 0.0, xs[20]], True, True)]),              # episode_length reached
+        (5, [("fling", miss["p1"], miss["p2"], True, True)]),              # grasp misses: terminated inside the handler,
+                                                                            # postaction runs with the grasp flags still set
+        (5, [("fling", corner["p1"], corner["p2"], False, False), ("drag", [xs[5], 0.0, xs[5]], [xs[5] + 0.1, 0.0, xs[5]], True, True)]),
+    ]
+    out = {"scene_params": sp, "n_cases": np.array(len(cases))}
+    for ci, (episode_length, script) in enumerate(cases):
+        orc = OracleSim()
+        orc_box["o"] = orc
+        orc.set_scene(sp)
+        orc.step(1)
+        n = orc.n
+        w = orc.get_positions().reshape(-1, 4)[0, 3]
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3] = xx.ravel(), 0.0125, zz.ravel(), w
+        orc.set_positions(pos.ravel())
+        orc.set_velocities(np.zeros(3 * n, np.float32))
+        out["init_pos"] = pos
+        env = SimEnv.__new__(SimEnv)
+        env.gui, env.gui_step, env.dump_visualizations = False, 0, False
+        env.default_speed, env.grasp_height, env.fling_speed, env.fixed_fling_height = 1e-2, 0.02, 6e-3, -1
+        env.stretchdrag_dist = 0.3
+        env.particle_radius = 0.00625
+        env.grasp_states = [False, False]
+        env.env_video_frames = {}
+        env.episode_memory = _Any()
+        env.current_task = _Any()
+        env.obs_dim, env.parallelize_prepare_image, env.ray_handle = 64, False, {"val": "handle"}
+        env.episode_length = episode_length
+        env.action_handlers = {"fling": env.pick_and_fling_primitive, "stretchdrag": env.pick_stretch_drag_primitive,
+                               "drag": env.pick_and_drag_primitive, "place": env.pick_and_place_primitive}
+        env.get_obs = lambda: "obs"
+        env.get_transformations = lambda: []
+        env.on_episode_end = lambda *a, **k: None
+        env.reset = lambda: ("reset", None)
+        covs = []
+
+        def cov(_env=env):
+            c = SimEnv.compute_coverage(_env)
+            covs.append(float(c))
+            return c
+        env.compute_coverage = cov
+        todo = list(script)
+
+        def scripted(value_maps):
+            prim, p1, p2, g1, g2 = todo.pop(0)
+            if prim is None:
+                return None, None
+            return prim, dict(p1=np.array(p1, np.float64), p2=np.array(p2, np.float64), p1_grasp_cloth=g1, p2_grasp_cloth=g2)
+        env.get_max_value_valid_action = scripted
+        env.action_tool = ref_fu.PickerPickPlace(num_picker=2, particle_radius=0.00625, picker_radius=0.02,
+                                                 picker_low=(-5, 0, -5), picker_high=(5, 5, 5))
+        # SimEnv.reset after set_scene (simEnv.py:674-681)
+        env.current_timestep, env.terminate = 0, False
+        env.init_coverage = ref_fu.get_current_covered_area(env.particle_radius)
+        env.action_tool.reset([0.2, 0.5, 0.0])
+        env.reset_end_effectors()
+        env.step_simulation()
+        env.set_grasp(False)
+        out[f"c{ci}_init_coverage"] = np.array(float(env.init_coverage))
+        out[f"c{ci}_episode_length"] = np.array(episode_length)
+        out[f"c{ci}_prim"] = np.array([str(a[0]) for a in script])
+        out[f"c{ci}_p1"] = np.array([a[1] if a[1] is not None else [np.nan] * 3 for a in script], np.float64)
+        out[f"c{ci}_p2"] = np.array([a[2] if a[2] is not None else [np.nan] * 3 for a in script], np.float64)
+        out[f"c{ci}_g1"] = np.array([bool(a[3]) for a in script])
+        out[f"c{ci}_g2"] = np.array([bool(a[4]) for a in script])
+        log = {k: [] for k in ("prev", "curr", "reward", "terminate", "timestep", "sim_steps", "grasp", "returned_reset", "pos",
+                               "shapes")}
+        for k in range(len(script)):
+            counter["steps"] = 0
+            del covs[:]
+            ret = env.step(None)
+            log["prev"].append(covs[0])
+            log["curr"].append(covs[1])
+            log["reward"].append(covs[1] - covs[0])
+            log["terminate"].append(bool(env.terminate))
+            log["timestep"].append(int(env.current_timestep))
+            log["sim_steps"].append(counter["steps"])
+            log["grasp"].append([bool(g) for g in env.grasp_states])
+            log["returned_reset"].append(ret == ("reset", None))
+            log["pos"].append(orc.get_positions().copy())
+            log["shapes"].append(orc.get_shape_states().copy())
+            print("step case", ci, "action", script[k][0], "reward %.5f" % log["reward"][-1], "terminate", env.terminate,
+                  "timestep", env.current_timestep, "sim steps", counter["steps"], "grasp", env.grasp_states)
+            if env.terminate:
+                break
+        for key, v in log.items():
+            out[f"c{ci}_{key}"] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "step_golden.npz"), **out)
+
+
 def picker_vectors():
     """Reference Picker / PickerPickPlace (environment/flex_utils.py) driven through a `pyflex` stub that is backed by
     the CPU oracle; the movep loop is simEnv.py:739-769 verbatim in behaviour (SimEnv itself needs ray/h5py/trimesh to
@@ -630,14 +885,14 @@ def task_vectors():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling", "action", "task"]
+    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling", "action", "task", "step"]
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:
         camera_vectors()
     if "nets" in which and "nets_vectors" in globals():
         nets_vectors()
-    if "envutils" in which and "envutils_vectors" in globals():
+    if "envutils" in which:
         envutils_vectors()
     if "picker" in which:
         picker_vectors()
@@ -647,3 +902,5 @@ if __name__ == "__main__":
         action_vectors()
     if "task" in which:
         task_vectors()
+    if "step" in which:
+        step_vectors()

@@ -40,3 +40,26 @@ def test_batched_env_reset_and_step(gpu_required):
     assert steps_taken >= 1 and all(terminate.values())  # episode_length = 2 (or an early end)
     assert obs == {}                                       # nothing left to observe
     assert env.prim.sim_steps > 0
+
+
+def test_step_bookkeeping_matches_reference_golden(gpu_required):
+    """SimEnv.step (environment/simEnv.py:464-515) recorded from the reference's own method with the action selection
+    scripted (tests/golden/make_golden.py step): BatchedFlingEnv.step_actions on the device reproduces rewards,
+    termination (early end when the cloth did not move, episode_length, a fling aborted because the grasp missed), timesteps,
+    simulation-step counts, grasp flags, every particle position and the picker states bit for bit."""
+    from fling_helpers import load_step_golden, run_step_golden
+    from flingbot_amd import sim as fsim
+
+    g = load_step_golden()
+
+    def make(n):
+        ctx = fsim.FlingSim(n_envs=n, solver=0)
+        for e in range(n):
+            env = ctx.env(e)
+            env.set_scene(g["scene_params"])
+            env.step(1)
+            env.set_positions(g["init_pos"].ravel())
+            env.set_velocities(np.zeros(3 * g["init_pos"].shape[0], np.float32))
+        return ctx
+
+    run_step_golden(make, lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))

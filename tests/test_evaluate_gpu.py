@@ -39,3 +39,59 @@ def test_run_episodes_statistics(gpu_required):
     flat = np.array([t["flatten_area"] for t in tasks])
     assert np.allclose(np.array(ctx.coverage())[:n] / flat, stats["final_coverage"])
     ctx.close()
+
+
+def test_full_size_eval_loop_config5(gpu_required):
+    """BASELINE.json configs[4] at the reference's own sizes (README.md:194, environment/simEnv.py:56-71 defaults): 12 rotations
+    x 8 scales, 720 x 720 render -> 400 x 400 observation with adaptive scaling, cloth sides 64..104 ('hard' tasks of the
+    reference's generator, environment/tasks.py:105-275), 8 episodes x up to 3 actions, seeded random-init fling policy (no
+    flingbot.pth in this image).  Checks the loop's invariants, that every stage ran on its device path (hand-written value
+    net, fs_observe_batch, fs_prepare_image, fs_select_action, streaming / fused solver forms) and reports the rates."""
+    import time
+    from flingbot_amd import nets, sim as fsim, tasks as ftasks
+    from flingbot_amd.env import BatchedFlingEnv
+    from flingbot_amd.evaluate import run_episodes
+
+    random.seed(5); np.random.seed(5); torch.manual_seed(5)
+    n, actions = 8, 3
+    params = [ftasks.draw_task_parameters() for _ in range(n)]          # the reference's defaults: sides 64 .. 104
+    sides = np.array([p["cloth_size"] for p in params])
+    assert sides.min() >= 64 and sides.max() <= 104 and (sides.prod(axis=1) > 4096).any()
+    gen = fsim.FlingSim(n_envs=n, solver=0)
+    tasks = ftasks.generate_tasks(gen, params)
+    gen.close()
+    assert all(t is not None for t in tasks)
+    ctx = fsim.FlingSim(n_envs=n, solver=0)
+    env = BatchedFlingEnv(ctx, episode_length=actions)                  # image_dim 400, render 720, 12 x 8 transforms
+    assert env.image_dim == 400 and env.render_dim == 720 and len(env.transformations) == 96 and env.obs_dim == 64
+    policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+                                     obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
+                                     depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
+                                     value_expl_decay=1.0, device="cuda:0")
+    t0 = time.perf_counter()
+    stats = run_episodes(policy, env, tasks)
+    dt = time.perf_counter() - t0
+    # stages on their device paths
+    assert all(net._hip is not None for net in policy.value_nets.values())
+    assert ctx.last_kernel_form() in (fsim.FS_FORM_STREAM_EAGER, fsim.FS_FORM_STREAM_CODED, fsim.FS_FORM_STREAM_GRID,
+                                      fsim.FS_FORM_STREAM_ELL)            # cloths above 4096 particles stream
+    assert all(np.asarray(d).shape == (400, 400) for d in env.pretransform_depth.values())
+    assert all(len(f) == 8 for f in env.adaptive_scale_factors.values())
+    # the loop's invariants
+    T = stats["coverage_steps"].shape[0]
+    assert 2 <= T <= actions + 1 and stats["coverage_steps"].shape[1] == n
+    assert np.allclose(stats["coverage_steps"][0], stats["init_coverage"])
+    assert np.allclose(stats["final_coverage"] - stats["init_coverage"], stats["delta_coverage_steps"].sum(axis=0), atol=1e-6)
+    assert (stats["episode_length"] >= 1).all() and (stats["episode_length"] <= actions).all()
+    assert (stats["init_coverage"] > 0.05).all() and (stats["init_coverage"] < 1.0).all()   # crumpled 'hard' tasks
+    assert np.isfinite(stats["final_coverage"]).all() and (stats["final_coverage"] < 1.2).all()
+    assert all(env.terminate.values())
+    flings = sum(stats["action_primitive_counts"].values())
+    assert flings >= 1 and stats["simulation_steps"] > 300 * flings
+    flat = np.array([t["flatten_area"] for t in tasks])
+    assert np.allclose(np.array(ctx.coverage())[:n] / flat, stats["final_coverage"])
+    print(f"\n  config 5 (8 episodes, sides {sides.min()}..{sides.max()}, 12 x 8 transforms, 720 -> 400): {dt:.2f} s, "
+          f"{flings} flings ({flings / dt:.1f} /s), {stats['simulation_steps']} episode-steps "
+          f"({stats['simulation_steps'] / dt:.0f} /s), coverage {stats['mean']['init_coverage']:.3f} -> "
+          f"{stats['mean']['final_coverage']:.3f}")
+    ctx.close()

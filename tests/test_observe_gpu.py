@@ -75,3 +75,32 @@ def test_largest_component_of_several_and_empty(gpu_required):
     obs, bbox = ctx.observe(0, 200)
     assert bbox.tolist() == [-1, -1, -1, -1, 0]
     ctx.close()
+
+
+def test_observe_batch_equals_single_calls(gpu_required):
+    """fs_observe_batch (one set of host round trips for all episodes) returns, per episode, exactly what fs_observe does:
+    episodes whose labelling converges after different numbers of rounds, one without any cloth in view."""
+    from flingbot_amd import sim as fsim
+
+    n = 5
+    ctx = fsim.FlingSim(n_envs=n, solver=0)
+    dims = [(40, 30), (64, 64), (24, 50), (32, 32), (48, 20)]
+    for e in range(n):
+        env = _scene(ctx, e, dims[e], seed=10 + e, crumple=e != 3)
+        cp = ctx.get_camera_params(e)
+        ctx.set_camera_params(e, [*cp[2:8], 360, 360])
+    ctx.step(20)
+    q = ctx.get_positions(3).reshape(-1, 4).copy()
+    q[:, 0] += 50.0   # episode 3: the cloth is out of view
+    ctx.set_positions(3, q.ravel())
+    singles = [ctx.observe(e, 160, want_mask=True) for e in range(n)]
+    order = [4, 0, 3, 1, 2]
+    obs, bbox, mask = ctx.observe_batch(order, 160, want_mask=True)
+    assert tuple(obs.shape) == (n, 4, 160, 160) and bbox.shape == (n, 5)
+    for k, e in enumerate(order):
+        o1, b1, m1 = singles[e]
+        assert np.array_equal(obs[k].cpu().numpy(), o1.cpu().numpy()), e
+        assert bbox[k].tolist() == b1.tolist(), e
+        assert np.array_equal(mask[k].cpu().numpy(), m1.cpu().numpy()), e
+    assert bbox[2].tolist() == [-1, -1, -1, -1, 0] and (bbox[[0, 1, 3, 4], 4] > 0).all()
+    ctx.close()

@@ -559,6 +559,50 @@ def test_action_selector_host_evaluation_matches_reference_golden():
         assert np.array_equal(res["p1"], g[f"c{ci}_p1"]) and np.array_equal(res["p2"], g[f"c{ci}_p2"]), ci
 
 
+def test_envutils_host_mirror_matches_reference_vectors():
+    """environment/utils.py:161-276, 579-582 (compute_pose, compute_intrinsics, get_transform_matrix, pixel_to_3d,
+    pixels_to_3d_positions, preprocess_obs) run by tests/golden/make_golden.py::envutils_vectors on seeded inputs: the
+    product's host mirror (flingbot_amd/action.py) and the oracle's restatements reproduce every output EXACTLY."""
+    from flingbot_amd import action as fa
+    from oracle import action as oa
+    from oracle import observe as oo
+
+    g = np.load(os.path.join(GOLD, "envutils_golden.npz"))
+    for mod in (fa, oa):
+        for k, (pos, lookat, up) in enumerate(g["pose_in"]):
+            assert np.array_equal(mod.compute_pose(pos=list(pos), lookat=list(lookat), up=list(up)), g["pose_out"][k])
+        for k, (fov, size) in enumerate(g["intrinsics_in"]):
+            assert np.array_equal(mod.compute_intrinsics(fov, size), g["intrinsics_out"][k])
+        for k, (a, b, rot, sc_) in enumerate(g["tm_in"]):
+            assert np.array_equal(mod.get_transform_matrix(original_dim=int(a), resized_dim=int(b), rotation=rot, scale=sc_),
+                                  g["tm_out"][k])
+        for pk in range(2):
+            for q, (x, y) in enumerate(g["p3d_xy"]):
+                got = mod.pixel_to_3d(g["p3d_depth"].copy(), int(x), int(y), pose_matrix=g["pose_out"][pk])
+                assert np.array_equal(got, g["p3d_out"][pk][q]) and got.dtype == g["p3d_out"].dtype
+        assert np.array_equal(mod.pixel_to_3d(g["p3d_depth"].copy(), 20, 30, pose_matrix=g["pose_out"][0], fov=50.0,
+                                              depth_scale=0.5), g["p3d_scaled"])
+    assert np.allclose(fa.pixel_to_3d(np.full((400, 400), 2.0, np.float32), 300, 200, g["pose_out"][0]), [0.36, 0, 0],
+                       atol=1e-6)  # the known answer SURVEY.md 8c quotes
+    for k in range(int(g["pp_n"])):
+        v = g[f"pp{k}_in"]
+        pix, scale, rot, only = v[:4].astype(int).reshape(2, 2), v[4], v[5], bool(v[6])
+        r = fa.pixels_to_3d_positions(pixels=pix, scale=scale, rotation=rot, pretransform_depth=g["pp_depth"].copy(),
+                                      transformed_depth=np.zeros((32, 32), np.float32), pose_matrix=g["pose_out"][0],
+                                      pretransform_pix_only=only)
+        assert bool(r["valid_action"]) == bool(g[f"pp{k}_valid"])
+        assert np.array_equal(r["pretransform_pixels"], g[f"pp{k}_pixels"])
+        assert (r.get("p1") is not None) == bool(g[f"pp{k}_has_points"])
+        if r.get("p1") is not None:
+            assert np.array_equal(r["p1"], g[f"pp{k}_p1"]) and np.array_equal(r["p2"], g[f"pp{k}_p2"])
+    assert sum(bool(g[f"pp{k}_valid"]) for k in range(int(g["pp_n"]))) >= 3 and not bool(g["pp4_valid"])
+    obs = fa.preprocess_obs(g["obs_rgb"].copy(), g["obs_d"].copy())
+    assert obs.dtype.is_floating_point and np.array_equal(obs.numpy(), g["obs_out"])
+    # the oracle of the device observation stage composes its tensor with the same expression
+    ref = np.concatenate([g["obs_rgb"].astype(np.float32) / np.float32(255), g["obs_d"][:, :, None]], 2).transpose(2, 0, 1)
+    assert np.array_equal(ref, g["obs_out"]) and oo.get_obs is not None
+
+
 def test_drag_place_stretchdrag_host_logic_reproduces_reference_golden():
     """primitives.pick_and_drag / pick_and_place / pick_stretch_drag on the CPU oracle retrace what the REFERENCE's
     SimEnv.pick_and_drag_primitive / pick_and_place_primitive / pick_stretch_drag_primitive did
@@ -666,3 +710,15 @@ def test_observe_resize_agrees_with_an_independent_bilinear():
         reff = F.interpolate(torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None], size=(dst, dst), mode="bilinear",
                              align_corners=False)[0].permute(1, 2, 0).numpy()
         assert np.abs(oo.resize_linear_u8(img, dst).astype(np.float32) - reff).max() <= 1.0, (src, dst)
+
+
+def test_env_step_bookkeeping_reproduces_reference_golden():
+    """SimEnv.step (environment/simEnv.py:464-515) around the primitives -- preaction / postaction, the "cloth did not move"
+    early end, episode_length, the coverage reward, grasp flags that survive an aborted fling -- through
+    BatchedFlingEnv.step_actions with the CPU oracle standing in for the device (host logic only), against the golden
+    recorded from the reference's own SimEnv.step (tests/golden/make_golden.py step)."""
+    from fling_helpers import OracleBatch, load_step_golden, run_step_golden
+
+    g = load_step_golden()
+    run_step_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"], pickers=False),
+                    lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
