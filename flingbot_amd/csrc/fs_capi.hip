@@ -100,13 +100,14 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
 extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
 extern "C" int fs_n_envs(const fs_ctx *ctx) { return ctx ? ctx->n_envs : FS_ERR_ARG; }
 extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
-    if (!ctx || solver < 0 || solver > 5) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    if (!ctx || solver < 0 || solver > 6) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    ctx->force_coded_stream = (solver == FS_SOLVER_STREAM_CODED);
     ctx->force_generic_fused = (solver == FS_SOLVER_FUSED_GENERIC);
     ctx->force_coded_fused = (solver == FS_SOLVER_FUSED_CODED);
     ctx->force_ell_stream = (solver == FS_SOLVER_STREAM_ELL);
     ctx->solver = (solver == FS_SOLVER_FUSED_GENERIC || solver == FS_SOLVER_FUSED_CODED)
                       ? FS_SOLVER_FUSED
-                      : (solver == FS_SOLVER_STREAM_ELL ? FS_SOLVER_STREAM : solver);
+                      : ((solver == FS_SOLVER_STREAM_ELL || solver == FS_SOLVER_STREAM_CODED) ? FS_SOLVER_STREAM : solver);
     return FS_OK;
 }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
@@ -172,7 +173,7 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         topo->restnear_w = c.take<uint32_t>(size_t(8) * n + 1);
         topo->sdict = c.take<FsVec4>(256);
         topo->scode = c.take<FsU32x4>(n + 1);
-        topo->g64_L = c.take<float>(s.g64_ok ? size_t(FS_G64_SLOTS) * n : 1);
+        topo->g64_L = c.take<float>(s.gp_L_ok ? size_t(FS_G64_SLOTS) * n : 1);
         topo->tris = c.take<int>(size_t(3) * s.t + 1);
         topo->vt_off = c.take<int>(n + 1);
         topo->vt_tri = c.take<int>(size_t(3) * s.t + 1);
@@ -205,7 +206,10 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
     topo->restnear_ok = s.restnear_ok;
     up(topo->restnear_w, s.restnear_w.data(), size_t(8) * n * 4);
     topo->g64_ok = s.g64_ok;
-    if (s.g64_ok) up(topo->g64_L, s.g64_L.data(), size_t(FS_G64_SLOTS) * n * 4);
+    topo->gp_L_ok = s.gp_L_ok;
+    topo->gp_magic = s.gp_magic;
+    topo->gp_halvable = s.gp_halvable;
+    if (s.gp_L_ok) up(topo->g64_L, s.g64_L.data(), size_t(FS_G64_SLOTS) * n * 4);
     for (int q = 0; q < FS_G64_SLOTS; ++q) topo->g64_k[q] = s.g64_k[q];
     up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
     up(topo->vt_off, s.vt_off.data(), (n + 1) * 4);
@@ -292,8 +296,9 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     d.gp_count = scene.sdict_size > 0 ? scene.gp_count : 0;  // the pattern is used together with the spring codes
     d.gp_dimx = scene.gp_dimx; d.gp_dimz = scene.gp_dimz; d.gp_pad = 0;
     for (int q = 0; q < 16; ++q) { d.gp_dx[q] = scene.gp_dx[q]; d.gp_dz[q] = scene.gp_dz[q]; }
-    d.g64_ok = topo->g64_ok; d.g64_L = topo->g64_L; d.g64_pad = 0;
-    for (int q = 0; q < FS_G64_SLOTS; ++q) d.g64_kh[q] = topo->g64_k[q] * 0.5f;
+    d.g64_ok = topo->g64_ok; d.g64_L = topo->g64_L;
+    d.gp_L_ok = topo->gp_L_ok; d.gp_magic = topo->gp_magic; d.gp_halvable = topo->gp_halvable;
+    for (int q = 0; q < FS_G64_SLOTS; ++q) { d.g64_kh[q] = topo->g64_k[q] * 0.5f; d.gp_k[q] = topo->g64_k[q]; }
     d.p = scene.params;
 
     // uploads (main.cpp:1025-1085): positions, velocities (zero), phases

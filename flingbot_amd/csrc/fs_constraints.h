@@ -109,6 +109,32 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
     a.cnt += active ? 1 : 0;
 }
 
+// fs_spring_bf with a per-lane "this slot exists" predicate (grid forms: a slot that leaves the grid gathers the particle
+// itself and must neither move nor count it, whatever its length)
+__device__ __forceinline__ void fs_spring_bfm(FsAcc &a, float xi0, float xi1, float xi2, float wi, const FsVec4 xj, float L,
+                                              float k, bool in) {
+    float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
+    float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
+    float inv_len = fs_rsqrt(l2);
+    float len = l2 * inv_len;
+    float C = len - L;
+    const bool tether = k < 0.0f;
+    const bool active = in & (len > 0.0f) & (!tether | (C > 0.0f));
+    const float kk = tether ? -k : k;
+    const float wj = xj.w;
+    float ratio = 0.5f;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(wj != wi) != 0ull, 0)) {
+        ratio = (wj == wi) ? 0.5f : 1.0f;
+        const bool odd = active & (wj != wi) & (wj != 0.0f);
+        if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
+    }
+    float sc = active ? (kk * ratio) * (C * inv_len) : 0.0f;
+    a.d0 = FS_FMA(-ex, sc, a.d0);
+    a.d1 = FS_FMA(-ey, sc, a.d1);
+    a.d2 = FS_FMA(-ez, sc, a.d2);
+    a.cnt += active ? 1 : 0;
+}
+
 // fs_spring_bf for the case that covers a free cloth: the neighbour has the particle's own mass (ratio == 0.5 exactly)
 // and the cloth has no tethers (every k > 0); kh = 0.5 * k (exact: a power-of-two scaling).  Performs exactly the
 // operations of fs_spring on an active constraint, in the same order -- (k * 0.5) * (C * inv_len) -- minus the tests

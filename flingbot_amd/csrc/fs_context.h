@@ -30,7 +30,8 @@ struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
     FsVec4 *sdict = nullptr;
     FsU32x4 *scode = nullptr;
     int restnear_ok = 0;
-    int g64_ok = 0;
+    int g64_ok = 0, gp_L_ok = 0, gp_halvable = 0;
+    uint32_t gp_magic = 0;
     float *g64_L = nullptr;  // [12][n] canonical-slot rest lengths of the grid-64 fused kernel
     float g64_k[FS_G64_SLOTS] = {0};
     int *tris = nullptr;  // 3t
@@ -71,6 +72,7 @@ struct fs_ctx {
     int solver = 0;
     bool force_ell_stream = false;     // FS_SOLVER_STREAM_ELL: streaming kernels with the uncompressed ELL adjacency
     bool force_generic_fused = false;  // FS_SOLVER_FUSED_GENERIC: fused kernel with the streamed ELL adjacency
+    bool force_coded_stream = false;   // FS_SOLVER_STREAM_CODED: never the grid-L form (dictionary-coded / latency / grid forms by size)
     bool force_coded_fused = false;    // FS_SOLVER_FUSED_CODED: never the grid-64 form (dictionary-coded adjacency kernel)
     bool fused_attr_set = false;       // hipFuncAttributeMaxDynamicSharedMemorySize applied on this context's device
     int last_form = 0;                 // FS_FORM_* of the most recent solver launch (fs_last_kernel_form)

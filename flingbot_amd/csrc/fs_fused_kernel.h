@@ -72,6 +72,20 @@ __device__ __forceinline__ void fs_st4(FsVec4 *p, size_t i, const FsVec4 v) {
     ((FS_GLOBAL fs_f4 *)p)[i] = fs_f4{v.x, v.y, v.z, v.w};
 }
 
+// the same with a 32-bit BYTE offset from a (uniform) base: global_load / global_store with a scalar base register and a
+// 32-bit vector offset instead of a 64-bit vector address built with VALU adds
+__device__ __forceinline__ FsVec4 fs_ld4o(const FsVec4 *base, unsigned idx) {
+    const fs_f4 v = *(FS_GLOBAL const fs_f4 *)((FS_GLOBAL const char *)base + (idx << 4));
+    return FsVec4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void fs_st4o(FsVec4 *base, unsigned idx, const FsVec4 v) {
+    *(FS_GLOBAL fs_f4 *)((FS_GLOBAL char *)base + (idx << 4)) = fs_f4{v.x, v.y, v.z, v.w};
+}
+template <typename T>
+__device__ __forceinline__ T fs_ldo(const T *base, unsigned idx) {
+    return *(FS_GLOBAL const T *)((FS_GLOBAL const char *)base + (idx << 2));
+}
+
 // Cell -> bucket of the LDS hash.  The row (cy, cz) is hashed, x is added on top: the three cells cx-1..cx+1 a search
 // visits per row are ADJACENT buckets, i.e. one contiguous run of the bucket-ordered arrays (9 runs per particle instead
 // of 27 cells; longer runs also even out the per-lane trip counts of a wave).

@@ -249,28 +249,33 @@ void build_grid_pattern(FsHostScene &s, int dimx, int dimz) {
     s.gp_count = cdeg;
 }
 
-// Tables of the grid-64 fused kernel, or g64_ok = 0 when the cloth does not have that structure (see fs_scene.h).
+// Rest lengths in canonical slot order for ANY grid cloth whose springs follow FS_G64_DX_LIST / FS_G64_DZ_LIST with one
+// stiffness per slot (gp_L_ok), and on top of that the structure the grid-64 fused kernel needs (g64_ok): see fs_scene.h.
 void build_grid64(FsHostScene &s) {
     s.g64_ok = 0;
+    s.gp_L_ok = 0;
+    s.gp_halvable = 0;
     s.g64_L.clear();
+    s.gp_magic = 0;
     static const int cdx[FS_G64_SLOTS] = FS_G64_DX_LIST, cdz[FS_G64_SLOTS] = FS_G64_DZ_LIST;
-    if (s.gp_count != FS_G64_SLOTS || s.gp_dimx != 64 || s.gp_dimz < 5 || s.gp_dimz > 64) return;
+    if (s.gp_count != FS_G64_SLOTS || s.gp_dimx < 5 || s.gp_dimz < 5 || s.gp_dimx > 4096) return;
     for (int q = 0; q < FS_G64_SLOTS; ++q)
         if (s.gp_dx[q] != cdx[q] || s.gp_dz[q] != cdz[q]) return;
-    const int n = s.n, dimz = s.gp_dimz;
+    const int n = s.n, dimx = s.gp_dimx, dimz = s.gp_dimz;
     std::vector<float> L(size_t(FS_G64_SLOTS) * n, 0.0f);
     bool have_k[FS_G64_SLOTS] = {false};
+    bool halvable = true;
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
     for (int i = 0; i < n; ++i) {
-        const int ix = i % 64, iz = i / 64;
+        const int ix = i % dimx, iz = i / dimx;
         int a = s.adj_off[i];
         for (int q = 0; q < FS_G64_SLOTS; ++q) {
             const int jx = ix + cdx[q], jz = iz + cdz[q];
-            if (jx < 0 || jx >= 64 || jz < 0 || jz >= dimz) continue;
+            if (jx < 0 || jx >= dimx || jz < 0 || jz >= dimz) continue;
             // build_grid_pattern has verified that adjacency entry `a` is exactly this neighbour
             const float k = s.adj_k[a];
-            if (!(k > 0.0f) || (k * 0.5f) * 2.0f != k) return;          // tethers / non-halvable stiffness: coded kernel
             if (have_k[q] && bits(s.g64_k[q]) != bits(k)) return;       // one stiffness per slot
+            if (!(k > 0.0f) || (k * 0.5f) * 2.0f != k) halvable = false;  // tethers / non-halvable stiffness
             s.g64_k[q] = k; have_k[q] = true;
             L[size_t(q) * n + i] = s.adj_len[a];
             ++a;
@@ -278,17 +283,28 @@ void build_grid64(FsHostScene &s) {
     }
     for (int q = 0; q < FS_G64_SLOTS; ++q)
         if (!have_k[q]) return;
-    // x-direction slots: one rest length per column (taken from row 2 by the kernel); z-direction slots: one per row
+    // row = (i * magic) >> 32 for every i < n (checked): one v_mul_hi instead of an integer division per thread
+    const uint64_t magic = ((uint64_t(1) << 32) + dimx - 1) / dimx;
+    if (magic > 0xffffffffull) return;
+    for (int i = 0; i < n; ++i)
+        if (int((uint64_t(i) * magic) >> 32) != i / dimx) return;
+    s.gp_magic = uint32_t(magic);
+    s.g64_L.swap(L);
+    s.gp_L_ok = 1;
+    s.gp_halvable = halvable ? 1 : 0;
+    // grid-64 form: 64 columns, at most 64 rows, positive halvable stiffness; x-direction slots: one rest length per
+    // column (taken from row 2 by the kernel); z-direction slots: one per row
+    if (dimx != 64 || dimz > 64 || !halvable) return;
+    const std::vector<float> &T = s.g64_L;
     for (int i = 0; i < n; ++i) {
         const int ix = i % 64, iz = i / 64;
         for (int q = 0; q < FS_G64_SLOTS; ++q) {
             const int jx = ix + cdx[q], jz = iz + cdz[q];
             if (jx < 0 || jx >= 64 || jz < 0 || jz >= dimz) continue;
-            if (cdz[q] == 0 && bits(L[size_t(q) * n + i]) != bits(L[size_t(q) * n + 2 * 64 + ix])) return;
-            if (cdx[q] == 0 && bits(L[size_t(q) * n + i]) != bits(L[size_t(q) * n + iz * 64 + 2])) return;
+            if (cdz[q] == 0 && bits(T[size_t(q) * n + i]) != bits(T[size_t(q) * n + 2 * 64 + ix])) return;
+            if (cdx[q] == 0 && bits(T[size_t(q) * n + i]) != bits(T[size_t(q) * n + iz * 64 + 2])) return;
         }
     }
-    s.g64_L.swap(L);
     s.g64_ok = 1;
 }
 

@@ -61,7 +61,10 @@ struct FsHostScene {
     // lengths (slots with dz == 0) depend on the column only and whose z-direction ones (dx == 0) on the row only --
     // what lower + spacing * (x, 0, z) in fp32 produces (helpers.h:852).  g64_L: rest lengths [12][n] in canonical slot
     // order; g64_k: stiffness per slot.
-    int g64_ok = 0;
+    // gp_L_ok: the table alone (any grid size, any sign of stiffness, one stiffness per slot) -- what the streaming
+    // kernels' grid form reads instead of an adjacency; gp_magic = ceil(2^32 / dimx): row = (i * gp_magic) >> 32.
+    int g64_ok = 0, gp_L_ok = 0, gp_halvable = 0;  // gp_halvable: every stiffness positive and exactly halvable
+    uint32_t gp_magic = 0;
     std::vector<float> g64_L;
     float g64_k[FS_G64_SLOTS] = {0};
     // rest-pose neighbours for the SelfCollideFilter test (NvFlex.h:166,564-565): ids of the particles closer than the

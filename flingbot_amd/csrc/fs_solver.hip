@@ -54,9 +54,14 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         grid_form = grid_form && d.sdict_size > 0 && d.gp_count > 0 && d.gp_count <= FS_GRID_SLOTS;
     }
     grid_form = grid_form && (size_t)max_n * ids.size() >= (size_t)96 * 4096;
+    // canonical grid cloths: neighbour ids from the grid coordinates, rest lengths from the per-particle table -- no
+    // adjacency, no dictionary, every load of the spring phase in one round trip (fs_k_iterate_gridl)
+    bool gridl_form = !ctx->force_ell_stream && !ctx->force_coded_stream;
+    for (int id : ids) gridl_form = gridl_form && ctx->envs[id].dev.gp_L_ok;
     hipStream_t st = ctx->stream;
-    ctx->last_form = grid_form ? FS_FORM_STREAM_GRID
-                               : (eager ? FS_FORM_STREAM_EAGER : (coded ? FS_FORM_STREAM_CODED : FS_FORM_STREAM_ELL));
+    ctx->last_form = gridl_form ? FS_FORM_STREAM_GRIDL
+                     : grid_form ? FS_FORM_STREAM_GRID
+                                 : (eager ? FS_FORM_STREAM_EAGER : (coded ? FS_FORM_STREAM_CODED : FS_FORM_STREAM_ELL));
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
             hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
@@ -66,6 +71,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             for (int it = 0; it < iters; ++it) {
                 auto kern = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
                 if (grid_form) kern = fs_k_iterate_grid;
+                if (gridl_form) kern = fs_k_iterate_gridl;
                 hipLaunchKernelGGL(kern, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1, gx, ne);
             }
             hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1, gx, ne);

@@ -41,10 +41,10 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, co
     if (i >= E.n) return;
     const FsParams &p = E.p;
     const float h = p.dt / (float)p.numSubsteps;
-    FsVec4 x = E.pos[i];
-    FsVec4 v = E.vel[i];
-    E.x0[i] = x;
-    E.v0[i] = v;
+    FsVec4 x = fs_ld4o(E.pos, (unsigned)i);  // scalar base + 32-bit offset (global_load saddr form), like every access below
+    FsVec4 v = fs_ld4o(E.vel, (unsigned)i);
+    fs_st4o(E.x0, (unsigned)i, x);
+    fs_st4o(E.v0, (unsigned)i, v);
     FsVec4 xp = x;
     if (x.w > 0.0f) {
         float vx = v.x + h * (p.gravity[0] - p.damping * v.x);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, co
         xp.y = x.y + h * vy;
         xp.z = x.z + h * vz;
     }
-    E.xa[i] = xp;
+    fs_st4o(E.xa, (unsigned)i, xp);
     const float inv = 1.0f / (p.radius + p.particleCollisionMargin);
     int b = fs_stream_bucket((int)floorf(xp.x * inv), (int)floorf(xp.y * inv), (int)floorf(xp.z * inv));
     atomicAdd(&E.cell_count[b], 1);
@@ -103,12 +103,12 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
     if (i >= E.n) return;
     const FsParams &p = E.p;
     const float inv = 1.0f / (p.radius + p.particleCollisionMargin);
-    FsVec4 xp = E.xa[i];
+    FsVec4 xp = fs_ld4o(E.xa, (unsigned)i);
     int b = fs_stream_bucket((int)floorf(xp.x * inv), (int)floorf(xp.y * inv), (int)floorf(xp.z * inv));
     int slot = atomicAdd(&E.cell_fill[b], 1);
     // bucket-ordered copy of the predicted positions with the particle id in w: the search reads candidates sequentially
     // (xb is free until the first Jacobi iteration writes it)
-    E.xb[slot] = FsVec4{xp.x, xp.y, xp.z, __int_as_float(i)};
+    fs_st4o(E.xb, (unsigned)slot, FsVec4{xp.x, xp.y, xp.z, __int_as_float(i)});
 }
 
 // ---- particle-contact candidates: ascending neighbour id, the (up to) 96 smallest ids.
@@ -434,6 +434,94 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *env
     fs_iterate_particle_grid(E, shapes[e], i, i < E.n, sub, flip, sdict);
 }
 
+// GRID-L form of the iteration (grid cloths with the canonical spring list, FsEnvDev::gp_L_ok): like the GRID form the
+// neighbour ids follow from (column, row) + the canonical (dx, dz) list -- compile-time constants here, the host has
+// verified the cloth against FS_G64_DX_LIST / FS_G64_DZ_LIST -- and the rest lengths come from the per-particle table
+// gp_L[12][n] in canonical slot order (coalesced), the stiffness per slot from the descriptor (scalar).  Nothing has to be
+// decoded or staged: no dictionary, no workgroup barrier, and ALL loads of the spring phase -- own position, twelve
+// neighbour positions, twelve rest lengths, substep-start position, candidate count and the first candidate ids -- leave
+// in one round trip.  Per-particle accumulation order = canonical order = spring-id order (build_grid_pattern).
+__device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip) {
+    const FsParams &p = E.p;
+    // global address space + 32-bit indices: global_load with a scalar base instead of flat loads behind 64-bit VALU adds
+    const FsVec4 *src = flip ? E.xb : E.xa;
+    FsVec4 *dst = flip ? E.xa : E.xb;
+    constexpr int cdx[FS_G64_SLOTS] = FS_G64_DX_LIST, cdz[FS_G64_SLOTS] = FS_G64_DZ_LIST;
+    const unsigned un = (unsigned)E.n, ui = (unsigned)i;
+    FsVec4 xi = fs_ld4o(src, ui);
+    const FsVec4 x0i = fs_ld4o(E.x0, ui);
+    const int nc = fs_ldo(E.ncount, ui);
+    int cj0[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cj0[k] = fs_ldo(E.nlist, (unsigned)k * un + ui);  // slots beyond the count hold stale ids: masked below
+    const int dimx = E.gp_dimx, dimz = E.gp_dimz;
+    const int iz = (int)__umulhi(ui, E.gp_magic), ix = i - iz * dimx;
+    FsVec4 xj[FS_G64_SLOTS];
+    float L[FS_G64_SLOTS];
+    unsigned inb = 0u;
+#pragma unroll
+    for (int q = 0; q < FS_G64_SLOTS; ++q) {
+        const bool in = (unsigned)(ix + cdx[q]) < (unsigned)dimx && (unsigned)(iz + cdz[q]) < (unsigned)dimz;
+        inb |= (unsigned)in << q;
+        xj[q] = fs_ld4o(src, in ? (unsigned)(i + cdz[q] * dimx + cdx[q]) : ui);
+        L[q] = fs_ldo(E.g64_L, (unsigned)q * un + ui);
+    }
+    if (!(xi.w > 0.0f)) {
+        fs_st4o(dst, ui, xi);
+        return;
+    }
+    FsAcc a = {0.0f, 0.0f, 0.0f, 0};
+    // (An equal-mass fast form like the fused grid-64 kernel's -- 26 instead of 37 VALU instructions per spring, wave-uniform
+    // fallback -- was measured here and is SLOWER at every launch size (64 episodes: 1.42 -> 1.51 ms per step): this kernel
+    // runs one round of 4-5 waves per SIMD and is bound by its load latency and the launch, not by VALU issue, and the second
+    // code path costs registers.)
+#pragma unroll
+    for (int q = 0; q < FS_G64_SLOTS; ++q)
+        fs_spring_bfm(a, xi.x, xi.y, xi.z, xi.w, xj[q], L[q], E.gp_k[q], (inb >> q) & 1u);
+    const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
+    const float restd = p.solidRestDistance, restd2 = restd * restd;
+    // candidates: four per trip, the ids of the next trip requested with the positions of the current one
+    int cj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cj[k] = (k < nc && cj0[k] >= 0 && cj0[k] < E.n) ? cj0[k] : -1;
+    for (int q0 = 0; q0 < nc; q0 += 4) {
+        int cjn[4] = {-1, -1, -1, -1};
+        if (q0 + 4 < nc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cjn[k] = q0 + 4 + k < nc ? fs_ldo(E.nlist, (unsigned)(q0 + 4 + k) * un + ui) : -1;
+        }
+        FsVec4 cx[4], c0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned j = cj[k] < 0 ? ui : (unsigned)cj[k];
+            cx[k] = fs_ld4o(src, j);
+            c0[k] = fs_ld4o(E.x0, j);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cj[k] >= 0)
+                fs_particle_contact(a, xi.x, xi.y, xi.z, xi.w, ri0, ri1, ri2, cx[k], cx[k].x - c0[k].x, cx[k].y - c0[k].y,
+                                    cx[k].z - c0[k].z, restd, restd2, p.particleFriction);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
+    }
+    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
+    fs_st4o(dst, ui, xi);
+}
+
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+                                                              int sub, int flip, int gx, int ne) {
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    const int e = ids[by];
+    if (e < 0) return;  // retired slot
+    const FsEnvDev &E = envs[e];
+    const int i = bx * FS_TILE + threadIdx.x;
+    if (i >= E.n) return;
+    fs_iterate_particle_gridl(E, shapes[e], i, sub, flip);
+}
+
 // The spring dictionary of the workgroup's episode -> LDS (one entry per thread; FS_TILE = 256 = dictionary size).
 template <bool CODED>
 __device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict) {
@@ -486,13 +574,13 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, c
     const FsParams &p = E.p;
     const float h = p.dt / (float)p.numSubsteps;
     const float inv_h = 1.0f / h;
-    const FsVec4 x0 = E.x0[i];
+    const FsVec4 x0 = fs_ld4o(E.x0, (unsigned)i);
     if (!(x0.w > 0.0f)) {
-        E.vel[i] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+        fs_st4o(E.vel, (unsigned)i, FsVec4{0.0f, 0.0f, 0.0f, 0.0f});
         return;
     }
-    const FsVec4 xp = (flip ? E.xb : E.xa)[i];
-    const FsVec4 v0 = E.v0[i];
+    const FsVec4 xp = fs_ld4o(flip ? E.xb : E.xa, (unsigned)i);
+    const FsVec4 v0 = fs_ld4o(E.v0, (unsigned)i);
     float vx = (xp.x - x0.x) * inv_h, vy = (xp.y - x0.y) * inv_h, vz = (xp.z - x0.z) * inv_h;
     float ax = vx - v0.x, ay = vy - v0.y, az = vz - v0.z;
     float dv2 = ax * ax + ay * ay + az * az;
@@ -509,9 +597,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, c
     }
     const float thr2 = p.sleepThreshold * p.sleepThreshold;
     if (v2 < thr2) {
-        E.vel[i] = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+        fs_st4o(E.vel, (unsigned)i, FsVec4{0.0f, 0.0f, 0.0f, 0.0f});
     } else {
-        E.vel[i] = FsVec4{vx, vy, vz, 0.0f};
-        E.pos[i] = FsVec4{xp.x, xp.y, xp.z, x0.w};
+        fs_st4o(E.vel, (unsigned)i, FsVec4{vx, vy, vz, 0.0f});
+        fs_st4o(E.pos, (unsigned)i, FsVec4{xp.x, xp.y, xp.z, x0.w});
     }
 }

@@ -95,7 +95,13 @@ struct FsEnvDev {
     // slot-major [12][n] (0 where the slot leaves the grid), and the per-slot stiffness halved; g64_ok = 0 = unavailable
     const float *g64_L;
     float g64_kh[FS_G64_SLOTS];
-    int g64_ok, g64_pad;
+    int g64_ok;
+    // the table alone for any canonical grid cloth (streaming grid form): gp_L_ok, the full stiffness per slot, and
+    // gp_magic = ceil(2^32 / gp_dimx) so that row = (i * gp_magic) >> 32
+    int gp_L_ok;
+    float gp_k[FS_G64_SLOTS];
+    uint32_t gp_magic;
+    int gp_halvable;  // every stiffness positive and exactly halvable: g64_kh = stiffness / 2 is usable (equal-mass spring form)
     // rest-pose neighbour ids for the SelfCollideFilter test, packed like nbr_w but holding plain particle ids
     const uint32_t *restnear_w;  // [8][n], 0xffff = empty
     int restnear_ok;

@@ -37,6 +37,7 @@ typedef struct fs_ctx fs_ctx;
 #define FS_SOLVER_FUSED_GENERIC 3 /* FUSED, but spring adjacency streamed from L2 instead of register-resident */
 #define FS_SOLVER_STREAM_ELL 4    /* STREAM, but with the uncompressed (index, length, stiffness) adjacency arrays */
 #define FS_SOLVER_FUSED_CODED 5   /* FUSED, but never the grid-64 form: the dictionary-coded adjacency kernel */
+#define FS_SOLVER_STREAM_CODED 6  /* STREAM, but never the grid-L form: coded / latency / grid forms chosen by launch size */
 
 const char *fs_last_error(void);
 int fs_version(void);
@@ -130,6 +131,7 @@ int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
 #define FS_FORM_STREAM_CODED 5   /* fs_k_iterate<true>: throughput form, one-byte spring codes */
 #define FS_FORM_STREAM_ELL 6     /* fs_k_iterate<false>: throughput form, uncompressed adjacency */
 #define FS_FORM_STREAM_GRID 7    /* fs_k_iterate_grid: neighbour ids from the grid coordinates (large launches) */
+#define FS_FORM_STREAM_GRIDL 9   /* fs_k_iterate_gridl: canonical grid cloths, rest lengths from the per-particle table */
 #define FS_FORM_FUSED_GRID64 8   /* fs_k_fused_grid64: 64-wide grid cloths, packed two-particle springs, no adjacency */
 int fs_last_kernel_form(const fs_ctx *ctx);
 /* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */

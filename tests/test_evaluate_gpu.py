@@ -73,8 +73,7 @@ def test_full_size_eval_loop_config5(gpu_required):
     dt = time.perf_counter() - t0
     # stages on their device paths
     assert all(net._hip is not None for net in policy.value_nets.values())
-    assert ctx.last_kernel_form() in (fsim.FS_FORM_STREAM_EAGER, fsim.FS_FORM_STREAM_CODED, fsim.FS_FORM_STREAM_GRID,
-                                      fsim.FS_FORM_STREAM_ELL)            # cloths above 4096 particles stream
+    assert ctx.last_kernel_form() == fsim.FS_FORM_STREAM_GRIDL            # grid cloths above 4096 particles stream
     assert all(np.asarray(d).shape == (400, 400) for d in env.pretransform_depth.values())
     assert all(len(f) == 8 for f in env.adaptive_scale_factors.values())
     # the loop's invariants

@@ -36,7 +36,9 @@ def _assert_state_equal(hip, orc, what=""):
         f"{what}: velocities not bit-exact (max abs diff {np.abs(vh - vo).max():.3e})"
 
 
-SOLVERS = [1, 2, 4]  # FS_SOLVER_STREAM (one-byte spring codes), FS_SOLVER_FUSED, FS_SOLVER_STREAM_ELL (uncompressed adjacency)
+# FS_SOLVER_STREAM (grid-L iterate for grid cloths), FS_SOLVER_FUSED (coded adjacency: these cloths are not 64 wide),
+# FS_SOLVER_STREAM_ELL (uncompressed adjacency), FS_SOLVER_STREAM_CODED (latency form fs_k_iterate_eager at one episode)
+SOLVERS = [1, 2, 4, 6]
 
 
 @pytest.mark.parametrize("dims", [(32, 32), (64, 64), (5, 3), (1, 1), (2, 1)])
@@ -148,7 +150,7 @@ def test_streaming_large_launch_uses_grid_form_bit_exact(gpu_required):
     from oracle import OracleSim
 
     n_envs = 100
-    ctx = fsim.FlingSim(n_envs=n_envs, solver=1)
+    ctx = fsim.FlingSim(n_envs=n_envs, solver=fsim.FS_SOLVER_STREAM_CODED)
     orc = OracleSim()
     params = cloth_params(64, 64, pos=(0.0, -0.12, 0.0))
     orc.set_scene(params)

@@ -12,11 +12,12 @@ on distinct-seed episodes, and sampled episodes are compared with the CPU oracle
     fs_k_fused_step<12>   the same batches with FS_SOLVER_FUSED_CODED (every other cloth that fits the fused kernel)
     fs_k_fused_step<0>    FS_SOLVER_FUSED_GENERIC, 9 episodes
     fs_k_fused_step<16>   a mesh cloth with 16 springs per particle, 3 episodes
-    fs_k_iterate<true>    64 x 64x64 episodes, AUTO (BASELINE.json configs[2] and configs[3]'s per-GPU share)
+    fs_k_iterate_gridl    64 x 64x64 episodes, AUTO (BASELINE.json configs[2] and configs[3]'s per-GPU share); 8 episodes;
+                          16 x 104x104 episodes (the upper end of the reference's cloth sizes, environment/tasks.py:108-121)
+    fs_k_iterate<true>    64 x 64x64 episodes, FS_SOLVER_STREAM_CODED (non-canonical cloths at that size)
     fs_k_iterate<false>   64 x 64x64 episodes, FS_SOLVER_STREAM_ELL
-    fs_k_iterate_eager    8 x 64x64 episodes
-    fs_k_iterate_grid     112 x 64x64 distinct episodes
-    fs_k_iterate<true>    16 x 104x104 episodes (the upper end of the reference's cloth sizes, environment/tasks.py:108-121)
+    fs_k_iterate_eager    8 x 64x64 episodes, FS_SOLVER_STREAM_CODED
+    fs_k_iterate_grid     112 x 64x64 distinct episodes, FS_SOLVER_STREAM_CODED
 """
 import threading
 
@@ -229,11 +230,13 @@ def test_fused_16_slot_kernel_bit_exact(gpu_required):
     ctx.close()
 
 
-@pytest.mark.parametrize("solver,form", [(0, "FS_FORM_STREAM_CODED"), (4, "FS_FORM_STREAM_ELL")])
+@pytest.mark.parametrize("solver,form", [(0, "FS_FORM_STREAM_GRIDL"), (6, "FS_FORM_STREAM_CODED"), (4, "FS_FORM_STREAM_ELL")])
 def test_streaming_64_episode_launch_bit_exact(gpu_required, solver, form):
     """BASELINE.json configs[2] (and configs[3]'s per-GPU share): 64 distinct 64x64 episodes in one launch sequence.
-    AUTO routes that size to the streaming back-end's throughput form fs_k_iterate<true> (one-byte spring codes);
-    FS_SOLVER_STREAM_ELL runs fs_k_iterate<false> at the same size."""
+    AUTO routes that size to the streaming back-end, whose iterate kernel for canonical grid cloths is fs_k_iterate_gridl
+    (neighbours from the grid coordinates, rest lengths from the per-particle table); FS_SOLVER_STREAM_CODED runs the
+    dictionary-coded throughput form fs_k_iterate<true> every other cloth gets at this size, FS_SOLVER_STREAM_ELL
+    fs_k_iterate<false>."""
     from flingbot_amd import sim as fsim
 
     contacts = _bench_batch(64, solver, 40, [0, 1, 31, 63], getattr(fsim, form))
@@ -245,8 +248,9 @@ def test_streaming_small_and_large_launch_forms_bit_exact(gpu_required):
     fs_k_iterate_grid (112 episodes >= 96 x 4096 particles)."""
     from flingbot_amd import sim as fsim
 
-    _bench_batch(8, fsim.FS_SOLVER_STREAM, 40, [0, 7], fsim.FS_FORM_STREAM_EAGER)
-    _bench_batch(112, fsim.FS_SOLVER_STREAM, 30, [0, 55, 111], fsim.FS_FORM_STREAM_GRID)
+    _bench_batch(8, fsim.FS_SOLVER_STREAM_CODED, 40, [0, 7], fsim.FS_FORM_STREAM_EAGER)
+    _bench_batch(112, fsim.FS_SOLVER_STREAM_CODED, 30, [0, 55, 111], fsim.FS_FORM_STREAM_GRID)
+    _bench_batch(8, fsim.FS_SOLVER_STREAM, 40, [0, 7], fsim.FS_FORM_STREAM_GRIDL)
 
 
 def test_large_cloth_104_batch_bit_exact(gpu_required):
@@ -270,7 +274,7 @@ def test_large_cloth_104_batch_bit_exact(gpu_required):
     for e in range(n_envs):
         setup(ctx.env(e), e)
     ctx.step(steps)
-    assert ctx.last_kernel_form() == fsim.FS_FORM_STREAM_CODED
+    assert ctx.last_kernel_form() == fsim.FS_FORM_STREAM_GRIDL
     sample = [0, 9, 15]
     orcs = _oracle_runs([lambda o, s=s: setup(o, s) for s in sample], steps)
     for s, o in zip(sample, orcs):
