@@ -202,8 +202,9 @@ def timed_batch(ctx, fdist, torch, steps, warmup, preroll):
         ctx.sync()
         torch.cuda.synchronize()
 
-    if preroll:
-        ctx.step(preroll)                  # bring the workload to its steady crumpled state (untimed, not warm-up)
+    for _ in range(preroll):
+        ctx.step(1)                        # bring the workload to its steady crumpled state (untimed, not warm-up); one
+                                           # frame per launch like the timed steps, so a profile sees launches of ONE shape
     for _ in range(warmup):
         ctx.step(1)
     barrier()

@@ -355,11 +355,16 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
         // crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py): between 64 and 128 episodes.
         solver = FS_SOLVER_FUSED;
         size_t particles = 0;
+        bool grid64 = true;
         for (int id : ids) {
             if (!fs_fused_supported(ctx, ctx->envs[id])) solver = FS_SOLVER_STREAM;
             particles += (size_t)ctx->envs[id].host.n;
+            grid64 = grid64 && ctx->envs[id].dev.g64_ok;
         }
-        if (particles < (size_t)136 * 4096) solver = FS_SOLVER_STREAM;  // measured crossover (crumpled 64x64): 128 episodes 2.65 vs 2.76 ms, 256: 4.67 vs 2.90
+        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py, round 2): streaming 1.54 / 2.49 /
+        // 4.29 ms per step at 64 / 128 / 256 episodes against a flat 2.40-2.47 ms of the grid-64 fused kernel (~123 episodes);
+        // the dictionary-coded fused kernel (2.9 ms) crosses at ~136
+        if (particles < (size_t)(grid64 ? 124 : 136) * 4096) solver = FS_SOLVER_STREAM;
     } else if (solver == FS_SOLVER_FUSED) {
         for (int id : ids)
             if (!fs_fused_supported(ctx, ctx->envs[id])) {
