@@ -1,14 +1,14 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the evaluation loop (scripts/eval_loop_demo.py 32 3: BASELINE.json configs[4] in miniature).
-# GPU box, repo root.  Writes gpurun_out/eval_summary/r01_eval_kernel_stats.csv (copy it to profiles/).
+# GPU box, repo root.  Writes gpurun_out/eval_summary/r02_eval_kernel_stats.csv (copy it to profiles/).
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_eval
 rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out/eval_summary
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o ev -- python3 $ROOT/scripts/eval_loop_demo.py 32 3 > $OUT/stats.log 2>&1
 cd $ROOT
-tail -2 $OUT/stats.log | tee $ROOT/gpurun_out/eval_summary/r01_eval_run.txt
-python3 - $OUT/stats $ROOT/gpurun_out/eval_summary/r01_eval_kernel_stats.csv <<'PY'
+tail -2 $OUT/stats.log | tee $ROOT/gpurun_out/eval_summary/r02_eval_run.txt
+python3 - $OUT/stats $ROOT/gpurun_out/eval_summary/r02_eval_kernel_stats.csv <<'PY'
 import csv, os, sqlite3, sys
 db = [os.path.join(r, f) for r, _, fs in os.walk(sys.argv[1]) for f in fs if f.endswith(".db")][0]
 con = sqlite3.connect(db)
@@ -19,5 +19,5 @@ with open(sys.argv[2], "w", newline="") as fh:
         if pct >= 0.05:
             w.writerow([name[:120], calls, f"{total:.3f}", f"{avg:.3f}", f"{pct:.2f}"])
 PY
-cat $ROOT/gpurun_out/eval_summary/r01_eval_kernel_stats.csv | cut -c1-150
+cat $ROOT/gpurun_out/eval_summary/r02_eval_kernel_stats.csv | cut -c1-150
 find $OUT -name "*.db" -delete

@@ -299,3 +299,25 @@ def test_mixed_phases_take_the_general_pair_filter(gpu_required, solver):
     mask = np.arange(96)[None, :] < co[:, None]
     assert np.array_equal(np.where(mask, lh, -1), np.where(mask, lo, -1))
     _assert_state_equal(hip, orc, "mixed phases")
+
+
+def test_two_contexts_on_two_devices(gpu_required):
+    """One process driving two devices: the fused kernel's dynamic-LDS attribute belongs to each DEVICE's copy of the kernel
+    (tracked per context).  Needs a second GPU; skipped on a one-GPU box."""
+    import torch
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    ctxs = [fsim.FlingSim(n_envs=1, device=d, solver=fsim.FS_SOLVER_FUSED) for d in (0, 1)]
+    orc = OracleSim()
+    p = cloth_params(64, 64, pos=(0.0, -0.05, 0.0))
+    orc.set_scene(p)
+    orc.step(10)
+    for ctx in ctxs:
+        ctx.set_scene(0, p)
+        ctx.step(10)
+        _assert_state_equal(ctx.env(0), orc, "device %d" % ctx.device)
+    for ctx in ctxs:
+        ctx.close()
