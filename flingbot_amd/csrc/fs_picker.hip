@@ -177,6 +177,7 @@ struct Plan {  // host-side trajectory of one episode for one movep call
     std::vector<FsPickerCmd> cmds;  // one per SIMULATION step
     int iterations = 0;             // movep loop iterations (>= cmds.size(): iterations on the target take no step)
     bool limit_hit = false;
+    bool capped = false;            // stopped because max_cmds simulation steps are planned: resume at `iterations`
 };
 
 inline double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
@@ -185,13 +186,15 @@ inline double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v
 // f32_targets: the caller's targets are a float32 numpy array in the reference (stretch_cloth builds them from the
 // float32 picker positions, simEnv.py:146-156,180-182), so movep's own arithmetic -- delta, its norm, the step toward the
 // target -- happens in float32 there; PickerPickPlace.step below always works in float64.
+// start_step / max_cmds: resume the loop at iteration `start_step` (movep is stateless apart from its loop index: every
+// iteration starts from the pickers' current positions) and stop once max_cmds simulation steps are planned (< 0: no cap).
 Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *grasp, double speed, int limit,
-                int min_steps, double eps, bool f32_targets) {
+                int min_steps, double eps, bool f32_targets, int start_step = 0, int max_cmds = -1) {
     Plan plan;
     const int S = shapes.count;
     float cur[FS_MAX_SHAPES][3];
     for (int k = 0; k < S; ++k) { cur[k][0] = shapes.pos[k].x; cur[k][1] = shapes.pos[k].y; cur[k][2] = shapes.pos[k].z; }
-    for (int step = 0; step < limit; ++step) {
+    for (int step = start_step; step < limit; ++step) {
         double end[FS_MAX_SHAPES][3];
         bool all_close = true;
         for (int k = 0; k < S; ++k) {
@@ -225,6 +228,11 @@ Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *gra
             if (ns > num_step) num_step = ns;
         }
         if (num_step < 0.1) continue;  // already on the targets: the reference returns without stepping the simulation
+        if (max_cmds >= 0 && (int)plan.cmds.size() >= max_cmds) {  // this call's budget of simulation steps is planned
+            plan.iterations = step;
+            plan.capped = true;
+            return plan;
+        }
         double delta[FS_MAX_SHAPES][3], sq = 0.0;
         for (int k = 0; k < S; ++k)
             for (int c = 0; c < 3; ++c) {
@@ -347,6 +355,212 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
         }
     }
     if (any_limit) { fs_set_error("fs_movep: step limit reached (MoveJointsException)"); return FS_ERR_LIMIT; }
+    return FS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fs_advance: one CHUNK of simulation for episodes that are in DIFFERENT phases of their primitives -- some inside a movep
+// (simEnv.py:739-769), some inside wait_until_stable (flex_utils.py:430-441) -- so that all of them share every launch
+// sequence.  The batched primitives of flingbot_amd/primitives.py advance the episodes phase by phase in lock step and the
+// whole batch waits for the slowest episode of every phase (measured: 15.6 of 32 episodes active per launch sequence in the
+// evaluation loop); the scheduler of flingbot_amd/schedule.py instead gives every episode its own state machine and calls
+// this function with whatever each episode needs next, at most `cap` simulation steps per call.  Both loops are resumable
+// without changing a bit: a movep iteration only reads the pickers' current positions and its own loop index (start[]),
+// wait_until_stable only counts its steps.
+// One device id list per launch sequence: [waiters | movers still moving at this step]; a check kernel retires a waiter
+// (id -> -1) when it is stable or its step budget is used up, the picker kernel moves the movers' pickers.
+__global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int *ids, double tol, const int *budget, int *steps,
+                                                       int *stable) {
+    __shared__ float red[256];
+    const int slot = blockIdx.x;
+    const int e = ids[slot];
+    if (e < 0) return;
+    if (steps[slot] >= budget[slot]) {  // this call's (or the loop's) steps are used up: not stable, no test (flex_utils.py:441)
+        if (threadIdx.x == 0) ids[slot] = -1;
+        return;
+    }
+    const FsEnvDev &E = envs[e];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < E.n; i += 256) {
+        const FsVec4 v = E.vel[i];
+        const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z);
+        const float q = (a != a || b != b || c != c) ? __int_as_float(0x7fc00000) : fmaxf(a, fmaxf(b, c));
+        m = (m != m || q != q) ? __int_as_float(0x7fc00000) : fmaxf(m, q);  // numpy's max propagates NaN
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float x = red[threadIdx.x], y = red[threadIdx.x + s];
+            red[threadIdx.x] = (x != x || y != y) ? __int_as_float(0x7fc00000) : fmaxf(x, y);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if ((double)red[0] < tol) { stable[slot] = 1; ids[slot] = -1; }
+        else steps[slot] += 1;  // the step that follows
+    }
+}
+
+extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
+                          const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start,
+                          double eps, double tolerance, int cap_min, int cap, int *progress_out, int *status_out,
+                          int *steps_out) {
+    if (!ctx || n <= 0 || n > ctx->n_envs || !envs || !kind || !limit || !start || !progress_out || !status_out || !steps_out ||
+        cap <= 0 || cap_min <= 0 || cap_min > cap) {
+        fs_set_error("fs_advance: bad arguments");
+        return FS_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int> movers, waiters;
+    int S = -1;
+    for (int a = 0; a < n; ++a) {
+        FsEnv *e = picker_env(ctx, envs[a]);
+        if (!e) return FS_ERR_ARG;
+        for (int b = 0; b < a; ++b)
+            if (envs[b] == envs[a]) { fs_set_error("fs_advance: an episode is listed twice"); return FS_ERR_ARG; }
+        if (kind[a] == 0) {
+            if (!targets || !grasp || !speed || !min_steps || !f32) { fs_set_error("fs_advance: movep arguments missing"); return FS_ERR_ARG; }
+            if (!e->picker_ready) { fs_set_error("fs_advance: call fs_picker_reset first"); return FS_ERR_STATE; }
+            if (S < 0) S = e->shapes.count;
+            if (e->shapes.count != S || S <= 0) { fs_set_error("fs_advance: episodes need the same (non-zero) picker count"); return FS_ERR_STATE; }
+            if (!movers.empty() && picker_grasp_threshold(*e) != picker_grasp_threshold(ctx->envs[envs[movers[0]]])) {
+                fs_set_error("fs_advance: episodes moved together need the same grasp threshold");
+                return FS_ERR_STATE;
+            }
+            movers.push_back(a);
+        } else if (kind[a] == 1) {
+            waiters.push_back(a);
+        } else {
+            fs_set_error("fs_advance: kind must be 0 (movep) or 1 (wait_until_stable)");
+            return FS_ERR_ARG;
+        }
+    }
+    const int nm = (int)movers.size(), nw = (int)waiters.size();
+    // movers: plan this call's part of each trajectory.  The chunk ends when the FIRST mover finishes its movep (so that its
+    // program can issue the next request without idling through the others' steps), but not before cap_min steps (the host
+    // round trip per call) and not after cap.
+    std::vector<Plan> plans(nm);
+    size_t n_seq = 0, shortest = (size_t)cap;
+    for (int q = 0; q < nm; ++q) {
+        const int a = movers[q];
+        plans[q] = plan_movep(ctx->envs[envs[a]].shapes, targets + (size_t)a * S * 3, grasp + (size_t)a * S, speed[a], limit[a],
+                              min_steps[a], eps, f32[a] != 0, start[a], cap);
+        if (plans[q].cmds.size() < shortest) shortest = plans[q].cmds.size();
+    }
+    const int chunk = nm == 0 ? cap : (int)(shortest < (size_t)cap_min ? (size_t)cap_min : shortest);
+    for (int q = 0; q < nm; ++q) {
+        const int a = movers[q];
+        if ((int)plans[q].cmds.size() > chunk)  // same trajectory, cut at the chunk's end
+            plans[q] = plan_movep(ctx->envs[envs[a]].shapes, targets + (size_t)a * S * 3, grasp + (size_t)a * S, speed[a], limit[a],
+                                  min_steps[a], eps, f32[a] != 0, start[a], chunk);
+        progress_out[a] = plans[q].iterations;
+        status_out[a] = plans[q].capped ? 0 : (plans[q].limit_hit ? 2 : 1);
+        steps_out[a] = (int)plans[q].cmds.size();
+        if (plans[q].cmds.size() > n_seq) n_seq = plans[q].cmds.size();
+    }
+    const size_t mover_seq = n_seq;  // launch sequences that still have a mover
+    std::vector<int> w_budget(nw, 0);
+    for (int q = 0; q < nw; ++q) {
+        const int a = waiters[q];
+        const int left = limit[a] - start[a];
+        w_budget[q] = left < 0 ? 0 : (left < chunk ? left : chunk);
+        if ((size_t)w_budget[q] > n_seq) n_seq = (size_t)w_budget[q];
+        if (w_budget[q] == 0) {  // budget of the whole loop already used: wait_until_stable returns False
+            progress_out[a] = start[a]; status_out[a] = 2; steps_out[a] = 0;
+        }
+    }
+    if (n_seq == 0) return FS_OK;
+    // device tables
+    const int width = nm > 0 ? nm : 1;
+    std::vector<int> h_tab(n_seq * width, -1), h_cnt(n_seq, 0);
+    std::vector<FsPickerCmd> h_cmds(n_seq * width);
+    for (size_t s = 0; s < n_seq; ++s)
+        for (int q = 0; q < nm; ++q)
+            if (s < plans[q].cmds.size()) {
+                const int slot = h_cnt[s]++;
+                h_tab[s * width + slot] = envs[movers[q]];
+                h_cmds[s * width + slot] = plans[q].cmds[s];
+            }
+    std::vector<int> h_w(4 * (nw > 0 ? nw : 1), 0);  // ids | budget | steps | stable
+    for (int q = 0; q < nw; ++q) { h_w[q] = envs[waiters[q]]; h_w[nw + q] = w_budget[q]; }
+    std::vector<int *> h_picked(ctx->n_envs, nullptr);
+    std::vector<float *> h_saved(ctx->n_envs, nullptr);
+    for (int i = 0; i < ctx->n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
+    struct DevBufs {
+        int *tab = nullptr, *wait = nullptr, *all = nullptr;
+        FsPickerCmd *cmds = nullptr;
+        int **picked = nullptr;
+        float **saved = nullptr;
+        ~DevBufs() { (void)hipFree(tab); (void)hipFree(wait); (void)hipFree(all); (void)hipFree(cmds); (void)hipFree(picked); (void)hipFree(saved); }
+    } bufs;
+    HIP_TRY(hipMalloc((void **)&bufs.tab, sizeof(int) * h_tab.size()));
+    HIP_TRY(hipMalloc((void **)&bufs.cmds, sizeof(FsPickerCmd) * h_cmds.size()));
+    HIP_TRY(hipMalloc((void **)&bufs.wait, sizeof(int) * h_w.size()));
+    HIP_TRY(hipMalloc((void **)&bufs.all, sizeof(int) * (size_t)(nw + width)));
+    HIP_TRY(hipMalloc((void **)&bufs.picked, sizeof(int *) * ctx->n_envs));
+    HIP_TRY(hipMalloc((void **)&bufs.saved, sizeof(float *) * ctx->n_envs));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(bufs.tab, h_tab.data(), sizeof(int) * h_tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bufs.cmds, h_cmds.data(), sizeof(FsPickerCmd) * h_cmds.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bufs.wait, h_w.data(), sizeof(int) * h_w.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bufs.picked, h_picked.data(), sizeof(int *) * ctx->n_envs, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bufs.saved, h_saved.data(), sizeof(float *) * ctx->n_envs, hipMemcpyHostToDevice));
+    if (nw > 0) HIP_TRY(hipMemcpy(bufs.all, h_w.data(), sizeof(int) * nw, hipMemcpyHostToDevice));  // the waiters lead the list
+    int *d_w_budget = bufs.wait + nw, *d_w_steps = bufs.wait + 2 * nw, *d_w_stable = bufs.wait + 3 * nw;
+    int rc = FS_OK;
+    for (size_t s = 0; s < n_seq && rc == FS_OK; ++s) {
+        const int cnt = h_cnt[s];
+        std::vector<int> ids;
+        for (int q = 0; q < nw; ++q) ids.push_back(envs[waiters[q]]);
+        for (int k = 0; k < cnt; ++k) ids.push_back(h_tab[s * width + k]);
+        if (cnt > 0) {
+            HIP_TRY(hipMemcpyAsync(bufs.all + nw, bufs.tab + s * width, sizeof(int) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
+            const double thr = picker_grasp_threshold(ctx->envs[h_tab[s * width]]);
+            hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes,
+                               bufs.tab + s * width, bufs.cmds + s * width, bufs.picked, bufs.saved, thr);
+        }
+        if (nw > 0)
+            hipLaunchKernelGGL(fs_k_wait_check, dim3(nw), dim3(256), 0, ctx->stream, ctx->d_envs, bufs.all, tolerance,
+                               d_w_budget, d_w_steps, d_w_stable);
+        rc = fs_step_ids(ctx, ids, 1, bufs.all);
+        if (rc == FS_OK && nw > 0 && s >= mover_seq && (s & 15) == 15 && s + 1 < n_seq) {  // only waiters left: all retired?
+            std::vector<int> live(nw);
+            hipError_t pe = hipMemcpyAsync(live.data(), bufs.all, sizeof(int) * nw, hipMemcpyDeviceToHost, ctx->stream);
+            if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);
+            if (!fs_hip_ok(pe, "fs_advance poll")) { rc = FS_ERR_HIP; break; }
+            bool any = false;
+            for (int v : live) any = any || v >= 0;
+            if (!any) break;
+        }
+    }
+    std::vector<int> w_out(2 * (nw > 0 ? nw : 1), 0);
+    hipError_t err = hipSuccess;
+    if (rc == FS_OK && nw > 0)
+        err = hipMemcpyAsync(w_out.data(), d_w_steps, sizeof(int) * 2 * nw, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (rc != FS_OK) return rc;
+    HIP_TRY(err);
+    for (int q = 0; q < nw; ++q) {
+        const int a = waiters[q];
+        if (w_budget[q] == 0) continue;
+        const int taken = w_out[q], stable = w_out[nw + q];
+        progress_out[a] = start[a] + taken;
+        steps_out[a] = taken;
+        status_out[a] = stable ? 1 : (progress_out[a] >= limit[a] ? 2 : 0);
+    }
+    // host mirrors of the shape states follow the planned trajectories
+    for (int q = 0; q < nm; ++q) {
+        FsEnv &e = ctx->envs[envs[movers[q]]];
+        const auto &cm = plans[q].cmds;
+        if (cm.empty()) continue;
+        for (int k = 0; k < S; ++k) {
+            const float r = e.shapes.pos[k].w;
+            const float *pv = cm.size() >= 2 ? cm[cm.size() - 2].new_pos[k] : &e.shapes.pos[k].x;
+            e.shapes.prev[k] = FsVec4{pv[0], pv[1], pv[2], r};
+            e.shapes.pos[k] = FsVec4{cm.back().new_pos[k][0], cm.back().new_pos[k][1], cm.back().new_pos[k][2], r};
+        }
+    }
     return FS_OK;
 }
 

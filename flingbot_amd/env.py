@@ -27,8 +27,12 @@ class BatchedFlingEnv:
     def __init__(self, sim, action_primitives=("fling",), obs_dim=64, image_dim=400, num_rotations=12,
                  scale_factors=(1.0, 1.25, 1.5, 1.75, 2.0, 2.25, 2.5, 2.75), pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5,
                  reach_distance_limit=1.2, conservative_grasp_radius=1, episode_length=10, grasp_height=0.02,
-                 fling_speed=6e-3, stretchdrag_dist=0.3, device="cuda:0", render_dim=720, use_adaptive_scaling=True):
+                 fling_speed=6e-3, stretchdrag_dist=0.3, device="cuda:0", render_dim=720, use_adaptive_scaling=True,
+                 scheduled=True):
         self.sim = sim
+        # scheduled: every episode runs its action + postaction as its own program on shared launch sequences
+        # (flingbot_amd/schedule.py); False: the lock-step phases of FlingPrimitives.  Identical results.
+        self.scheduled = bool(scheduled)
         self.actions = list(action_primitives)
         self.obs_dim, self.image_dim = int(obs_dim), int(image_dim)
         self.render_dim = int(render_dim)  # pyflex renders 720 x 720 (get_image reshapes to it, flex_utils.py:421)
@@ -142,6 +146,11 @@ class BatchedFlingEnv:
         run = [int(e) for e in run]
         self.prim.preaction(run)
         prev = np.array(self.sim.coverage())
+        if getattr(self, "scheduled", False):
+            acts = {e: (chosen[e][0], chosen[e][1]["p1"], chosen[e][1]["p2"], chosen[e][1]["p1_grasp_cloth"],
+                        chosen[e][1]["p2_grasp_cloth"]) for e in run if e in chosen}
+            self.prim.act_scheduled(acts, run)
+            return self._finish_step(run, chosen, prev)
         for action in self.actions:  # one batched primitive call per action type
             es = [e for e in run if e in chosen and chosen[e][0] == action]
             if not es:
@@ -162,6 +171,9 @@ class BatchedFlingEnv:
                 # [p1_grasp, p2_grasp] set for postaction's reset_end_effectors / wait_until_stable
                 self.prim.grasp_states[e] = list(sub.grasp_states[e])
         self.prim.postaction(run)
+        return self._finish_step(run, chosen, prev)
+
+    def _finish_step(self, run, chosen, prev):
         curr = np.array(self.sim.coverage())
         rewards = {}
         for e in run:

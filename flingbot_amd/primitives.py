@@ -190,11 +190,32 @@ class FlingPrimitives:
         self.reset_end_effectors(envs)
         _, steps = self.sim.wait_until_stable(envs, max_steps=max_steps, tolerance=tolerance)
         self.sim_steps += int(np.sum(steps))
-        deltas_max = self.sim.max_displacement(envs)
+        return self.postaction_check(envs)
+
+    def postaction_check(self, envs):
+        """simEnv.py:470-475: if the action didn't really move the cloth then end early."""
+        envs = [int(e) for e in envs]
+        deltas_max = self.sim.max_displacement(envs) if envs else []
         for e, d in zip(envs, deltas_max):
-            if d < 5e-2:  # if didn't really move cloth then end early
+            if d < 5e-2:
                 self.terminate[e] = True
         return [self.terminate[e] for e in envs]
+
+    def act_scheduled(self, actions, envs=None, settle=True, cap_min=8, cap=64):
+        """The action handlers AND postaction of many episodes, each running the reference's straight-line code as its own
+        program (flingbot_amd/schedule.py) instead of the lock-step phases above: actions = {episode: (primitive, p1, p2,
+        p1_grasp_cloth, p2_grasp_cloth)}; episodes of `envs` (default: all) without an entry only settle.  Same
+        per-episode trajectories, bit for bit; returns ({episode: handler result}, terminate flags of envs)."""
+        from . import schedule as sch
+
+        envs = [int(e) for e in (self.envs if envs is None else envs)]
+        progs = {}
+        for e in envs:
+            ep = sch.Episode(self, e)
+            body = sch.PROGRAMS[actions[e][0]](ep, *actions[e][1:]) if e in actions else None
+            progs[e] = sch.action_then_settle(ep, body) if settle else body
+        out = sch.run_programs(self, {e: g for e, g in progs.items() if g is not None}, cap_min=cap_min, cap=cap)
+        return out, (self.postaction_check(envs) if settle else [self.terminate[e] for e in envs])
 
     # ---- simEnv.py:283-318
     def pick_and_fling(self, p1, p2, p1_grasp_cloth, p2_grasp_cloth):

@@ -150,6 +150,18 @@ int fs_picker_set_radius(fs_ctx *ctx, int env, double picker_radius);
 /* simulation steps, summed over the episodes, that the most recent fs_movep / fs_movep_batch* call executed (movep
    iterations that find the pickers on their targets do not step the simulation, flex_utils.py:231-233) */
 long long fs_last_movep_steps(const fs_ctx *ctx);
+/* One chunk (at most `cap` simulation steps) for episodes that are in different phases of their primitives, so that all of
+   them share every launch sequence; the chunk ends with the first movep that completes, but takes at least cap_min steps
+   (one host round trip per call) when somebody has that many left: kind[a] = 0: SimEnv.movep (simEnv.py:739-769) towards targets[a] ([S][3], float64; f32[a]
+   != 0: the caller's targets were a float32 array, see fs_movep_batch_f32) with grasp[a][S], speed[a], iteration limit[a],
+   min_steps[a] (< 0: None), resumed at loop iteration start[a]; kind[a] = 1: flex_utils.wait_until_stable
+   (flex_utils.py:430-441) with max_steps = limit[a], of which start[a] steps are already taken, tolerance `tolerance`.
+   Out: progress[a] = loop iteration / step count reached (pass it back as start[a]), status[a] = 0 continue with another
+   call, 1 finished (targets reached / stable), 2 finished at the limit (movep: MoveJointsException; wait: not stable),
+   steps[a] = simulation steps this call took for the episode.  Results are identical to the uninterrupted loops. */
+int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
+               const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start, double eps,
+               double tolerance, int cap_min, int cap, int *progress_out, int *status_out, int *steps_out);
 /* picked particle index per picker (-1 = none) */
 int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
 /* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all

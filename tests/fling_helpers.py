@@ -80,6 +80,39 @@ class OracleBatch:
         self.last_movep_steps = sum(self.tools[e].last_sim_steps for e in envs)
         return iters
 
+    def advance(self, envs, kind, targets, grasp, speed, limit, min_steps, f32, start, cap_min=8, cap=64, eps=1e-4,
+                tolerance=1e-2):
+        """FlingSim.advance (fs_advance) on the CPU oracles: every episode takes its next chunk of its own loop.  The chunk
+        length follows fs_advance's rule (the shortest mover's remaining steps, at least cap_min, at most cap) so that the
+        sequence of calls equals the device's; episodes are independent, so the rule cannot change any result."""
+        n = len(envs)
+        prog, status, steps = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        self.advance_calls = getattr(self, "advance_calls", 0) + 1
+        chunk = cap if not any(k == 0 for k in kind) else max(cap_min, 1)  # CPU stand-in: fixed short chunks (worst case for resumption)
+        for a, e in enumerate(envs):
+            if kind[a] == 0:
+                tg = np.asarray(targets[a], np.float32 if f32[a] else np.float64).reshape(-1, 3)
+                ms = None if min_steps[a] < 0 else int(min_steps[a])
+                prog[a], status[a] = self.tools[e].movep(tg, [bool(g) for g in np.asarray(grasp[a]).reshape(-1)], speed=speed[a],
+                                                         limit=int(limit[a]), min_steps=ms, eps=eps, start=int(start[a]),
+                                                         max_sim_steps=chunk)
+                steps[a] = self.tools[e].last_sim_steps
+            else:
+                done, st = 0, 0
+                while True:
+                    if start[a] + done >= limit[a]:
+                        st = 2
+                        break
+                    if done >= chunk:
+                        break
+                    if np.abs(self.sims[e].get_velocities()).max() < tolerance:
+                        st = 1
+                        break
+                    self.sims[e].step(1)
+                    done += 1
+                prog[a], status[a], steps[a] = start[a] + done, st, done
+        return prog, status, steps
+
     def get_shape_states(self, e):
         return self.sims[e].get_shape_states()
 
@@ -124,20 +157,29 @@ def load_primitives_golden():
     return np.load(os.path.join(GOLD, "primitives_golden.npz"))
 
 
-def run_primitives_golden(make_sim, get_positions, get_shapes):
-    """Runs the golden cases of the other manipulation primitives (drag / place / stretchdrag), batched per kind, on a
-    simulator made by make_sim(n) and checks final particle positions and picker states bit for bit."""
+def run_primitives_golden(make_sim, get_positions, get_shapes, scheduled=False):
+    """Runs the golden cases of the other manipulation primitives (drag / place / stretchdrag) on a simulator made by
+    make_sim(n) and checks final particle positions and picker states bit for bit.  scheduled=False: batched per kind
+    through the lock-step primitives; True: ALL cases of all kinds at once as per-episode programs (schedule.py)."""
     from flingbot_amd.primitives import FlingPrimitives
 
     g = load_primitives_golden()
     kinds = [str(k) for k in g["kind"]]
-    for kind in ("drag", "place", "stretchdrag"):
-        cases = [c for c, k in enumerate(kinds) if k == kind]
+    groups = [list(range(len(kinds)))] if scheduled else [[c for c, k in enumerate(kinds) if k == kind]
+                                                           for kind in ("drag", "place", "stretchdrag")]
+    for cases in groups:
+        kind = kinds[cases[0]]
         sim = make_sim(len(cases))
         prim = FlingPrimitives(sim, range(len(cases)), stretchdrag_dist=float(g["stretchdrag_dist"]))
-        fn = {"drag": prim.pick_and_drag, "place": prim.pick_and_place, "stretchdrag": prim.pick_stretch_drag}[kind]
-        out = fn(g["p1"][cases], g["p2"][cases], g["g1"][cases], g["g2"][cases])
+        if scheduled:
+            res, _ = prim.act_scheduled({k: (kinds[c], g["p1"][c], g["p2"][c], g["g1"][c], g["g2"][c])
+                                         for k, c in enumerate(cases)}, settle=False, cap_min=3, cap=7)
+            out = [res[k] for k in range(len(cases))]
+        else:
+            fn = {"drag": prim.pick_and_drag, "place": prim.pick_and_place, "stretchdrag": prim.pick_stretch_drag}[kind]
+            out = fn(g["p1"][cases], g["p2"][cases], g["g1"][cases], g["g2"][cases])
         for k, c in enumerate(cases):
+            kind = kinds[c]
             assert out[k]["skipped"] == (g["steps"][c] == 0), (kind, c)
             if kind == "stretchdrag" and not np.isnan(g["stretch_ret"][c]):
                 assert out[k]["dist"] == g["stretch_ret"][c], (kind, c)
@@ -256,7 +298,7 @@ def load_step_golden():
     return np.load(os.path.join(GOLD, "step_golden.npz"))
 
 
-def run_step_golden(make_sim, get_positions, get_shapes):
+def run_step_golden(make_sim, get_positions, get_shapes, scheduled=False):
     """SimEnv.step's bookkeeping (tests/golden/step_golden.npz, recorded from the reference's own SimEnv.step with the action
     selection scripted) through BatchedFlingEnv.step_actions on a simulator made by make_sim(n): every case is its own
     episode, all advanced together step by step; rewards, termination, timesteps, simulation-step counts, grasp flags,
@@ -271,6 +313,7 @@ def run_step_golden(make_sim, get_positions, get_shapes):
     env.actions = ["fling", "stretchdrag", "drag", "place"]
     env._prim_kwargs = dict(grasp_height=0.02, fling_speed=6e-3, stretchdrag_dist=0.3)
     env.episode_length = 0
+    env.scheduled = scheduled  # True: per-episode programs on shared launch sequences instead of the lock-step phases
     env.attach(range(n))
     lengths = {c: int(g[f"c{c}_episode_length"]) for c in range(n)}
     for c in range(n):

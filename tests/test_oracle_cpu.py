@@ -514,6 +514,28 @@ def test_fling_primitive_host_logic_reproduces_reference_golden():
     assert out[3]["skipped"]
 
 
+def test_scheduled_fling_programs_reproduce_reference_golden():
+    """The same golden through flingbot_amd/schedule.py: every case is its own program (the reference's straight-line code
+    as a coroutine), advanced in short resumable chunks next to the others -- including the no-op case -- and followed by
+    wait_until_stable inside the same scheduling run for the case the golden recorded it for."""
+    from fling_helpers import OracleBatch, load_fling_golden
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+    cases = [0, 1, 2, 3]
+    sim = OracleBatch(len(cases), g["scene_params"], g["init_pos"])
+    prim = FlingPrimitives(sim, range(len(cases)))
+    out, _ = prim.act_scheduled({k: ("fling", g["p1"][c], g["p2"][c], g["g1"][c], g["g2"][c]) for k, c in enumerate(cases)},
+                                settle=False, cap_min=5, cap=11)
+    assert sim.advance_calls > 60  # the trajectories really were cut into many chunks
+    for k, c in enumerate(cases):
+        assert out[k]["terminated"] == bool(g["terminate"][c])
+        if not np.isnan(g["stretch_ret"][c]):
+            assert out[k]["dist"] == g["stretch_ret"][c] and out[k]["fling_height"] == g["lift_ret"][c]
+        assert np.array_equal(sim.get_positions(k).view(np.uint32), g["pos_fling"][c].view(np.uint32)), c
+    assert out[3]["skipped"] and prim.sim_steps > 0  # (the device test compares the step count with the lock-step run's)
+
+
 def test_action_selection_restatement_matches_reference_golden():
     """oracle/action.py against tests/golden/action_golden.npz -- SimEnv.get_max_value_valid_action of the REFERENCE run
     on synthetic value maps and depth images (fling only / three primitives with tied values / stretchdrag / nothing
@@ -612,6 +634,16 @@ def test_drag_place_stretchdrag_host_logic_reproduces_reference_golden():
     g = load_primitives_golden()
     run_primitives_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"]),
                           lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
+
+
+def test_scheduled_drag_place_stretchdrag_programs_reproduce_reference_golden():
+    """All five cases of primitives_golden.npz -- three different primitives -- as per-episode programs in ONE scheduling
+    run (flingbot_amd/schedule.py), in chunks of 3..7 simulation steps."""
+    from fling_helpers import OracleBatch, load_primitives_golden, run_primitives_golden
+
+    g = load_primitives_golden()
+    run_primitives_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"]),
+                          lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k), scheduled=True)
 
 
 def test_task_generator_host_logic_reproduces_reference_golden():
@@ -722,3 +754,13 @@ def test_env_step_bookkeeping_reproduces_reference_golden():
     g = load_step_golden()
     run_step_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"], pickers=False),
                     lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
+
+
+def test_env_step_bookkeeping_scheduled_reproduces_reference_golden():
+    """The same golden with BatchedFlingEnv's default execution: action handler + postaction of every episode as one
+    program each, scheduled together (flingbot_amd/schedule.py)."""
+    from fling_helpers import OracleBatch, load_step_golden, run_step_golden
+
+    g = load_step_golden()
+    run_step_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"], pickers=False),
+                    lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k), scheduled=True)

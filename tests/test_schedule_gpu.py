@@ -1,0 +1,164 @@
+"""Per-episode programs on shared launch sequences (flingbot_amd/schedule.py + fs_advance) on the device: the goldens
+recorded from the REFERENCE's SimEnv methods (fling / drag / place / stretchdrag / SimEnv.step) bit for bit, and equality
+with the lock-step primitives on a batch of cloths of different sizes in different poses."""
+import numpy as np
+import pytest
+
+from fling_helpers import load_fling_golden, load_primitives_golden, load_step_golden, run_primitives_golden, run_step_golden
+from test_fling_gpu import _make
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("caps", [(8, 64), (1, 3), (40, 40)])
+def test_scheduled_pick_and_fling_matches_reference_golden(gpu_required, caps):
+    """Every golden case as its own program, followed -- inside the same scheduling run -- by postaction's
+    reset_end_effectors + wait_until_stable; chunk bounds from "one step at a time" to "longer than most moves"."""
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+    n = len(g["terminate"])
+    ctx = _make(g, n)
+    prim = FlingPrimitives(ctx, range(n))
+    out, _ = prim.act_scheduled({e: ("fling", g["p1"][e], g["p2"][e], g["g1"][e], g["g2"][e]) for e in range(n)},
+                                settle=False, cap_min=caps[0], cap=caps[1])
+    for e in range(n):
+        assert out[e]["terminated"] == bool(g["terminate"][e]), e
+        if np.isnan(g["stretch_ret"][e]):
+            assert out[e]["dist"] is None
+        else:
+            assert out[e]["dist"] == g["stretch_ret"][e] and out[e]["fling_height"] == g["lift_ret"][e], e
+        assert np.array_equal(ctx.get_positions(e).view(np.uint32), g["pos_fling"][e].view(np.uint32)), e
+    assert out[3]["skipped"]
+    # the lock-step primitives count the same simulation steps
+    ctx2 = _make(g, n)
+    prim2 = FlingPrimitives(ctx2, range(n))
+    prim2.pick_and_fling(g["p1"], g["p2"], g["g1"], g["g2"])
+    assert prim.sim_steps == prim2.sim_steps > 0
+    for e in range(n):
+        assert np.array_equal(ctx.get_shape_states(e).view(np.uint32), ctx2.get_shape_states(e).view(np.uint32)), e
+        assert ctx.picked(e).tolist() == ctx2.picked(e).tolist(), e
+
+
+def test_advance_waiters_match_wait_until_stable_golden(gpu_required):
+    """fs_advance's wait_until_stable leg alone, resumed across chunks of 7 steps: the golden's step counts, stability flags
+    and final states (episodes that settle after different numbers of steps, one that runs into max_steps)."""
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+    n = len(g["terminate"])
+    ctx = _make(g, n)
+    prim = FlingPrimitives(ctx, range(n))
+    prim.pick_and_fling(g["p1"], g["p2"], g["g1"], g["g2"])
+    for e in range(n):
+        lifted = ctx.get_positions(e).reshape(-1, 4).copy()
+        lifted[:, 1] += np.float32(0.25)
+        ctx.set_positions(e, lifted.ravel())
+        vel = np.zeros((lifted.shape[0], 3), np.float32)
+        vel[:, 1] = -0.5
+        ctx.set_velocities(e, vel.ravel())
+    start, total, done = np.zeros(n, np.int32), np.zeros(n, np.int32), {}
+    z, calls = np.zeros((n, 2, 3)), 0
+    live = list(range(n))
+    while live:
+        k = len(live)
+        prog, status, steps = ctx.advance(live, [1] * k, z[:k], np.zeros((k, 2), int), [0.0] * k, [200] * k, [-1] * k, [0] * k,
+                                          start[live], cap_min=7, cap=7, tolerance=2e-2)
+        calls += 1
+        for q, e in enumerate(list(live)):
+            start[e] = prog[q]
+            total[e] += steps[q]
+            if status[q] != 0:
+                done[e] = status[q] == 1
+                live.remove(e)
+    assert calls > 3
+    assert total.tolist() == g["steps_drop"].tolist() and [done[e] for e in range(n)] == g["stable_drop"].tolist()
+    for e in range(n):
+        assert np.array_equal(ctx.get_positions(e).view(np.uint32), g["pos_final"][e].view(np.uint32)), e
+        assert np.array_equal(ctx.get_shape_states(e).view(np.uint32), g["shapes_final"][e].view(np.uint32)), e
+    # a budget that is already used up: finished at the limit without a step or a test
+    prog, status, steps = ctx.advance([0], [1], z[:1], [[0, 0]], [0.0], [5], [-1], [0], [5], tolerance=2e-2)
+    assert (int(prog[0]), int(status[0]), int(steps[0])) == (5, 2, 0)
+
+
+def test_scheduled_drag_place_stretchdrag_match_reference_golden(gpu_required):
+    """All cases of primitives_golden.npz -- three different primitives -- in ONE scheduling run."""
+    g = load_primitives_golden()
+    run_primitives_golden(lambda n: _make(g, n), lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k),
+                          scheduled=True)
+
+
+def test_scheduled_step_bookkeeping_matches_reference_golden(gpu_required):
+    """SimEnv.step's golden through BatchedFlingEnv's default (scheduled) execution on the device."""
+    from flingbot_amd import sim as fsim
+
+    g = load_step_golden()
+
+    def make(n):
+        ctx = fsim.FlingSim(n_envs=n, solver=0)
+        for e in range(n):
+            env = ctx.env(e)
+            env.set_scene(g["scene_params"])
+            env.step(1)
+            env.set_positions(g["init_pos"].ravel())
+            env.set_velocities(np.zeros(3 * g["init_pos"].shape[0], np.float32))
+        return ctx
+
+    run_step_golden(make, lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k), scheduled=True)
+
+
+def test_scheduled_equals_lockstep_on_mixed_cloths(gpu_required):
+    """Six generated tasks with cloth sides 40..70 (different particle counts, so different kernels' launch lists mix),
+    each with its own fling; scheduled and lock-step execution of action + postaction give bit-identical particle
+    states, picker states, terminate flags and simulation-step counts, and the scheduler needs fewer launch sequences."""
+    import random
+
+    from flingbot_amd import sim as fsim, tasks as ftasks
+    from flingbot_amd.primitives import FlingPrimitives
+
+    def build():
+        random.seed(5)
+        np.random.seed(5)
+        n = 6
+        gen = fsim.FlingSim(n_envs=n, solver=0)
+        tasks = ftasks.generate_tasks(gen, [ftasks.draw_task_parameters(min_cloth_size=40, strict_min_edge_length=40,
+                                                                        max_cloth_size=70) for _ in range(n)])
+        gen.close()
+        ctx = fsim.FlingSim(n_envs=n, solver=0)
+        envs = ftasks.load_tasks(ctx, tasks)
+        prim = FlingPrimitives(ctx, envs)
+        prim.setup_pickers()
+        return ctx, prim, n
+
+    def grasp_points(ctx, e, k):
+        pos = ctx.get_positions(e).reshape(-1, 4)[:, :3]
+        order = np.argsort(pos[:, 0])
+        a, b = pos[order[3 + k]], pos[order[-4 - k]]  # two particles near the opposite ends of the heap
+        return np.array([a[0], 0.0, a[2]], np.float64), np.array([b[0], 0.0, b[2]], np.float64)
+
+    results = []
+    for scheduled in (False, True):
+        ctx, prim, n = build()
+        pts = [grasp_points(ctx, e, e) for e in range(n)]
+        g1 = [True] * n
+        g2 = [True, True, False, True, True, True]  # one one-handed fling
+        prim.preaction()
+        if scheduled:
+            prim.act_scheduled({e: ("fling", pts[e][0], pts[e][1], g1[e], g2[e]) for e in range(n)})
+        else:
+            prim.pick_and_fling([p[0] for p in pts], [p[1] for p in pts], g1, g2)
+            prim.postaction()
+        results.append(dict(pos=[ctx.get_positions(e).copy() for e in range(n)],
+                            vel=[ctx.get_velocities(e).copy() for e in range(n)],
+                            shapes=[np.array(ctx.get_shape_states(e)).copy() for e in range(n)],
+                            terminate=dict(prim.terminate), steps=prim.sim_steps, cov=np.array(ctx.coverage())))
+        ctx.close()
+    a, b = results
+    assert a["steps"] == b["steps"] > 1000
+    assert a["terminate"] == b["terminate"]
+    assert np.array_equal(a["cov"], b["cov"])
+    for e in range(len(a["pos"])):
+        assert np.array_equal(a["pos"][e].view(np.uint32), b["pos"][e].view(np.uint32)), e
+        assert np.array_equal(a["vel"][e].view(np.uint32), b["vel"][e].view(np.uint32)), e
+        assert np.array_equal(a["shapes"][e].view(np.uint32), b["shapes"][e].view(np.uint32)), e
+    assert len({p.size for p in a["pos"]}) > 1  # the cloths really differ in size
