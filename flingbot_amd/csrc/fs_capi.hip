@@ -100,14 +100,19 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
 extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
 extern "C" int fs_n_envs(const fs_ctx *ctx) { return ctx ? ctx->n_envs : FS_ERR_ARG; }
 extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
-    if (!ctx || solver < 0 || solver > 6) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    if (!ctx || solver < 0 || solver > 8) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    ctx->force_merged_boundary = (solver == FS_SOLVER_STREAM_MERGED);
     ctx->force_coded_stream = (solver == FS_SOLVER_STREAM_CODED);
+    ctx->force_split_boundary = (solver == FS_SOLVER_STREAM_SPLIT);
     ctx->force_generic_fused = (solver == FS_SOLVER_FUSED_GENERIC);
     ctx->force_coded_fused = (solver == FS_SOLVER_FUSED_CODED);
     ctx->force_ell_stream = (solver == FS_SOLVER_STREAM_ELL);
     ctx->solver = (solver == FS_SOLVER_FUSED_GENERIC || solver == FS_SOLVER_FUSED_CODED)
                       ? FS_SOLVER_FUSED
-                      : ((solver == FS_SOLVER_STREAM_ELL || solver == FS_SOLVER_STREAM_CODED) ? FS_SOLVER_STREAM : solver);
+                      : ((solver == FS_SOLVER_STREAM_ELL || solver == FS_SOLVER_STREAM_CODED || solver == FS_SOLVER_STREAM_SPLIT ||
+                         solver == FS_SOLVER_STREAM_MERGED)
+                             ? FS_SOLVER_STREAM
+                             : solver);
     return FS_OK;
 }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }

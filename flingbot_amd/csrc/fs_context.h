@@ -74,6 +74,9 @@ struct fs_ctx {
     bool force_generic_fused = false;  // FS_SOLVER_FUSED_GENERIC: fused kernel with the streamed ELL adjacency
     bool force_coded_stream = false;   // FS_SOLVER_STREAM_CODED: never the grid-L form (dictionary-coded / latency / grid forms by size)
     bool force_coded_fused = false;    // FS_SOLVER_FUSED_CODED: never the grid-64 form (dictionary-coded adjacency kernel)
+    bool force_split_boundary = false; // FS_SOLVER_STREAM_SPLIT: separate finalize / predict / scan / scatter launches (the form for cloths > 16384 particles)
+    bool force_merged_boundary = false; // FS_SOLVER_STREAM_MERGED: fs_k_boundary at every launch size (AUTO / STREAM: from 16 episodes on)
+    bool bound_attr_set = false;       // fs_k_boundary's dynamic LDS attribute applied on this context's device
     bool fused_attr_set = false;       // hipFuncAttributeMaxDynamicSharedMemorySize applied on this context's device
     int last_form = 0;                 // FS_FORM_* of the most recent solver launch (fs_last_kernel_form)
     long long last_movep_steps = 0;    // simulation steps of the most recent fs_movep* call, all episodes (fs_last_movep_steps)

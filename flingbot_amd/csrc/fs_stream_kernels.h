@@ -111,6 +111,135 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
     fs_st4o(E.xb, (unsigned)slot, FsVec4{xp.x, xp.y, xp.z, __int_as_float(i)});
 }
 
+// ---- the substep boundary in ONE launch (cloths up to FS_BOUND_MAX particles; round 2): finalize of the substep that just
+// ended (FIN), predict of the one that starts (PRE), the bucket histogram, its exclusive scan and the bucket-ordered copy of
+// the predicted positions -- what fs_k_finalize, fs_k_predict, fs_k_grid_scan and fs_k_grid_scatter do in four dependent
+// launches.  One 1024-thread workgroup per episode: the histogram lives in LDS (64 KiB), an LDS atomicAdd returns the
+// particle's rank inside its bucket, so after the scan every particle knows its slot without a second pass of atomics; the
+// thread keeps its (up to 16) predicted positions in registers from the first pass to the last.  The arithmetic is that of
+// the four kernels, statement for statement; the order of the particles INSIDE a bucket differs (it was the order of the
+// global atomics before), which the search cannot see: its lists are sorted sets.  A frame is 129 dependent launches instead
+// of 140; measured in DESIGN.md 4.2.
+#define FS_BOUND_THREADS 1024
+#define FS_BOUND_PPT 16
+#define FS_BOUND_MAX (FS_BOUND_THREADS * FS_BOUND_PPT)
+#define FS_BOUND_LDS_BYTES (FS_GRID_BUCKETS * 4 + 64)
+template <bool FIN, bool PRE>
+__global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev *envs, const int *ids, int flip) {
+    static_assert(FS_GRID_BUCKETS == FS_BOUND_THREADS * 16 && FS_BOUND_MAX <= (1 << 14), "16 buckets per thread, 14-bit ranks");
+    extern __shared__ __attribute__((aligned(16))) int bound_smem[];
+    int *hist = bound_smem, *wave_tot = bound_smem + FS_GRID_BUCKETS;
+    const int e = ids[blockIdx.x];
+    if (e < 0) return;  // retired slot
+    const FsEnvDev &E = envs[e];
+    const int n = E.n, t = threadIdx.x;
+    const FsParams &p = E.p;
+    const float h = p.dt / (float)p.numSubsteps;
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hist[t + k * FS_BOUND_THREADS] = 0;
+        __syncthreads();
+    }
+    FsVec4 xpk[FS_BOUND_PPT];
+    int code[FS_BOUND_PPT];  // bucket | rank inside the bucket << 14
+    const float inv_cell = 1.0f / (p.radius + p.particleCollisionMargin);
+#pragma unroll
+    for (int k = 0; k < FS_BOUND_PPT; ++k) {
+        const unsigned i = (unsigned)(t + k * FS_BOUND_THREADS);
+        code[k] = -1;
+        if ((int)i < n) {
+            FsVec4 x, v;
+            if (FIN) {  // fs_k_finalize: velocity from displacement, maxAcceleration / maxSpeed clamps, sleeping
+                const float inv_h = 1.0f / h;
+                const FsVec4 x0 = fs_ld4o(E.x0, i);
+                x = x0;  // kinematic or asleep: the position stays (pos == x0 since the predict that copied it)
+                v = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (x0.w > 0.0f) {
+                    const FsVec4 xp = fs_ld4o(flip ? E.xb : E.xa, i);
+                    const FsVec4 v0 = fs_ld4o(E.v0, i);
+                    float vx = (xp.x - x0.x) * inv_h, vy = (xp.y - x0.y) * inv_h, vz = (xp.z - x0.z) * inv_h;
+                    float ax = vx - v0.x, ay = vy - v0.y, az = vz - v0.z;
+                    float dv2 = ax * ax + ay * ay + az * az;
+                    const float maxdv = p.maxAcceleration * h;
+                    if (dv2 > maxdv * maxdv) {
+                        float sc = maxdv / sqrtf(dv2);
+                        vx = v0.x + ax * sc; vy = v0.y + ay * sc; vz = v0.z + az * sc;
+                    }
+                    float v2 = vx * vx + vy * vy + vz * vz;
+                    if (p.maxSpeed < 3.402823466e+38f && v2 > p.maxSpeed * p.maxSpeed) {
+                        float sc = p.maxSpeed / sqrtf(v2);
+                        vx = vx * sc; vy = vy * sc; vz = vz * sc;
+                        v2 = vx * vx + vy * vy + vz * vz;
+                    }
+                    const float thr2 = p.sleepThreshold * p.sleepThreshold;
+                    if (!(v2 < thr2)) {
+                        v = FsVec4{vx, vy, vz, 0.0f};
+                        x = FsVec4{xp.x, xp.y, xp.z, x0.w};
+                        fs_st4o(E.pos, i, x);
+                    }
+                }
+                fs_st4o(E.vel, i, v);
+            } else {
+                x = fs_ld4o(E.pos, i);
+                v = fs_ld4o(E.vel, i);
+            }
+            if (PRE) {  // fs_k_predict
+                fs_st4o(E.x0, i, x);
+                fs_st4o(E.v0, i, v);
+                FsVec4 xp = x;
+                if (x.w > 0.0f) {
+                    float vx = v.x + h * (p.gravity[0] - p.damping * v.x);
+                    float vy = v.y + h * (p.gravity[1] - p.damping * v.y);
+                    float vz = v.z + h * (p.gravity[2] - p.damping * v.z);
+                    xp.x = x.x + h * vx;
+                    xp.y = x.y + h * vy;
+                    xp.z = x.z + h * vz;
+                }
+                fs_st4o(E.xa, i, xp);
+                const int b = fs_stream_bucket((int)floorf(xp.x * inv_cell), (int)floorf(xp.y * inv_cell), (int)floorf(xp.z * inv_cell));
+                const int rank = atomicAdd(&hist[b], 1);
+                xpk[k] = xp;
+                code[k] = b | (rank << 14);
+            }
+        }
+    }
+    if (!PRE) return;
+    __syncthreads();
+    // exclusive scan of the histogram: 16 consecutive buckets per thread, lanes, waves (fs_k_grid_scan)
+    int loc[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        loc[k] = hist[t * 16 + k];
+        sum += loc[k];
+    }
+    const int lane = t & 63, wave = t >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        hist[t * 16 + k] = run;  // first slot of the bucket
+        run += loc[k];
+        E.cell_fill[t * 16 + k] = run;  // what the search reads: the END of bucket b
+    }
+    __syncthreads();
+    // bucket-ordered copy of the predicted positions with the particle id in w (fs_k_grid_scatter)
+#pragma unroll
+    for (int k = 0; k < FS_BOUND_PPT; ++k) {
+        if (code[k] >= 0) {
+            const int slot = hist[code[k] & (FS_GRID_BUCKETS - 1)] + (code[k] >> 14);
+            fs_st4o(E.xb, (unsigned)slot, FsVec4{xpk[k].x, xpk[k].y, xpk[k].z, __int_as_float(t + k * FS_BOUND_THREADS)});
+        }
+    }
+}
+
 // ---- particle-contact candidates: ascending neighbour id, the (up to) 96 smallest ids.
 // Same two-phase scheme as the fused kernel (fs_fused_kernel.h), on global arrays: threads take the particles in BUCKET
 // order (thread <-> slot of the sorted copy in xb); phase A scans the 9 runs (3 adjacent buckets each) four candidates per

@@ -13,6 +13,7 @@ from . import build as _build
 
 FS_SOLVER_AUTO, FS_SOLVER_STREAM, FS_SOLVER_FUSED = 0, 1, 2
 FS_SOLVER_FUSED_GENERIC, FS_SOLVER_STREAM_ELL, FS_SOLVER_FUSED_CODED, FS_SOLVER_STREAM_CODED = 3, 4, 5, 6  # test / comparison variants (include/flingsim.h)
+FS_SOLVER_STREAM_SPLIT, FS_SOLVER_STREAM_MERGED = 7, 8
 # fs_last_kernel_form (white box): which kernel form the last solver launch ran
 (FS_FORM_FUSED_12, FS_FORM_FUSED_16, FS_FORM_FUSED_GENERIC, FS_FORM_STREAM_EAGER, FS_FORM_STREAM_CODED, FS_FORM_STREAM_ELL,
  FS_FORM_STREAM_GRID, FS_FORM_FUSED_GRID64, FS_FORM_STREAM_GRIDL) = range(1, 10)

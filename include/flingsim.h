@@ -38,6 +38,10 @@ typedef struct fs_ctx fs_ctx;
 #define FS_SOLVER_STREAM_ELL 4    /* STREAM, but with the uncompressed (index, length, stiffness) adjacency arrays */
 #define FS_SOLVER_FUSED_CODED 5   /* FUSED, but never the grid-64 form: the dictionary-coded adjacency kernel */
 #define FS_SOLVER_STREAM_CODED 6  /* STREAM, but never the grid-L form: coded / latency / grid forms chosen by launch size */
+#define FS_SOLVER_STREAM_SPLIT 7  /* STREAM, but the substep boundary as separate finalize / predict / scan / scatter launches
+                                     (the form cloths above 16384 particles and launches of fewer than 16 episodes take)
+                                     instead of fs_k_boundary */
+#define FS_SOLVER_STREAM_MERGED 8 /* STREAM, with fs_k_boundary at every launch size */
 
 const char *fs_last_error(void);
 int fs_version(void);

@@ -173,6 +173,33 @@ def test_streaming_large_launch_uses_grid_form_bit_exact(gpu_required):
     ctx.close()
 
 
+def test_cloth_above_16384_particles_bit_exact(gpu_required):
+    """A 150 x 120 cloth (18 000 particles): beyond the one-launch substep boundary (fs_k_boundary holds at most 16 particles
+    per thread of its one workgroup), so the streaming back-end runs finalize / predict / scan / scatter as separate launches;
+    a heap on the ground gives real contacts.  (tests/soak/soak_huge.py goes on to 75 000 particles.)"""
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    ctx = fsim.FlingSim(n_envs=1, solver=fsim.FS_SOLVER_AUTO)
+    orc = OracleSim()
+    params = cloth_params(150, 120, pos=(0.0, -0.1, 0.0))
+    rng = np.random.RandomState(11)
+    for s_ in (ctx.env(0), orc):
+        s_.set_scene(params)
+    p = orc.get_positions().reshape(-1, 4).copy()
+    p[:, :3] += (rng.randn(p.shape[0], 3) * 0.003).astype(np.float32)
+    p[:2000, :3] = (rng.rand(2000, 3) * [0.12, 0.05, 0.12] + [0, 0.03, 0]).astype(np.float32)
+    for s_ in (ctx.env(0), orc):
+        s_.set_positions(p.ravel())
+    ctx.step(4)
+    orc.step(4)
+    assert ctx.last_kernel_form() == fsim.FS_FORM_STREAM_GRIDL
+    _assert_state_equal(ctx.env(0), orc, "150 x 120 cloth")
+    co, _ = orc.get_last_neighbors()
+    assert co.max() > 8
+    ctx.close()
+
+
 def test_batched_envs_match_single(gpu_required):
     """Episodes in one batched launch are independent: each equals the oracle run of its own seed."""
     from flingbot_amd import sim as fsim

@@ -16,6 +16,9 @@ on distinct-seed episodes, and sampled episodes are compared with the CPU oracle
                           16 x 104x104 episodes (the upper end of the reference's cloth sizes, environment/tasks.py:108-121)
     fs_k_iterate<true>    64 x 64x64 episodes, FS_SOLVER_STREAM_CODED (non-canonical cloths at that size)
     fs_k_iterate<false>   64 x 64x64 episodes, FS_SOLVER_STREAM_ELL
+    fs_k_boundary         every streaming case above (finalize + predict + bucket sort in one launch per substep boundary);
+                          FS_SOLVER_STREAM_SPLIT (7) runs the 64-episode case with the four separate kernels that cloths
+                          above 16384 particles take
     fs_k_iterate_eager    8 x 64x64 episodes, FS_SOLVER_STREAM_CODED
     fs_k_iterate_grid     112 x 64x64 distinct episodes, FS_SOLVER_STREAM_CODED
 """
@@ -230,13 +233,16 @@ def test_fused_16_slot_kernel_bit_exact(gpu_required):
     ctx.close()
 
 
-@pytest.mark.parametrize("solver,form", [(0, "FS_FORM_STREAM_GRIDL"), (6, "FS_FORM_STREAM_CODED"), (4, "FS_FORM_STREAM_ELL")])
+@pytest.mark.parametrize("solver,form", [(0, "FS_FORM_STREAM_GRIDL"), (6, "FS_FORM_STREAM_CODED"), (4, "FS_FORM_STREAM_ELL"),
+                                         (7, "FS_FORM_STREAM_GRIDL")])
 def test_streaming_64_episode_launch_bit_exact(gpu_required, solver, form):
     """BASELINE.json configs[2] (and configs[3]'s per-GPU share): 64 distinct 64x64 episodes in one launch sequence.
     AUTO routes that size to the streaming back-end, whose iterate kernel for canonical grid cloths is fs_k_iterate_gridl
     (neighbours from the grid coordinates, rest lengths from the per-particle table); FS_SOLVER_STREAM_CODED runs the
     dictionary-coded throughput form fs_k_iterate<true> every other cloth gets at this size, FS_SOLVER_STREAM_ELL
-    fs_k_iterate<false>."""
+    fs_k_iterate<false>; FS_SOLVER_STREAM_SPLIT the grid-L form with separate finalize / predict / scan / scatter launches
+    instead of fs_k_boundary (all other cases run the merged boundary kernel; 40 frames in one call chain the frames through
+    its finalize + predict form)."""
     from flingbot_amd import sim as fsim
 
     contacts = _bench_batch(64, solver, 40, [0, 1, 31, 63], getattr(fsim, form))
@@ -251,6 +257,7 @@ def test_streaming_small_and_large_launch_forms_bit_exact(gpu_required):
     _bench_batch(8, fsim.FS_SOLVER_STREAM_CODED, 40, [0, 7], fsim.FS_FORM_STREAM_EAGER)
     _bench_batch(112, fsim.FS_SOLVER_STREAM_CODED, 30, [0, 55, 111], fsim.FS_FORM_STREAM_GRID)
     _bench_batch(8, fsim.FS_SOLVER_STREAM, 40, [0, 7], fsim.FS_FORM_STREAM_GRIDL)
+    _bench_batch(3, fsim.FS_SOLVER_STREAM_MERGED, 40, [0, 2], fsim.FS_FORM_STREAM_GRIDL)  # fs_k_boundary below its launch-size threshold
 
 
 def test_large_cloth_104_batch_bit_exact(gpu_required):
