@@ -19,7 +19,8 @@ batch that was timed, compared with the C oracle after the timed region), `confi
 BASELINE.json configs[2] / configs[3] next to the headline) and, at N=1, `cpu_baseline` (the C oracle on the host
 cores this process may use, one independent episode of the same workload per core, about 15 s), `perception` (the
 value network's forward of one observation) and `eval_loop` (BASELINE.json configs[4]: the run_sim.py evaluation loop
-on 32 generated tasks at the reference's sizes), both measured after the timed region.
+on 32 generated tasks at the reference's sizes, and 128 tasks streamed through 64 slots), both measured after the timed
+region.
 """
 import argparse
 import json
@@ -369,45 +370,60 @@ def run_rank(args):
         torch.distributed.destroy_process_group()
 
 
-def eval_loop_leg(device_index, episodes=32, actions=3):
+def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=128, stream_slots=64):
     """Secondary, after the timed region (rank 0, N = 1): BASELINE.json configs[4] at the reference's own sizes -- the
-    run_sim.py evaluation loop (flingbot_amd.evaluate.run_episodes) on `episodes` generated 'hard' tasks with cloth sides
-    64..103 (environment/tasks.py:105-275), 720 x 720 render -> 400 x 400 observation with adaptive scaling, 12 rotations x
-    8 scales, seeded random-init fling policy (flingbot.pth is not in this image), up to `actions` actions per episode.
-    Reports flings/s and simulated episode-steps/s of the whole loop (perception + action selection + primitives)."""
+    run_sim.py evaluation loop on generated 'hard' tasks with cloth sides 64..103 (environment/tasks.py:105-275), 720 x 720
+    render -> 400 x 400 observation with adaptive scaling, 12 rotations x 8 scales, seeded random-init fling policy
+    (flingbot.pth is not in this image), up to `actions` actions per episode.  The loop is flingbot_amd.evaluate.run_tasks:
+    like the reference's (utils.step_env's ray.wait, SimEnv pulling its next task) every slot steps on its own and refills
+    itself.  Two figures: `episodes` tasks on as many slots (the configuration of the earlier rounds' figure), and
+    `continuous`: stream_tasks tasks through stream_slots slots (throughput of a long evaluation run).  Reports flings/s and
+    simulated episode-steps/s of the whole loop (perception + action selection + primitives + resets)."""
     try:
         import random
         import torch
         from flingbot_amd import nets, sim as fsim, tasks as ftasks
         from flingbot_amd.env import BatchedFlingEnv
-        from flingbot_amd.evaluate import run_episodes
+        from flingbot_amd.evaluate import run_tasks
 
-        random.seed(0); np.random.seed(0); torch.manual_seed(0)
-        params = [ftasks.draw_task_parameters() for _ in range(episodes)]
-        t0 = time.perf_counter()
-        gen = fsim.FlingSim(n_envs=episodes, device=device_index, solver=0)
-        tasks = ftasks.generate_tasks(gen, params)
-        gen.close()
-        t_gen = time.perf_counter() - t0
-        ctx = fsim.FlingSim(n_envs=episodes, device=device_index, solver=0)
-        env = BatchedFlingEnv(ctx, episode_length=actions, device=f"cuda:{device_index}")
-        policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
-                                         obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
-                                         depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
-                                         value_expl_decay=1.0, device=f"cuda:{device_index}")
-        t0 = time.perf_counter()
-        stats = run_episodes(policy, env, tasks)
-        dt = time.perf_counter() - t0
-        flings = int(sum(stats["action_primitive_counts"].values()))
-        sides = np.array([p["cloth_size"] for p in params])
-        ctx.close()
-        return {"baseline_config": "configs[4]", "episodes": episodes, "max_actions": actions,
-                "cloth_sides": [int(sides.min()), int(sides.max())], "transforms": len(env.transformations),
-                "render_dim": env.render_dim, "image_dim": env.image_dim, "seconds": dt, "task_generation_seconds": t_gen,
-                "flings": flings, "flings_per_s": flings / dt, "episode_steps": int(stats["simulation_steps"]),
-                "episode_steps_per_s": stats["simulation_steps"] / dt,
-                "mean_init_coverage": stats["mean"]["init_coverage"], "mean_final_coverage": stats["mean"]["final_coverage"],
-                "policy": "random-init fling value net (seeded)"}
+        def one(n_tasks, n_slots, seed):
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+            params, tasks = [], []
+            t0 = time.perf_counter()
+            for k in range(0, n_tasks, n_slots):
+                part = [ftasks.draw_task_parameters() for _ in range(min(n_slots, n_tasks - k))]
+                gen = fsim.FlingSim(n_envs=len(part), device=device_index, solver=0)
+                tasks += ftasks.generate_tasks(gen, part)
+                gen.close()
+                params += part
+            t_gen = time.perf_counter() - t0
+            ctx = fsim.FlingSim(n_envs=n_slots, device=device_index, solver=0)
+            env = BatchedFlingEnv(ctx, episode_length=actions, device=f"cuda:{device_index}")
+            policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+                                             obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
+                                             depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
+                                             value_expl_decay=1.0, device=f"cuda:{device_index}")
+            t0 = time.perf_counter()
+            stats = run_tasks(policy, env, tasks)
+            dt = time.perf_counter() - t0
+            flings = int(sum(stats["action_primitive_counts"].values()))
+            sides = np.array([p["cloth_size"] for p in params])
+            sched = stats["scheduler"]
+            ctx.close()
+            return {"episodes": n_tasks, "slots": n_slots, "max_actions": actions, "cloth_sides": [int(sides.min()), int(sides.max())],
+                    "transforms": len(env.transformations), "render_dim": env.render_dim, "image_dim": env.image_dim,
+                    "seconds": dt, "task_generation_seconds": t_gen, "flings": flings, "flings_per_s": flings / dt,
+                    "episode_steps": int(stats["simulation_steps"]), "episode_steps_per_s": stats["simulation_steps"] / dt,
+                    "launch_sequences": int(sched.get("sequences", 0)),
+                    "mean_active_episodes": sched.get("episode_steps", 0) / max(sched.get("sequences", 1), 1),
+                    "mean_init_coverage": stats["mean"]["init_coverage"], "mean_final_coverage": stats["mean"]["final_coverage"]}
+
+        out = one(episodes, episodes, 0)
+        out.update({"baseline_config": "configs[4]", "loop": "evaluate.run_tasks (asynchronous slots, run_sim.py / utils.step_env)",
+                    "policy": "random-init fling value net (seeded)"})
+        if stream_tasks > 0:
+            out["continuous"] = one(stream_tasks, stream_slots, 1)
+        return out
     except Exception as exc:  # the headline number must not depend on this leg
         return {"error": str(exc)[:300]}
 

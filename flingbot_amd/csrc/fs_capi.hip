@@ -44,6 +44,7 @@ fs_ctx::~fs_ctx() {
     if (h_ids) (void)hipHostFree(h_ids);
     if (h_stage) (void)hipHostFree(h_stage);
     if (render_scratch) (void)hipFree(render_scratch);
+    if (loop_scratch) (void)hipFree(loop_scratch);
     if (d_coverage) (void)hipFree(d_coverage);
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
@@ -59,6 +60,20 @@ void *fs_stage(fs_ctx *ctx, size_t bytes) {
     if (!fs_hip_ok(hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault), "hipHostMalloc(stage)")) return nullptr;
     ctx->h_stage_bytes = want;
     return ctx->h_stage;
+}
+
+// grow-only device scratch of the manipulation loops (fs_advance): hipMalloc / hipFree cost ~0.1-0.3 ms each and hipFree
+// synchronises the device, which a call per chunk of a few simulation steps cannot afford
+void *fs_loop_scratch(fs_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->loop_scratch_bytes) return ctx->loop_scratch;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->loop_scratch) (void)hipFree(ctx->loop_scratch);
+    ctx->loop_scratch = nullptr;
+    ctx->loop_scratch_bytes = 0;
+    const size_t want = bytes < (1u << 18) ? (1u << 18) : bytes * 2;
+    if (!fs_hip_ok(hipMalloc(&ctx->loop_scratch, want), "hipMalloc(loop scratch)")) return nullptr;
+    ctx->loop_scratch_bytes = want;
+    return ctx->loop_scratch;
 }
 
 extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camera_height) {

@@ -93,6 +93,8 @@ struct fs_ctx {
     // renderer scratch (fs_render.hip)
     void *render_scratch = nullptr;
     size_t render_scratch_bytes = 0;
+    void *loop_scratch = nullptr;     // device tables of fs_advance (fs_picker.hip), grow-only
+    size_t loop_scratch_bytes = 0;
     double *d_coverage = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // fs_timer_start / fs_timer_stop
 
@@ -102,6 +104,7 @@ struct fs_ctx {
 void fs_set_error(const std::string &msg);
 bool fs_hip_ok(hipError_t e, const char *what);
 void *fs_stage(fs_ctx *ctx, size_t bytes);
+void *fs_loop_scratch(fs_ctx *ctx, size_t bytes);
 
 // solver back-ends
 // d_ids: optional device copy of `ids` already resident (skips the upload); nullptr = upload ids to ctx->d_ids

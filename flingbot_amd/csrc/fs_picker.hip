@@ -369,14 +369,17 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
 // wait_until_stable only counts its steps.
 // One device id list per launch sequence: [waiters | movers still moving at this step]; a check kernel retires a waiter
 // (id -> -1) when it is stable or its step budget is used up, the picker kernel moves the movers' pickers.
-__global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int *ids, double tol, const int *budget, int *steps,
-                                                       int *stable) {
+__global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int *row, const double *tols, const int *budget,
+                                                       int *steps, int *stable, int *dead) {
     __shared__ float red[256];
     const int slot = blockIdx.x;
-    const int e = ids[slot];
-    if (e < 0) return;
+    if (dead[slot]) {  // retired in an earlier launch sequence: this sequence's list entry goes too
+        if (threadIdx.x == 0) row[slot] = -1;
+        return;
+    }
+    const int e = row[slot];
     if (steps[slot] >= budget[slot]) {  // this call's (or the loop's) steps are used up: not stable, no test (flex_utils.py:441)
-        if (threadIdx.x == 0) ids[slot] = -1;
+        if (threadIdx.x == 0) { row[slot] = -1; dead[slot] = 1; }
         return;
     }
     const FsEnvDev &E = envs[e];
@@ -397,14 +400,14 @@ __global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if ((double)red[0] < tol) { stable[slot] = 1; ids[slot] = -1; }
+        if ((double)red[0] < tols[slot]) { stable[slot] = 1; dead[slot] = 1; row[slot] = -1; }  // (plain steps: tolerance -1, never true)
         else steps[slot] += 1;  // the step that follows
     }
 }
 
 extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
                           const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start,
-                          double eps, double tolerance, int cap_min, int cap, int *progress_out, int *status_out,
+                          double eps, const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out,
                           int *steps_out) {
     if (!ctx || n <= 0 || n > ctx->n_envs || !envs || !kind || !limit || !start || !progress_out || !status_out || !steps_out ||
         cap <= 0 || cap_min <= 0 || cap_min > cap) {
@@ -429,10 +432,11 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
                 return FS_ERR_STATE;
             }
             movers.push_back(a);
-        } else if (kind[a] == 1) {
+        } else if (kind[a] == 1 || kind[a] == 2) {
+            if (kind[a] == 1 && !tolerance) { fs_set_error("fs_advance: tolerance missing"); return FS_ERR_ARG; }
             waiters.push_back(a);
         } else {
-            fs_set_error("fs_advance: kind must be 0 (movep) or 1 (wait_until_stable)");
+            fs_set_error("fs_advance: kind must be 0 (movep), 1 (wait_until_stable) or 2 (plain steps)");
             return FS_ERR_ARG;
         }
     }
@@ -467,70 +471,76 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
         w_budget[q] = left < 0 ? 0 : (left < chunk ? left : chunk);
         if ((size_t)w_budget[q] > n_seq) n_seq = (size_t)w_budget[q];
         if (w_budget[q] == 0) {  // budget of the whole loop already used: wait_until_stable returns False
-            progress_out[a] = start[a]; status_out[a] = 2; steps_out[a] = 0;
+            progress_out[a] = start[a]; status_out[a] = kind[a] == 2 ? 1 : 2; steps_out[a] = 0;
         }
     }
     if (n_seq == 0) return FS_OK;
-    // device tables
-    const int width = nm > 0 ? nm : 1;
-    std::vector<int> h_tab(n_seq * width, -1), h_cnt(n_seq, 0);
-    std::vector<FsPickerCmd> h_cmds(n_seq * width);
-    for (size_t s = 0; s < n_seq; ++s)
+    // device tables, ONE upload into the context's scratch.  Per launch sequence s a row of the launch list:
+    // [waiters | movers still moving at s | -1 ...]; the check kernel retires a waiter from its row and, through dead[], from
+    // every later row.
+    const int width = nm > 0 ? nm : 1, W = nw + width, n_envs = ctx->n_envs;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~size_t(15); return o; };
+    const size_t o_picked = carve(sizeof(int *) * n_envs), o_saved = carve(sizeof(float *) * n_envs);
+    const size_t o_tol = carve(sizeof(double) * (nw > 0 ? nw : 1));
+    const size_t o_cmds = carve(sizeof(FsPickerCmd) * n_seq * width);
+    const size_t o_rows = carve(sizeof(int) * n_seq * W);
+    const size_t o_wait = carve(sizeof(int) * 4 * (nw > 0 ? nw : 1));  // budget | steps | stable | dead
+    std::vector<char> blob(off, 0);
+    int **h_picked = (int **)(blob.data() + o_picked);
+    float **h_saved = (float **)(blob.data() + o_saved);
+    double *h_tol = (double *)(blob.data() + o_tol);
+    FsPickerCmd *h_cmds = (FsPickerCmd *)(blob.data() + o_cmds);
+    int *h_rows = (int *)(blob.data() + o_rows), *h_wait = (int *)(blob.data() + o_wait);
+    std::vector<int> h_cnt(n_seq, 0);
+    for (int i = 0; i < n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
+    for (int q = 0; q < nw; ++q) {
+        h_tol[q] = kind[waiters[q]] == 1 ? tolerance[waiters[q]] : -1.0;
+        h_wait[q] = w_budget[q];
+    }
+    for (size_t s = 0; s < n_seq; ++s) {
+        int *row = h_rows + s * W;
+        for (int k = 0; k < W; ++k) row[k] = -1;
+        for (int q = 0; q < nw; ++q) row[q] = envs[waiters[q]];
         for (int q = 0; q < nm; ++q)
             if (s < plans[q].cmds.size()) {
                 const int slot = h_cnt[s]++;
-                h_tab[s * width + slot] = envs[movers[q]];
+                row[nw + slot] = envs[movers[q]];
                 h_cmds[s * width + slot] = plans[q].cmds[s];
             }
-    std::vector<int> h_w(4 * (nw > 0 ? nw : 1), 0);  // ids | budget | steps | stable
-    for (int q = 0; q < nw; ++q) { h_w[q] = envs[waiters[q]]; h_w[nw + q] = w_budget[q]; }
-    std::vector<int *> h_picked(ctx->n_envs, nullptr);
-    std::vector<float *> h_saved(ctx->n_envs, nullptr);
-    for (int i = 0; i < ctx->n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
-    struct DevBufs {
-        int *tab = nullptr, *wait = nullptr, *all = nullptr;
-        FsPickerCmd *cmds = nullptr;
-        int **picked = nullptr;
-        float **saved = nullptr;
-        ~DevBufs() { (void)hipFree(tab); (void)hipFree(wait); (void)hipFree(all); (void)hipFree(cmds); (void)hipFree(picked); (void)hipFree(saved); }
-    } bufs;
-    HIP_TRY(hipMalloc((void **)&bufs.tab, sizeof(int) * h_tab.size()));
-    HIP_TRY(hipMalloc((void **)&bufs.cmds, sizeof(FsPickerCmd) * h_cmds.size()));
-    HIP_TRY(hipMalloc((void **)&bufs.wait, sizeof(int) * h_w.size()));
-    HIP_TRY(hipMalloc((void **)&bufs.all, sizeof(int) * (size_t)(nw + width)));
-    HIP_TRY(hipMalloc((void **)&bufs.picked, sizeof(int *) * ctx->n_envs));
-    HIP_TRY(hipMalloc((void **)&bufs.saved, sizeof(float *) * ctx->n_envs));
+    }
+    char *dev = (char *)fs_loop_scratch(ctx, off);
+    if (!dev) return FS_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(bufs.tab, h_tab.data(), sizeof(int) * h_tab.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bufs.cmds, h_cmds.data(), sizeof(FsPickerCmd) * h_cmds.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bufs.wait, h_w.data(), sizeof(int) * h_w.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bufs.picked, h_picked.data(), sizeof(int *) * ctx->n_envs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(bufs.saved, h_saved.data(), sizeof(float *) * ctx->n_envs, hipMemcpyHostToDevice));
-    if (nw > 0) HIP_TRY(hipMemcpy(bufs.all, h_w.data(), sizeof(int) * nw, hipMemcpyHostToDevice));  // the waiters lead the list
-    int *d_w_budget = bufs.wait + nw, *d_w_steps = bufs.wait + 2 * nw, *d_w_stable = bufs.wait + 3 * nw;
+    HIP_TRY(hipMemcpy(dev, blob.data(), off, hipMemcpyHostToDevice));
+    int **d_picked = (int **)(dev + o_picked);
+    float **d_saved = (float **)(dev + o_saved);
+    const double *d_tol = (const double *)(dev + o_tol);
+    const FsPickerCmd *d_cmds = (const FsPickerCmd *)(dev + o_cmds);
+    int *d_rows = (int *)(dev + o_rows), *d_wait = (int *)(dev + o_wait);
+    int *d_w_budget = d_wait, *d_w_steps = d_wait + nw, *d_w_stable = d_wait + 2 * nw, *d_w_dead = d_wait + 3 * nw;
     int rc = FS_OK;
+    std::vector<int> ids;
     for (size_t s = 0; s < n_seq && rc == FS_OK; ++s) {
         const int cnt = h_cnt[s];
-        std::vector<int> ids;
-        for (int q = 0; q < nw; ++q) ids.push_back(envs[waiters[q]]);
-        for (int k = 0; k < cnt; ++k) ids.push_back(h_tab[s * width + k]);
+        int *d_row = d_rows + s * W;
+        ids.assign(h_rows + s * W, h_rows + s * W + nw + cnt);
         if (cnt > 0) {
-            HIP_TRY(hipMemcpyAsync(bufs.all + nw, bufs.tab + s * width, sizeof(int) * cnt, hipMemcpyDeviceToDevice, ctx->stream));
-            const double thr = picker_grasp_threshold(ctx->envs[h_tab[s * width]]);
-            hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes,
-                               bufs.tab + s * width, bufs.cmds + s * width, bufs.picked, bufs.saved, thr);
+            const double thr = picker_grasp_threshold(ctx->envs[ids[nw]]);
+            hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes, d_row + nw,
+                               d_cmds + s * width, d_picked, d_saved, thr);
         }
         if (nw > 0)
-            hipLaunchKernelGGL(fs_k_wait_check, dim3(nw), dim3(256), 0, ctx->stream, ctx->d_envs, bufs.all, tolerance,
-                               d_w_budget, d_w_steps, d_w_stable);
-        rc = fs_step_ids(ctx, ids, 1, bufs.all);
+            hipLaunchKernelGGL(fs_k_wait_check, dim3(nw), dim3(256), 0, ctx->stream, ctx->d_envs, d_row, d_tol, d_w_budget,
+                               d_w_steps, d_w_stable, d_w_dead);
+        rc = fs_step_ids(ctx, ids, 1, d_row);
         if (rc == FS_OK && nw > 0 && s >= mover_seq && (s & 15) == 15 && s + 1 < n_seq) {  // only waiters left: all retired?
-            std::vector<int> live(nw);
-            hipError_t pe = hipMemcpyAsync(live.data(), bufs.all, sizeof(int) * nw, hipMemcpyDeviceToHost, ctx->stream);
+            int *live = (int *)fs_stage(ctx, sizeof(int) * nw);
+            hipError_t pe = live ? hipMemcpyAsync(live, d_w_dead, sizeof(int) * nw, hipMemcpyDeviceToHost, ctx->stream) : hipErrorOutOfMemory;
             if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);
             if (!fs_hip_ok(pe, "fs_advance poll")) { rc = FS_ERR_HIP; break; }
             bool any = false;
-            for (int v : live) any = any || v >= 0;
+            for (int q = 0; q < nw; ++q) any = any || live[q] == 0;
             if (!any) break;
         }
     }
@@ -547,7 +557,7 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
         const int taken = w_out[q], stable = w_out[nw + q];
         progress_out[a] = start[a] + taken;
         steps_out[a] = taken;
-        status_out[a] = stable ? 1 : (progress_out[a] >= limit[a] ? 2 : 0);
+        status_out[a] = stable ? 1 : (progress_out[a] >= limit[a] ? (kind[a] == 2 ? 1 : 2) : 0);
     }
     // host mirrors of the shape states follow the planned trajectories
     for (int q = 0; q < nm; ++q) {

@@ -651,6 +651,12 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
     fs_iterate_particle_gridl(E, shapes[e], i, sub, flip);
 }
 
+// (A GRID-T form -- this kernel with the 256 + 4 dimx positions a workgroup's particles and their spring neighbours occupy
+// staged in LDS by coalesced loads, 2.6 dwordx4 loads per thread instead of 13 gathers -- was built and measured in round 2:
+// bit-identical and SLOWER at every launch size (64x64 x 64 episodes 1.480 -> 1.504 ms per step, x 8: 1.05 -> 1.17, x 256:
+// 4.19 -> 4.38): the gathers hit the L1 / the XCD's L2 and are not what a launch waits for, while the staging adds a barrier
+// and an LDS hop to the chain of dependent latencies that is.  Removed)
+
 // The spring dictionary of the workgroup's episode -> LDS (one entry per thread; FS_TILE = 256 = dictionary size).
 template <bool CODED>
 __device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict) {

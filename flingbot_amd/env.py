@@ -20,7 +20,7 @@ import torch
 from . import nets
 from .action import ActionSelector
 from .primitives import FlingPrimitives
-from .tasks import load_tasks
+from .tasks import load_task_scene, load_task_state, load_tasks
 
 
 class BatchedFlingEnv:
@@ -172,6 +172,70 @@ class BatchedFlingEnv:
                 self.prim.grasp_states[e] = list(sub.grasp_states[e])
         self.prim.postaction(run)
         return self._finish_step(run, chosen, prev)
+
+    # ---- SimEnv.reset + SimEnv.step until the episode ends, for ONE slot, as a program (flingbot_amd/schedule.py)
+    def open_slots(self, slots):
+        """Bookkeeping for slots that episode_program will fill (instead of reset / attach)."""
+        self.envs = [int(e) for e in slots]
+        self.prim = FlingPrimitives(self.sim, self.envs, **self._prim_kwargs)
+        self.timestep = {e: 0 for e in self.envs}
+        self.terminate = {e: True for e in self.envs}
+        self.init_coverage = np.zeros(self.sim.n_envs)
+        self.unpaid_steps = 0  # simulation steps the lock-step path does not count either (the step inside set_scene)
+
+    def episode_program(self, e, task):
+        """One episode in slot e -- SimEnv.reset (simEnv.py:663-697: set_scene(config, state), initial coverage, pickers,
+        reset_end_effectors, one step, grasp off) and then SimEnv.step (simEnv.py:477-515) until it terminates -- written as
+        the reference's straight-line code with a request wherever it needs the simulator, the policy or a reduction (see
+        schedule.run_programs; evaluate.run_tasks provides the services "observe", "act", "coverage", "snapshot",
+        "max_disp").  Returns {'coverage': [initial, after step 1, ...] (absolute areas), 'actions': [primitive or None, ...]}."""
+        from . import schedule as sch
+
+        e = int(e)
+        sim, prim = self.sim, self.prim
+        ep = sch.Episode(prim, e)
+        load_task_scene(sim, e, task)
+        yield ("step", 1)
+        self.unpaid_steps += 1
+        load_task_state(sim, e, task)
+        cov = yield ("coverage",)
+        self.init_coverage[e] = cov
+        prim.grasp_states[e] = [False, False]
+        prim.terminate[e] = False
+        prim.place_pickers(e)
+        yield from sch.reset_end_effectors(ep)
+        yield ("step", 1)
+        prim.set_grasp([e], False)
+        cp = sim.get_camera_params(e)
+        sim.set_camera_params(e, [*cp[2:8], self.render_dim, self.render_dim])
+        self.timestep[e], self.terminate[e] = 0, False
+        cov = yield ("coverage",)  # what run_sim's statistics call the initial coverage: the state the first observation shows
+        rec = dict(coverage=[float(cov)], actions=[])
+        obs = yield ("observe",)
+        while True:
+            maps = yield ("act", obs)
+            action, params = self.selector.select(maps, self.adaptive_scale_factors[e], self.pretransform_depth[e])
+            body = None
+            if action is not None:
+                d, pix = self.pretransform_depth[e], params["pretransform_pixels"]
+                g1 = self._on_cloth(d, (pix[0][1], pix[0][0]))
+                g2 = self._on_cloth(d, (pix[1][1], pix[1][0]))
+                body = sch.PROGRAMS[action](ep, params["p1"], params["p2"], g1, g2)
+            yield ("snapshot",)                      # preaction
+            prev = yield ("coverage",)
+            yield from sch.action_then_settle(ep, body)
+            moved = yield ("max_disp",)
+            if moved < 5e-2:  # if didn't really move cloth then end early (simEnv.py:470-475)
+                prim.terminate[e] = True
+            curr = yield ("coverage",)
+            self.timestep[e] += 1
+            self.terminate[e] = prim.terminate[e] or self.timestep[e] >= self.episode_length
+            rec["coverage"].append(float(curr))
+            rec["actions"].append(action)
+            rec.setdefault("rewards", []).append(float(curr - prev))
+            if self.terminate[e]:
+                return rec
+            obs = yield ("observe",)
 
     def _finish_step(self, run, chosen, prev):
         curr = np.array(self.sim.coverage())

@@ -56,6 +56,79 @@ def run_episodes(policy, env, tasks, max_steps=None, fold=True):
     }
 
 
+def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32):
+    """The evaluation loop the way the reference actually runs it: every environment steps on its own, the policy acts for
+    whichever environments are ready (utils.step_env, utils.py:394-418: `ray.wait` on the step futures), and an environment
+    whose episode ends pulls the NEXT task by itself (SimEnv.step -> on_episode_end -> reset -> get_task_fn, tasks.py
+    TaskLoader.get_next_task) -- continuous batching of `len(tasks)` episodes over the `env.sim.n_envs` slots of one GPU
+    context.  Each slot runs BatchedFlingEnv.episode_program; schedule.run_programs serves them together: observations of
+    all ready slots in one fs_observe_batch call, one batched value-net forward, shared launch sequences for every
+    simulation step (fs_advance).  Episodes are independent and every stage is deterministic per episode, so the
+    statistics equal run_episodes' on the same tasks exactly (tests/test_evaluate_gpu.py); what changes is that no episode
+    waits for another one -- neither inside an action nor between actions nor at the end of an episode.
+    Returns run_episodes' dictionary (arrays ordered by task index)."""
+    from collections import deque
+
+    from . import nets, schedule as sch
+
+    if fold:
+        for net in policy.value_nets.values():
+            if getattr(net, "_folded", None) is None:
+                net.fold_batchnorm()
+    sim = env.sim
+    slots = list(range(min(sim.n_envs, len(tasks))))
+    env.open_slots(slots)
+    queue = deque(enumerate(tasks))
+    records = {}
+
+    def slot_program(slot):
+        while queue:
+            ti, task = queue.popleft()
+            records[ti] = yield from env.episode_program(slot, task)
+
+    def observe(reqs):
+        es = [e for e, _ in reqs]
+        obs = env.get_obs_batch(es)
+        return [nets.prepare_image(obs[k], env.get_transformations(e), env.obs_dim) for k, e in enumerate(es)]
+
+    def act(reqs):
+        with torch.no_grad():
+            maps = policy.act([a[0] for _, a in reqs], keep_on_device=True)
+        return [{k: v.to(env.device) for k, v in m.items()} for m in maps]
+
+    def coverage(reqs):
+        cov = np.array(sim.coverage())
+        return [cov[e] for e, _ in reqs]
+
+    def snapshot(reqs):
+        sim.snapshot_positions([e for e, _ in reqs])
+        return [None] * len(reqs)
+
+    services = {"observe": observe, "act": act, "coverage": coverage, "snapshot": snapshot,
+                "max_disp": lambda reqs: list(sim.max_displacement([e for e, _ in reqs]))}
+    sch.run_programs(env.prim, {s: slot_program(s) for s in slots}, cap_min=cap_min, cap=cap, services=services)
+    n = len(tasks)
+    flat = np.array([float(t["flatten_area"]) for t in tasks])
+    lengths = np.array([len(records[i]["actions"]) for i in range(n)], int)
+    steps = int(lengths.max()) if n else 0
+    trace = np.stack([[records[i]["coverage"][min(k, lengths[i])] for i in range(n)] for k in range(steps + 1)]) / flat
+    counts = {a: 0 for a in env.actions}
+    for i in range(n):
+        for a in records[i]["actions"]:
+            if a is not None:
+                counts[a] += 1
+    init, final = trace[0], trace[-1]
+    return {
+        "init_coverage": init, "final_coverage": final, "best_coverage": trace.max(axis=0),
+        "episode_delta_coverage": final - init, "episode_length": lengths,
+        "delta_coverage_steps": np.diff(trace, axis=0), "coverage_steps": trace, "action_primitive_counts": counts,
+        "simulation_steps": int(env.prim.sim_steps - env.unpaid_steps), "scheduler": dict(getattr(env.prim, "sched_stats", {})),
+        "mean": {"init_coverage": float(init.mean()), "final_coverage": float(final.mean()),
+                 "best_coverage": float(trace.max(axis=0).mean()), "episode_delta_coverage": float((final - init).mean()),
+                 "episode_length": float(lengths.mean())},
+    }
+
+
 def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=run_episodes, **kwargs):
     """BASELINE.json configs[3] for the evaluation loop: global episode g runs on rank g // episodes_per_rank (one process
     per GPU, launched with torch.distributed.run); the only exchange is the all_gather of the per-episode initial / final

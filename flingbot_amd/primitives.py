@@ -39,20 +39,24 @@ class FlingPrimitives:
     # ---- SimEnv.reset after set_scene (simEnv.py:674-681): action_tool.reset([0.2, 0.5, 0.0]), reset_end_effectors,
     #      one simulation step, set_grasp(False)
     def setup_pickers(self, center=(0.2, 0.5, 0.0), picker_radius=None, picker_threshold=0.005, particle_radius=0.00625):
-        r_p = self.grasp_height if picker_radius is None else picker_radius  # picker_radius = grasp_height (simEnv.py:129-134)
-        r = np.sqrt(2 - 1) * r_p * 2.
-        centres = [[center[0] + np.cos(2 * np.pi * i / 2) * r, center[1], center[2] + np.sin(2 * np.pi * i / 2) * r]
-                   for i in range(2)]
         for e in (int(e) for e in self.envs):
-            for c in centres:
-                self.sim.add_sphere(e, r_p, c, [1, 0, 0, 0])
-            self.sim.set_shape_states(e, self.sim.get_shape_states(e))
-            self.sim.set_shape_states(e, np.array([np.hstack([c, c, [1, 0, 0, 0], [1, 0, 0, 0]]) for c in centres]))
-            self.sim.picker_reset(e, picker_threshold, particle_radius, picker_radius=r_p)
+            self.place_pickers(e, center, picker_radius, picker_threshold, particle_radius)
         self.reset_end_effectors(self.envs)
         self.sim.step_list([int(e) for e in self.envs], 1)
         self.sim_steps += len(self.envs)
         self.set_grasp(self.envs, False)
+
+    def place_pickers(self, e, center=(0.2, 0.5, 0.0), picker_radius=None, picker_threshold=0.005, particle_radius=0.00625):
+        """Picker.reset(center) for one episode (flex_utils.py:82-101): the two spheres, their states, the picker bookkeeping."""
+        r_p = self.grasp_height if picker_radius is None else picker_radius  # picker_radius = grasp_height (simEnv.py:129-134)
+        r = np.sqrt(2 - 1) * r_p * 2.
+        centres = [[center[0] + np.cos(2 * np.pi * i / 2) * r, center[1], center[2] + np.sin(2 * np.pi * i / 2) * r]
+                   for i in range(2)]
+        for c in centres:
+            self.sim.add_sphere(e, r_p, c, [1, 0, 0, 0])
+        self.sim.set_shape_states(e, self.sim.get_shape_states(e))
+        self.sim.set_shape_states(e, np.array([np.hstack([c, c, [1, 0, 0, 0], [1, 0, 0, 0]]) for c in centres]))
+        self.sim.picker_reset(e, picker_threshold, particle_radius, picker_radius=r_p)
 
     # ---- SimEnv.movep for a subset of the episodes, each with its own targets
     def movep(self, envs, targets, speed=None, min_steps=None, limit=1000):

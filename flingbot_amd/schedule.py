@@ -17,7 +17,8 @@ as environment/simEnv.py, one episode at a time --
     SimEnv.postaction (reset_end_effectors + wait_until_stable)  simEnv.py:467-475, flex_utils.py:430-441
 
 and yields a REQUEST wherever the reference touches the simulator: ("movep", targets, speed, min_steps, limit),
-("wait", max_steps, tolerance), ("stats",) (cloth heights / speed), ("probe", midpoint_xz, height) (stretch_cloth's test).
+("wait", max_steps, tolerance), ("step", n), ("stats",) (cloth heights / speed), ("probe", midpoint_xz, height)
+(stretch_cloth's test).
 `run_programs` serves the requests of all episodes together: reductions in one batched call per kind, motion through
 `FlingSim.advance` (fs_advance), which steps every episode through the next chunk of ITS OWN loop in shared launch sequences.
 Episodes are independent and both loops are resumable without changing a bit (a movep iteration reads only the pickers'
@@ -248,10 +249,26 @@ PROGRAMS = {"fling": pick_and_fling, "drag": pick_and_drag, "place": pick_and_pl
 
 
 # ---- the scheduler ---------------------------------------------------------------------------------------------------
-def run_programs(prim, programs, cap_min=8, cap=64, eps=1e-4):
+def _serve_stats(sim, reqs):
+    rows = sim.cloth_stats([e for e, _ in reqs])
+    return [rows[k] for k in range(len(reqs))]
+
+
+def _serve_probe(sim, reqs):
+    single, nearest = sim.stretch_probe([e for e, _ in reqs], [a[0] for _, a in reqs], [a[1] for _, a in reqs])
+    return [(bool(single[k]), nearest[k]) for k in range(len(reqs))]
+
+
+def run_programs(prim, programs, cap_min=8, cap=64, eps=1e-4, services=None):
     """Run {episode: generator} to completion on prim.sim; returns {episode: the program's return value}.  Simulation steps
-    are added to prim.sim_steps.  cap_min / cap: bounds of one fs_advance chunk (see include/flingsim.h)."""
+    are added to prim.sim_steps.  cap_min / cap: bounds of one fs_advance chunk (see include/flingsim.h).
+    Requests a program may yield: ("movep", targets, speed, min_steps, limit), ("wait", max_steps, tolerance),
+    ("step", n) -- served together by FlingSim.advance -- and host-side ones, served in ONE batched call per kind for all the
+    episodes that stand at it: "stats", "probe", plus whatever `services` adds ({kind: fn([(episode, args), ...]) -> results};
+    flingbot_amd/evaluate.py registers observation, policy and reward services there)."""
     sim = prim.sim
+    table = {"stats": lambda reqs: _serve_stats(sim, reqs), "probe": lambda reqs: _serve_probe(sim, reqs)}
+    table.update(services or {})
     gens = {int(e): g for e, g in programs.items()}
     results, pending = {}, {}
 
@@ -270,41 +287,39 @@ def run_programs(prim, programs, cap_min=8, cap=64, eps=1e-4):
                               start=0, steps=0)
         elif req[0] == "wait":
             pending[e] = dict(kind=1, limit=int(req[1]), tolerance=float(req[2]), start=0, steps=0)
-        else:
+        elif req[0] == "step":
+            pending[e] = dict(kind=2, limit=int(req[1]), start=0, steps=0)
+        elif req[0] in table:
             pending[e] = dict(kind=req[0], args=req[1:])
+        else:
+            raise ValueError(f"run_programs: unknown request {req[0]!r} from episode {e}")
 
     for e in sorted(gens):
         resume(e, None)
     while pending:
-        # reductions first, one batched call per kind, until every episode waits for simulation steps
+        # host-side requests first, one batched call per kind, until every episode waits for simulation steps
         while True:
-            stats = sorted(e for e, r in pending.items() if r["kind"] == "stats")
-            probes = sorted(e for e, r in pending.items() if r["kind"] == "probe")
-            if not stats and not probes:
+            kinds = sorted({r["kind"] for r in pending.values() if not isinstance(r["kind"], int)})
+            if not kinds:
                 break
-            if stats:
-                rows = sim.cloth_stats(stats)
-                for k, e in enumerate(stats):
-                    resume(e, rows[k])
-            if probes:
-                single, nearest = sim.stretch_probe(probes, [pending[e]["args"][0] for e in probes],
-                                                    [pending[e]["args"][1] for e in probes])
-                for k, e in enumerate(probes):
-                    resume(e, (bool(single[k]), nearest[k]))
+            for kind in kinds:
+                who = sorted(e for e, r in pending.items() if r["kind"] == kind)
+                if not who:
+                    continue
+                out = table[kind]([(e, pending[e]["args"]) for e in who])
+                for k, e in enumerate(who):
+                    resume(e, out[k])
         if not pending:
             break
         order = sorted(pending)
         reqs = [pending[e] for e in order]
         n_shapes = max([r["targets"].shape[0] for r in reqs if r["kind"] == 0], default=2)
-        tol = {r["tolerance"] for r in reqs if r["kind"] == 1}
-        if len(tol) > 1:
-            raise ValueError("run_programs: the waiting episodes of one call need the same tolerance")
         zeros, nog = np.zeros((n_shapes, 3)), [0] * n_shapes
         prog, status, steps = sim.advance(
             order, [r["kind"] for r in reqs], [r["targets"] if r["kind"] == 0 else zeros for r in reqs],
             [r["grasp"] if r["kind"] == 0 else nog for r in reqs], [r.get("speed", 0.0) for r in reqs],
             [r["limit"] for r in reqs], [r.get("min_steps", -1) for r in reqs], [r.get("f32", 0) for r in reqs],
-            [r["start"] for r in reqs], cap_min=cap_min, cap=cap, eps=eps, tolerance=tol.pop() if tol else 1e-2)
+            [r["start"] for r in reqs], cap_min=cap_min, cap=cap, eps=eps, tolerance=[r.get("tolerance", -1.0) for r in reqs])
         prim.sim_steps += int(np.sum(steps))
         st = prim.__dict__.setdefault("sched_stats", dict(calls=0, sequences=0, episode_steps=0, slots=0))
         st["calls"] += 1
@@ -320,6 +335,8 @@ def run_programs(prim, programs, cap_min=8, cap=64, eps=1e-4):
                 if status[k] == 2:
                     raise MoveLimitError(f"movep: step limit reached in episode {e} (MoveJointsException)")
                 resume(e, None)
-            else:
+            elif r["kind"] == 1:
                 resume(e, (status[k] == 1, r["steps"]))
+            else:
+                resume(e, None)
     return results

@@ -100,7 +100,7 @@ def load_library(build_if_missing=True):
         "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_movep_batch_f32": (ci, [vp, ci, ip, fp, ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_advance": (ci, [vp, ci, ip, ip, C.POINTER(C.c_double), ip, C.POINTER(C.c_double), ip, ip, ip, ip, C.c_double,
-                            C.c_double, ci, ci, ip, ip, ip]),
+                            C.POINTER(C.c_double), ci, ci, ip, ip, ip]),
         "fs_wait_until_stable": (ci, [vp, ci, ip, ci, C.c_double, ip, ip]),
         "fs_cloth_stats": (ci, [vp, ci, ip, fp, ci]),
         "fs_stretch_probe": (ci, [vp, ci, ip, fp, fp, ip, fp]),
@@ -274,8 +274,9 @@ class FlingSim:
         """One chunk of simulation for episodes in DIFFERENT phases of their primitives (fs_advance): kind[a] 0 = movep
         towards targets[a] ([S,3]) with grasp[a], speed[a], iteration limit[a], min_steps[a] (None -> -1), f32[a] (the
         caller's targets were float32), resumed at loop iteration start[a]; 1 = wait_until_stable with max_steps =
-        limit[a], start[a] steps already taken.  Returns (progress, status, steps) int32 arrays: status 0 = call again
-        with start = progress, 1 = finished, 2 = finished at the limit."""
+        limit[a], start[a] steps already taken, tolerance (scalar or per entry); 2 = limit[a] plain steps.  Returns
+        (progress, status, steps) int32 arrays: status 0 = call again with start = progress, 1 = finished, 2 = finished
+        at the limit."""
         ids, kd = _i(envs), _i(kind)
         n = ids.size
         tg = np.ascontiguousarray(np.asarray(targets, np.float64).reshape(n, -1))
@@ -283,9 +284,10 @@ class FlingSim:
         sp = np.ascontiguousarray(np.asarray(speed, np.float64).reshape(n))
         lim, ms, f3, st = _i(limit), _i(min_steps), _i(f32), _i(start)
         prog, status, steps = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(tolerance, np.float64), (n,)))
         dp = C.POINTER(C.c_double)
         self._ck(self.lib.fs_advance(self.h, n, _ip(ids), _ip(kd), tg.ctypes.data_as(dp), _ip(gr), sp.ctypes.data_as(dp),
-                                     _ip(lim), _ip(ms), _ip(f3), _ip(st), float(eps), float(tolerance), int(cap_min), int(cap),
+                                     _ip(lim), _ip(ms), _ip(f3), _ip(st), float(eps), tol.ctypes.data_as(dp), int(cap_min), int(cap),
                                      _ip(prog), _ip(status), _ip(steps)))
         return prog, status, steps
 

@@ -159,13 +159,14 @@ long long fs_last_movep_steps(const fs_ctx *ctx);
    (one host round trip per call) when somebody has that many left: kind[a] = 0: SimEnv.movep (simEnv.py:739-769) towards targets[a] ([S][3], float64; f32[a]
    != 0: the caller's targets were a float32 array, see fs_movep_batch_f32) with grasp[a][S], speed[a], iteration limit[a],
    min_steps[a] (< 0: None), resumed at loop iteration start[a]; kind[a] = 1: flex_utils.wait_until_stable
-   (flex_utils.py:430-441) with max_steps = limit[a], of which start[a] steps are already taken, tolerance `tolerance`.
+   (flex_utils.py:430-441) with max_steps = limit[a], of which start[a] steps are already taken, tolerance tolerance[a];
+   kind[a] = 2: limit[a] plain pyflex.step() calls, start[a] of them taken (status 1 when done).
    Out: progress[a] = loop iteration / step count reached (pass it back as start[a]), status[a] = 0 continue with another
    call, 1 finished (targets reached / stable), 2 finished at the limit (movep: MoveJointsException; wait: not stable),
    steps[a] = simulation steps this call took for the episode.  Results are identical to the uninterrupted loops. */
 int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
                const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start, double eps,
-               double tolerance, int cap_min, int cap, int *progress_out, int *status_out, int *steps_out);
+               const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out, int *steps_out);
 /* picked particle index per picker (-1 = none) */
 int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
 /* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all

@@ -89,6 +89,7 @@ class OracleBatch:
         prog, status, steps = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
         self.advance_calls = getattr(self, "advance_calls", 0) + 1
         chunk = cap if not any(k == 0 for k in kind) else max(cap_min, 1)  # CPU stand-in: fixed short chunks (worst case for resumption)
+        tols = np.broadcast_to(np.asarray(tolerance, np.float64), (n,))
         for a, e in enumerate(envs):
             if kind[a] == 0:
                 tg = np.asarray(targets[a], np.float32 if f32[a] else np.float64).reshape(-1, 3)
@@ -105,12 +106,12 @@ class OracleBatch:
                         break
                     if done >= chunk:
                         break
-                    if np.abs(self.sims[e].get_velocities()).max() < tolerance:
+                    if kind[a] == 1 and np.abs(self.sims[e].get_velocities()).max() < tols[a]:
                         st = 1
                         break
                     self.sims[e].step(1)
                     done += 1
-                prog[a], status[a], steps[a] = start[a] + done, st, done
+                prog[a], status[a], steps[a] = start[a] + done, (1 if st == 2 and kind[a] == 2 else st), done
         return prog, status, steps
 
     def get_shape_states(self, e):

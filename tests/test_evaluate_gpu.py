@@ -94,3 +94,48 @@ def test_full_size_eval_loop_config5(gpu_required):
           f"({stats['simulation_steps'] / dt:.0f} /s), coverage {stats['mean']['init_coverage']:.3f} -> "
           f"{stats['mean']['final_coverage']:.3f}")
     ctx.close()
+
+
+def _policy(env, seed=1):
+    from flingbot_amd import nets
+
+    torch.manual_seed(seed)
+    return nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+                                   obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
+                                   depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
+                                   value_expl_decay=1.0, device="cuda:0")
+
+
+def test_async_task_loop_equals_lockstep_loop(gpu_required):
+    """evaluate.run_tasks -- every slot runs reset / act / step on its own and pulls the next task when its episode ends
+    (run_sim.py:46-60 with utils.step_env's ray.wait asynchrony, utils.py:394-418) -- against evaluate.run_episodes, the
+    lock-step loop, on the same six generated tasks: once with one slot per task and once with TWO slots for the six tasks
+    (continuous batching: tasks land in slots the lock-step run never used for them).  Coverage after every step, episode
+    lengths, action counts and the simulation-step total are identical."""
+    from flingbot_amd import sim as fsim, tasks as ftasks
+    from flingbot_amd.env import BatchedFlingEnv
+    from flingbot_amd.evaluate import run_episodes, run_tasks
+
+    random.seed(3); np.random.seed(3)
+    n = 6
+    gen = fsim.FlingSim(n_envs=n, solver=0)
+    tasks = ftasks.generate_tasks(gen, [ftasks.draw_task_parameters(min_cloth_size=26, strict_min_edge_length=26, max_cloth_size=40)
+                                        for _ in range(n)])
+    gen.close()
+    results = []
+    for mode, slots in (("lockstep", n), ("async", n), ("async", 2)):
+        ctx = fsim.FlingSim(n_envs=slots, solver=0)
+        env = BatchedFlingEnv(ctx, image_dim=128, episode_length=3)
+        policy = _policy(env)
+        stats = (run_episodes if mode == "lockstep" else run_tasks)(policy, env, tasks)
+        assert all(net._hip is not None for net in policy.value_nets.values())
+        results.append(stats)
+        ctx.close()
+    ref = results[0]
+    assert ref["coverage_steps"].shape[0] >= 2 and sum(ref["action_primitive_counts"].values()) > 0
+    for other in results[1:]:
+        assert np.array_equal(ref["coverage_steps"], other["coverage_steps"])
+        assert np.array_equal(ref["episode_length"], other["episode_length"])
+        assert ref["action_primitive_counts"] == other["action_primitive_counts"]
+        assert ref["simulation_steps"] == other["simulation_steps"]
+        assert other["scheduler"]["calls"] > 0
