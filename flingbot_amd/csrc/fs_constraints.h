@@ -111,6 +111,9 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
 
 // fs_spring_bf with a per-lane "this slot exists" predicate (grid forms: a slot that leaves the grid gathers the particle
 // itself and must neither move nor count it, whatever its length)
+// POSK: the caller knows k > 0 (no tether): the slack test and the sign flip drop out, an active constraint performs exactly
+// the same operations
+template <bool POSK = false>
 __device__ __forceinline__ void fs_spring_bfm(FsAcc &a, float xi0, float xi1, float xi2, float wi, const FsVec4 xj, float L,
                                               float k, bool in) {
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
@@ -118,8 +121,8 @@ __device__ __forceinline__ void fs_spring_bfm(FsAcc &a, float xi0, float xi1, fl
     float inv_len = fs_rsqrt(l2);
     float len = l2 * inv_len;
     float C = len - L;
-    const bool tether = k < 0.0f;
-    const bool active = in & (len > 0.0f) & (!tether | (C > 0.0f));
+    const bool tether = !POSK && k < 0.0f;
+    const bool active = POSK ? (in & (len > 0.0f)) : (in & (len > 0.0f) & (!tether | (C > 0.0f)));
     const float kk = tether ? -k : k;
     const float wj = xj.w;
     float ratio = 0.5f;

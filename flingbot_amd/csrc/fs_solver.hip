@@ -57,7 +57,12 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     // canonical grid cloths: neighbour ids from the grid coordinates, rest lengths from the per-particle table -- no
     // adjacency, no dictionary, every load of the spring phase in one round trip (fs_k_iterate_gridl)
     bool gridl_form = !ctx->force_ell_stream && !ctx->force_coded_stream;
-    for (int id : ids) gridl_form = gridl_form && ctx->envs[id].dev.gp_L_ok;
+    bool gridl_posk = true;  // no tethers anywhere in the launch: the spring form without the slack test
+    for (int id : ids) {
+        gridl_form = gridl_form && ctx->envs[id].dev.gp_L_ok;
+        gridl_posk = gridl_posk && ctx->envs[id].dev.gp_halvable;
+    }
+    gridl_posk = gridl_posk && grid.x <= 1024u;  // one round of 4 waves per SIMD at most (see fs_k_iterate_gridl)
     hipStream_t st = ctx->stream;
     ctx->last_form = gridl_form ? FS_FORM_STREAM_GRIDL
                      : grid_form ? FS_FORM_STREAM_GRID
@@ -89,7 +94,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             for (int it = 0; it < iters; ++it) {
                 auto kern = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
                 if (grid_form) kern = fs_k_iterate_grid;
-                if (gridl_form) kern = fs_k_iterate_gridl;
+                if (gridl_form) kern = gridl_posk ? fs_k_iterate_gridl<true> : fs_k_iterate_gridl<false>;
                 hipLaunchKernelGGL(kern, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1, gx, ne);
             }
             if (!merged) hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1, gx, ne);

@@ -570,6 +570,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *env
 // decoded or staged: no dictionary, no workgroup barrier, and ALL loads of the spring phase -- own position, twelve
 // neighbour positions, twelve rest lengths, substep-start position, candidate count and the first candidate ids -- leave
 // in one round trip.  Per-particle accumulation order = canonical order = spring-id order (build_grid_pattern).
+template <bool POSK>
 __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip) {
     const FsParams &p = E.p;
     // global address space + 32-bit indices: global_load with a scalar base instead of flat loads behind 64-bit VALU adds
@@ -606,7 +607,7 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
     // code path costs registers.)
 #pragma unroll
     for (int q = 0; q < FS_G64_SLOTS; ++q)
-        fs_spring_bfm(a, xi.x, xi.y, xi.z, xi.w, xj[q], L[q], E.gp_k[q], (inb >> q) & 1u);
+        fs_spring_bfm<POSK>(a, xi.x, xi.y, xi.z, xi.w, xj[q], L[q], E.gp_k[q], (inb >> q) & 1u);
     const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
     const float restd = p.solidRestDistance, restd2 = restd * restd;
     // candidates: four per trip, the ids of the next trip requested with the positions of the current one
@@ -639,6 +640,12 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
     fs_st4o(dst, ui, xi);
 }
 
+// POSK: every episode of the launch has positive stiffnesses only (no tethers; FsEnvDev::gp_halvable, decided by the host).
+// 10 % fewer VALU instructions per spring but 106 instead of 96 VGPRs (4 instead of 5 waves per SIMD; forcing 5 spills), so
+// the launcher takes it only for launches of at most one round of 4 waves per SIMD (<= 1024 workgroups), where occupancy
+// beyond 4 buys nothing: 64x64 cloths x 1 / 8 / 32 / 64 episodes 0.913 / 1.054 / 1.133 / 1.484 -> 0.880 / 1.026 / 1.099 / 1.454 ms
+// per step; larger launches measured slower with it and keep the general form.
+template <bool POSK>
 __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
                                                               int sub, int flip, int gx, int ne) {
     int bx, by;
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
     const FsEnvDev &E = envs[e];
     const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
-    fs_iterate_particle_gridl(E, shapes[e], i, sub, flip);
+    fs_iterate_particle_gridl<POSK>(E, shapes[e], i, sub, flip);
 }
 
 // (A GRID-T form -- this kernel with the 256 + 4 dimx positions a workgroup's particles and their spring neighbours occupy

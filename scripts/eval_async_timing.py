@@ -22,10 +22,10 @@ for k in range(0, N, S):  # generated in batches of S like the loop's context
     gen.close()
 ref = None
 for label in ("lock-step", "scheduled steps", "async slots"):
-    if label != "async slots" and N > S:
+    if label != "async slots" and (N > S or os.environ.get("EVAL_ONLY_ASYNC")):
         continue
     torch.manual_seed(0)
-    ctx = fsim.FlingSim(n_envs=S, solver=0)
+    ctx = fsim.FlingSim(n_envs=S, solver=int(os.environ.get("EVAL_SOLVER", "0")))  # 7: separate boundary kernels, 1: streaming only
     env = BatchedFlingEnv(ctx, episode_length=steps, scheduled=label != "lock-step")
     policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
                                      obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
