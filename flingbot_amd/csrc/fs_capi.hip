@@ -41,6 +41,7 @@ fs_ctx::~fs_ctx() {
     if (d_envs) (void)hipFree(d_envs);
     if (d_shapes) (void)hipFree(d_shapes);
     if (d_ids) (void)hipFree(d_ids);
+    if (d_slot_envs) (void)hipFree(d_slot_envs);
     if (h_ids) (void)hipHostFree(h_ids);
     if (h_stage) (void)hipHostFree(h_stage);
     if (render_scratch) (void)hipFree(render_scratch);
@@ -101,6 +102,7 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
               fs_hip_ok(hipMalloc((void **)&ctx->d_envs, sizeof(FsEnvDev) * n_envs), "hipMalloc(envs)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_shapes, sizeof(FsShapesDev) * n_envs), "hipMalloc(shapes)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_ids, sizeof(int) * n_envs), "hipMalloc(ids)") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_slot_envs, sizeof(FsEnvDev) * n_envs), "hipMalloc(slot table)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_coverage, sizeof(double) * n_envs), "hipMalloc(cov)") &&
               fs_hip_ok(hipHostMalloc((void **)&ctx->h_ids, sizeof(int) * n_envs, hipHostMallocDefault), "hipHostMalloc") &&
               fs_hip_ok(hipMemset(ctx->d_envs, 0, sizeof(FsEnvDev) * n_envs), "hipMemset") &&

@@ -84,6 +84,7 @@ struct fs_ctx {
     std::vector<FsEnv> envs;
     FsEnvDev *d_envs = nullptr;       // [n_envs]
     FsShapesDev *d_shapes = nullptr;  // [n_envs]
+    FsEnvDev *d_slot_envs = nullptr;  // [n_envs] launch table of the streaming kernels (fs_k_slot_table)
     int *d_ids = nullptr;             // [n_envs] launch list
     int *h_ids = nullptr;             // pinned
     void *h_stage = nullptr;          // pinned staging for accessors

@@ -67,6 +67,9 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     ctx->last_form = gridl_form ? FS_FORM_STREAM_GRIDL
                      : grid_form ? FS_FORM_STREAM_GRID
                                  : (eager ? FS_FORM_STREAM_EAGER : (coded ? FS_FORM_STREAM_CODED : FS_FORM_STREAM_ELL));
+    // slot-indexed copies of the listed episodes' descriptors: one scalar indirection less in front of every kernel below
+    hipLaunchKernelGGL(fs_k_slot_table, dim3((unsigned)ne), dim3(64), 0, st, ctx->d_envs, d_ids, ctx->d_slot_envs);
+    const FsEnvDev *tab = ctx->d_slot_envs;
     // substep boundaries in one launch each (finalize + predict + bucket sort, fs_k_boundary) when every cloth fits it
     // (one workgroup per episode: launches of fewer than 16 episodes are 2-3 % faster with the four small kernels spread
     // over the chip -- measured, scripts/boundary_timing.py -- and keep them unless FS_SOLVER_STREAM_MERGED asks otherwise)
@@ -82,25 +85,25 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         for (int sub = 0; sub < substeps; ++sub) {
             if (merged) {
                 if (f == 0 && sub == 0)
-                    hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, ctx->d_envs, d_ids, 0);
+                    hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, tab, d_ids, 0);
                 else  // the finalize of the previous substep (also the previous frame's last one) rides along
-                    hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, ctx->d_envs, d_ids, iters & 1);
+                    hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, tab, d_ids, iters & 1);
             } else {
-                hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
-                hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, ctx->d_envs, d_ids);
-                hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
+                hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, tab, d_ids, gx, ne);
+                hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, tab, d_ids);
+                hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, tab, d_ids, gx, ne);
             }
-            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, ctx->d_envs, d_ids, gx, ne);
+            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, tab, d_ids, gx, ne);
             for (int it = 0; it < iters; ++it) {
                 auto kern = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
                 if (grid_form) kern = fs_k_iterate_grid;
                 if (gridl_form) kern = gridl_posk ? fs_k_iterate_gridl<true> : fs_k_iterate_gridl<false>;
-                hipLaunchKernelGGL(kern, grid, block, 0, st, ctx->d_envs, ctx->d_shapes, d_ids, sub, it & 1, gx, ne);
+                hipLaunchKernelGGL(kern, grid, block, 0, st, tab, ctx->d_shapes, d_ids, sub, it & 1, gx, ne);
             }
-            if (!merged) hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, ctx->d_envs, d_ids, iters & 1, gx, ne);
+            if (!merged) hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, tab, d_ids, iters & 1, gx, ne);
         }
     }
-    if (merged) hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, ctx->d_envs, d_ids, iters & 1);
+    if (merged) hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, tab, d_ids, iters & 1);
     HIP_TRY(hipGetLastError());
     return FS_OK;
 }

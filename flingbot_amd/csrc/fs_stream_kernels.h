@@ -32,11 +32,28 @@ __device__ __forceinline__ bool fs_stream_tile(int gx, int ne, int &bx, int &by)
     return by < ne;
 }
 
+// ---- launch table.  The kernels of a step reach their episode through the launch list: ids[slot] -> envs[episode] -> arrays,
+// two DEPENDENT scalar loads in front of every kernel's first vector load -- and a step is 129 dependent kernels of ~9 us.
+// Once per fs_step_stream call this kernel copies the descriptor of every listed episode into the slot-indexed table the
+// other kernels then receive as `envs` (slot_env = the episode id, -1 for a slot a device-side loop has retired), so each
+// of them starts with ONE scalar load.  One workgroup per slot.
+__global__ __launch_bounds__(64) void fs_k_slot_table(const FsEnvDev *envs, const int *ids, FsEnvDev *table) {
+    static_assert(sizeof(FsEnvDev) % 4 == 0, "copied as dwords");
+    const int slot = blockIdx.x, e = ids[slot];
+    uint32_t *dst = (uint32_t *)(table + slot);
+    if (e >= 0) {
+        const uint32_t *src = (const uint32_t *)(envs + e);
+        for (unsigned k = threadIdx.x; k < sizeof(FsEnvDev) / 4; k += 64) dst[k] = src[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) table[slot].slot_env = e;
+}
+
 __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *ids, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    if (ids[by] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[by]];
+    const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
+    if (E.slot_env < 0) return;    // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     const FsParams &p = E.p;
@@ -62,8 +79,8 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, co
 
 // ---- exclusive scan of the bucket histogram (one workgroup per episode); leaves count/fill zeroed for the next use
 __global__ __launch_bounds__(1024) void fs_k_grid_scan(const FsEnvDev *envs, const int *ids) {
-    if (ids[blockIdx.x] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[blockIdx.x]];
+    const FsEnvDev &E = envs[blockIdx.x];
+    if (E.slot_env < 0) return;  // retired slot
     __shared__ int wave_tot[16];
     constexpr int PER = FS_GRID_BUCKETS / 1024;
     const int t = threadIdx.x;
@@ -97,8 +114,8 @@ __global__ __launch_bounds__(1024) void fs_k_grid_scan(const FsEnvDev *envs, con
 __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *envs, const int *ids, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    if (ids[by] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[by]];
+    const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
+    if (E.slot_env < 0) return;    // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     const FsParams &p = E.p;
@@ -123,21 +140,25 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 #define FS_BOUND_THREADS 1024
 #define FS_BOUND_PPT 16
 #define FS_BOUND_MAX (FS_BOUND_THREADS * FS_BOUND_PPT)
-#define FS_BOUND_LDS_BYTES (FS_GRID_BUCKETS * 4 + 64)
+// histogram entry of bucket b: one pad word per 32 buckets, so that the scan's 16 consecutive buckets per thread (lane
+// stride 16 words = 2 banks for a whole wave) spread over all banks (measured: fs_k_boundary 24.5 -> see DESIGN.md 4.2)
+#define FS_BOUND_IDX(b) ((b) + ((b) >> 5))
+#define FS_BOUND_HIST (FS_GRID_BUCKETS + FS_GRID_BUCKETS / 32)
+#define FS_BOUND_LDS_BYTES (FS_BOUND_HIST * 4 + 64)
 template <bool FIN, bool PRE>
 __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev *envs, const int *ids, int flip) {
     static_assert(FS_GRID_BUCKETS == FS_BOUND_THREADS * 16 && FS_BOUND_MAX <= (1 << 14), "16 buckets per thread, 14-bit ranks");
     extern __shared__ __attribute__((aligned(16))) int bound_smem[];
-    int *hist = bound_smem, *wave_tot = bound_smem + FS_GRID_BUCKETS;
-    const int e = ids[blockIdx.x];
-    if (e < 0) return;  // retired slot
-    const FsEnvDev &E = envs[e];
+    int *hist = bound_smem, *wave_tot = bound_smem + FS_BOUND_HIST;
+    const FsEnvDev &E = envs[blockIdx.x];
+    if (E.slot_env < 0) return;  // retired slot
     const int n = E.n, t = threadIdx.x;
     const FsParams &p = E.p;
     const float h = p.dt / (float)p.numSubsteps;
     if (PRE) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) hist[t + k * FS_BOUND_THREADS] = 0;
+        for (int k = 0; k < 17; ++k)
+            if (t + k * FS_BOUND_THREADS < FS_BOUND_HIST) hist[t + k * FS_BOUND_THREADS] = 0;
         __syncthreads();
     }
     FsVec4 xpk[FS_BOUND_PPT];
@@ -197,7 +218,7 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
                 }
                 fs_st4o(E.xa, i, xp);
                 const int b = fs_stream_bucket((int)floorf(xp.x * inv_cell), (int)floorf(xp.y * inv_cell), (int)floorf(xp.z * inv_cell));
-                const int rank = atomicAdd(&hist[b], 1);
+                const int rank = atomicAdd(&hist[FS_BOUND_IDX(b)], 1);
                 xpk[k] = xp;
                 code[k] = b | (rank << 14);
             }
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
     int loc[16], sum = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        loc[k] = hist[t * 16 + k];
+        loc[k] = hist[FS_BOUND_IDX(t * 16 + k)];
         sum += loc[k];
     }
     const int lane = t & 63, wave = t >> 6;
@@ -225,16 +246,21 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
     for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        hist[t * 16 + k] = run;  // first slot of the bucket
+        hist[FS_BOUND_IDX(t * 16 + k)] = run;  // first slot of the bucket
         run += loc[k];
-        E.cell_fill[t * 16 + k] = run;  // what the search reads: the END of bucket b
     }
     __syncthreads();
+    // what the search reads: the END of bucket b = the first slot of bucket b + 1; written coalesced
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int b = t + k * FS_BOUND_THREADS;
+        E.cell_fill[b] = b + 1 < FS_GRID_BUCKETS ? hist[FS_BOUND_IDX(b + 1)] : n;
+    }
     // bucket-ordered copy of the predicted positions with the particle id in w (fs_k_grid_scatter)
 #pragma unroll
     for (int k = 0; k < FS_BOUND_PPT; ++k) {
         if (code[k] >= 0) {
-            const int slot = hist[code[k] & (FS_GRID_BUCKETS - 1)] + (code[k] >> 14);
+            const int slot = hist[FS_BOUND_IDX(code[k] & (FS_GRID_BUCKETS - 1))] + (code[k] >> 14);
             fs_st4o(E.xb, (unsigned)slot, FsVec4{xpk[k].x, xpk[k].y, xpk[k].z, __int_as_float(t + k * FS_BOUND_THREADS)});
         }
     }
@@ -251,8 +277,8 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
 __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    if (ids[by] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[by]];
+    const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
+    if (E.slot_env < 0) return;    // retired slot
     __shared__ uint32_t queue_s[FS_STREAM_FINDQ][FS_TILE];
     const int qs = bx * FS_TILE + threadIdx.x;
     const int n = E.n;
@@ -555,9 +581,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *env
     __shared__ FsVec4 sdict[256];
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    const int e = ids[by];
+    const FsEnvDev &E = envs[by];
+    const int e = E.slot_env;
     if (e < 0) return;  // retired slot
-    const FsEnvDev &E = envs[e];
     if (bx * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
     const int i = bx * FS_TILE + threadIdx.x;
     fs_iterate_particle_grid(E, shapes[e], i, i < E.n, sub, flip, sdict);
@@ -650,9 +676,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
                                                               int sub, int flip, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    const int e = ids[by];
+    const FsEnvDev &E = envs[by];
+    const int e = E.slot_env;
     if (e < 0) return;  // retired slot
-    const FsEnvDev &E = envs[e];
     const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     fs_iterate_particle_gridl<POSK>(E, shapes[e], i, sub, flip);
@@ -681,9 +707,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, co
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    const int e = ids[by];
+    const FsEnvDev &E = envs[by];
+    const int e = E.slot_env;
     if (e < 0) return;  // retired slot
-    const FsEnvDev &E = envs[e];
     const int i = bx * FS_TILE + threadIdx.x;
     if (bx * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
     fs_stage_sdict<CODED>(E, sdict);
@@ -696,9 +722,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *en
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    const int e = ids[by];
+    const FsEnvDev &E = envs[by];
+    const int e = E.slot_env;
     if (e < 0) return;  // retired slot
-    const FsEnvDev &E = envs[e];
     const int i = bx * FS_TILE + threadIdx.x;
     if (bx * FS_TILE >= E.n) return;
     fs_stage_sdict<CODED>(E, sdict);
@@ -709,8 +735,8 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *en
 __global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, const int *ids, int flip, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
-    if (ids[by] < 0) return;  // retired slot
-    const FsEnvDev &E = envs[ids[by]];
+    const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
+    if (E.slot_env < 0) return;    // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
     const FsParams &p = E.p;

@@ -79,7 +79,7 @@ struct FsEnvDev {
     const float *ell_k;
     // compact adjacency (fused kernel): dictionary of distinct (len, k) pairs + packed codes / neighbour ids
     int dict_size;           // 0 = unavailable
-    int pad0;
+    int slot_env;            // in a launch table (fs_k_slot_table): the episode this slot holds, -1 = retired; unused elsewhere
     const float *dict;       // [256][2]
     const uint32_t *code_w;  // [8][n]
     const uint32_t *nbr_w;   // [8][n]
