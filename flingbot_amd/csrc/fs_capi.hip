@@ -383,10 +383,10 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
             particles += (size_t)ctx->envs[id].host.n;
             grid64 = grid64 && ctx->envs[id].dev.g64_ok;
         }
-        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py, round 2): streaming 1.54 / 2.49 /
-        // 4.29 ms per step at 64 / 128 / 256 episodes against a flat 2.40-2.47 ms of the grid-64 fused kernel (~123 episodes);
-        // the dictionary-coded fused kernel (2.9 ms) crosses at ~136
-        if (particles < (size_t)(grid64 ? 124 : 136) * 4096) solver = FS_SOLVER_STREAM;
+        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py, end of round 2): streaming
+        // 1.40 / 2.29 / 4.01 ms per step at 64 / 128 / 256 episodes against a flat 2.39-2.46 ms of the grid-64 fused kernel
+        // (~136 episodes); the dictionary-coded fused kernel (2.9 ms) crosses at ~172
+        if (particles < (size_t)(grid64 ? 136 : 172) * 4096) solver = FS_SOLVER_STREAM;
     } else if (solver == FS_SOLVER_FUSED) {
         for (int id : ids)
             if (!fs_fused_supported(ctx, ctx->envs[id])) {

@@ -62,7 +62,9 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         gridl_form = gridl_form && ctx->envs[id].dev.gp_L_ok;
         gridl_posk = gridl_posk && ctx->envs[id].dev.gp_halvable;
     }
-    gridl_posk = gridl_posk && grid.x <= 1024u;  // one round of 4 waves per SIMD at most (see fs_k_iterate_gridl)
+    size_t launch_particles = 0;
+    for (int id : ids) launch_particles += (size_t)ctx->envs[id].host.n;
+    gridl_posk = gridl_posk && launch_particles <= (size_t)4 * 1024 * 64;  // one round of 4 waves per SIMD at most (see fs_k_iterate_gridl)
     hipStream_t st = ctx->stream;
     ctx->last_form = gridl_form ? FS_FORM_STREAM_GRIDL
                      : grid_form ? FS_FORM_STREAM_GRID

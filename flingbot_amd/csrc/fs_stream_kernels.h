@@ -668,7 +668,7 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
 
 // POSK: every episode of the launch has positive stiffnesses only (no tethers; FsEnvDev::gp_halvable, decided by the host).
 // 10 % fewer VALU instructions per spring but 106 instead of 96 VGPRs (4 instead of 5 waves per SIMD; forcing 5 spills), so
-// the launcher takes it only for launches of at most one round of 4 waves per SIMD (<= 1024 workgroups), where occupancy
+// the launcher takes it only for launches of at most one round of 4 waves per SIMD (<= 262144 particles), where occupancy
 // beyond 4 buys nothing: 64x64 cloths x 1 / 8 / 32 / 64 episodes 0.913 / 1.054 / 1.133 / 1.484 -> 0.880 / 1.026 / 1.099 / 1.454 ms
 // per step; larger launches measured slower with it and keep the general form.
 template <bool POSK>

@@ -8,7 +8,7 @@ rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out/eval_summary
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o ev -- python3 $ROOT/scripts/eval_async_timing.py 64 32 3 > $OUT/stats.log 2>&1
 cd $ROOT
-grep -v amdgpu.ids $OUT/stats.log | tail -3 | tee $ROOT/gpurun_out/eval_summary/r02_eval_run.txt
+grep -A1 "async slots" $OUT/stats.log | tee $ROOT/gpurun_out/eval_summary/r02_eval_run.txt
 python3 - $OUT/stats $ROOT/gpurun_out/eval_summary/r02_eval_kernel_stats.csv <<'PY'
 import csv, os, sqlite3, sys
 db = [os.path.join(r, f) for r, _, fs in os.walk(sys.argv[1]) for f in fs if f.endswith(".db")][0]
