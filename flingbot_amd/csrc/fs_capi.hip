@@ -47,6 +47,11 @@ fs_ctx::~fs_ctx() {
     if (render_scratch) (void)hipFree(render_scratch);
     if (loop_scratch) (void)hipFree(loop_scratch);
     if (d_coverage) (void)hipFree(d_coverage);
+    for (int g = 0; g < FS_MAX_STREAM_GROUPS; ++g) {
+        if (aux_streams[g]) { (void)hipStreamSynchronize(aux_streams[g]); (void)hipStreamDestroy(aux_streams[g]); }
+        if (aux_events[g]) (void)hipEventDestroy(aux_events[g]);
+    }
+    if (fork_event) (void)hipEventDestroy(fork_event);
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
     if (stream) (void)hipStreamDestroy(stream);
@@ -132,6 +137,12 @@ extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
                              : solver);
     return FS_OK;
 }
+extern "C" int fs_set_stream_groups(fs_ctx *ctx, int groups) {
+    if (!ctx || groups < 0 || groups > FS_MAX_STREAM_GROUPS) { fs_set_error("fs_set_stream_groups: 0 (default) .. 4"); return FS_ERR_ARG; }
+    ctx->stream_groups = groups;
+    return FS_OK;
+}
+extern "C" int fs_last_stream_groups(const fs_ctx *ctx) { return ctx ? ctx->last_stream_groups : FS_ERR_ARG; }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
 extern "C" int fs_last_kernel_form(const fs_ctx *ctx) { return ctx ? ctx->last_form : FS_ERR_ARG; }
 extern "C" void *fs_stream(fs_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -383,10 +394,10 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
             particles += (size_t)ctx->envs[id].host.n;
             grid64 = grid64 && ctx->envs[id].dev.g64_ok;
         }
-        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py, end of round 2): streaming
-        // 1.40 / 2.29 / 4.01 ms per step at 64 / 128 / 256 episodes against a flat 2.39-2.46 ms of the grid-64 fused kernel
-        // (~136 episodes); the dictionary-coded fused kernel (2.9 ms) crosses at ~172
-        if (particles < (size_t)(grid64 ? 136 : 172) * 4096) solver = FS_SOLVER_STREAM;
+        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py, end of round 2, concurrent
+        // chains): streaming 1.20 / 1.74 / 3.46 ms per step at 64 / 128 / 256 episodes against a flat 2.39-2.46 ms of the
+        // grid-64 fused kernel (~176 episodes); the dictionary-coded fused kernel (2.9 ms) crosses at ~214
+        if (particles < (size_t)(grid64 ? 176 : 214) * 4096) solver = FS_SOLVER_STREAM;
     } else if (solver == FS_SOLVER_FUSED) {
         for (int id : ids)
             if (!fs_fused_supported(ctx, ctx->envs[id])) {

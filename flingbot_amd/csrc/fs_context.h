@@ -66,6 +66,8 @@ struct FsEnv {
     FsCamera cam;
 };
 
+#define FS_MAX_STREAM_GROUPS 4
+
 struct fs_ctx {
     int device = 0;
     int n_envs = 0;
@@ -81,6 +83,12 @@ struct fs_ctx {
     int last_form = 0;                 // FS_FORM_* of the most recent solver launch (fs_last_kernel_form)
     long long last_movep_steps = 0;    // simulation steps of the most recent fs_movep* call, all episodes (fs_last_movep_steps)
     hipStream_t stream = nullptr;
+    // concurrent chains of the streaming back-end (fs_solver.hip): streams / join events per group, the fork event
+    hipStream_t aux_streams[FS_MAX_STREAM_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t aux_events[FS_MAX_STREAM_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    int stream_groups = 0;        // > 0: forced number of chains (fs_set_stream_groups); 0: the default of fs_solver.hip
+    int last_stream_groups = 1;   // chains of the most recent streaming launch
     std::vector<FsEnv> envs;
     FsEnvDev *d_envs = nullptr;       // [n_envs]
     FsShapesDev *d_shapes = nullptr;  // [n_envs]

@@ -7,10 +7,27 @@
 #include "fs_fused_grid_kernel.h"
 #include "fs_stream_kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 #define HIP_TRY(call)                                     \
     do {                                                  \
         if (!fs_hip_ok((call), #call)) return FS_ERR_HIP; \
     } while (0)
+
+// number of concurrent chains of a streaming launch (0 = FLINGSIM_STREAM_GROUPS unset: the measured default below)
+static int fs_default_stream_groups(int ne, size_t particles) {
+    static const int env_groups = [] { const char *v = getenv("FLINGSIM_STREAM_GROUPS"); return v ? atoi(v) : 0; }();
+    if (env_groups > 0) return env_groups;
+    // measured on crumpled 64x64 cloths (scripts/boundary_timing.py with FLINGSIM_STREAM_GROUPS = 1 / 2 / 3 / 4, ms per step):
+    //   32 episodes 1.03 / 1.04 / 1.97 / 1.89   64: 1.39 / 1.19 / 1.36 / 2.11   128: 2.27 / 1.86 / 1.74 / 2.73   256: 4.36 / 3.70 / 3.57 / 4.34
+    // -- nothing to hide below ~40 x 4096 particles (the launch is at its latency floor), two chains from there, three
+    // from ~112 x 4096; four chains (five queues with the context's own) are slower everywhere
+    (void)ne;
+    if (particles >= (size_t)112 * 4096) return 3;
+    if (particles >= (size_t)40 * 4096) return 2;
+    return 1;
+}
 
 static int upload_ids(fs_ctx *ctx, const std::vector<int> &ids) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // h_ids may still be read by an earlier copy
@@ -71,7 +88,6 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
                                  : (eager ? FS_FORM_STREAM_EAGER : (coded ? FS_FORM_STREAM_CODED : FS_FORM_STREAM_ELL));
     // slot-indexed copies of the listed episodes' descriptors: one scalar indirection less in front of every kernel below
     hipLaunchKernelGGL(fs_k_slot_table, dim3((unsigned)ne), dim3(64), 0, st, ctx->d_envs, d_ids, ctx->d_slot_envs);
-    const FsEnvDev *tab = ctx->d_slot_envs;
     // substep boundaries in one launch each (finalize + predict + bucket sort, fs_k_boundary) when every cloth fits it
     // (one workgroup per episode: launches of fewer than 16 episodes are 2-3 % faster with the four small kernels spread
     // over the chip -- measured, scripts/boundary_timing.py -- and keep them unless FS_SOLVER_STREAM_MERGED asks otherwise)
@@ -82,30 +98,91 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
         ctx->bound_attr_set = true;
     }
-    const dim3 bgrid((unsigned)ne), bblock(FS_BOUND_THREADS);
+    // Concurrent chains.  A frame is 129 DEPENDENT launches, each about one wave's critical path long whatever the amount of
+    // work, so a launch list that cannot fill the chip is split into `groups` slot ranges (multiples of 8:
+    // the XCD mapping of fs_stream_tile) whose chains run on streams of their own: while one chain's kernel drains and its
+    // successor starts up, the other chains' kernels compute.  The chains are launched interleaved from this thread, fork
+    // from and join into the context's stream through events; episodes are independent, results are bit-identical.
+    int groups = ctx->stream_groups > 0 ? ctx->stream_groups : fs_default_stream_groups(ne, launch_particles);
+    if (groups > FS_MAX_STREAM_GROUPS) groups = FS_MAX_STREAM_GROUPS;
+    if (groups > (ne + 7) / 8) groups = (ne + 7) / 8;
+    if (groups < 1) groups = 1;
+    struct Chain { int first, count, gx; dim3 grid; hipStream_t st; };
+    Chain chain[FS_MAX_STREAM_GROUPS];
+    {
+        const int blocks8 = (ne + 7) / 8;
+        int at = 0;
+        for (int g = 0; g < groups; ++g) {
+            const int b8 = blocks8 / groups + (g < blocks8 % groups ? 1 : 0);
+            Chain &c = chain[g];
+            c.first = at * 8;
+            c.count = (at + b8) * 8 <= ne ? b8 * 8 : ne - at * 8;
+            at += b8;
+            int mx = 0;
+            for (int k = 0; k < c.count; ++k) mx = std::max(mx, ctx->envs[ids[c.first + k]].host.n);
+            c.gx = (mx + FS_TILE - 1) / FS_TILE;
+            c.grid = dim3((unsigned)(((c.count + 7) / 8) * 8) * (unsigned)c.gx);
+            c.st = st;
+        }
+    }
+    if (groups > 1) {
+        for (int g = 0; g < groups; ++g) {
+            if (!ctx->aux_streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_streams[g], hipStreamNonBlocking));
+            if (!ctx->aux_events[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->aux_events[g], hipEventDisableTiming));
+            chain[g].st = ctx->aux_streams[g];
+        }
+        if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ctx->fork_event, st));
+        for (int g = 0; g < groups; ++g) HIP_TRY(hipStreamWaitEvent(chain[g].st, ctx->fork_event, 0));
+    }
+    auto iter_kernel = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
+    if (grid_form) iter_kernel = fs_k_iterate_grid;
+    if (gridl_form) iter_kernel = gridl_posk ? fs_k_iterate_gridl<true> : fs_k_iterate_gridl<false>;
+    const int flip_end = iters & 1;
+    // the frame's launch sequence, issued for every chain in turn (interleaved from this thread: one host thread per chain was
+    // measured too and is no faster -- the host is not the limit at two or three chains)
+    enum { K_BOUND_FIRST, K_BOUND_MID, K_BOUND_LAST, K_PREDICT, K_SCAN, K_SCATTER, K_FIND, K_ITER, K_FINALIZE };
+    auto launch = [&](int kind, int sub, int flip) {
+        for (int g = 0; g < groups; ++g) {
+            const Chain &c = chain[g];
+            const FsEnvDev *tab = ctx->d_slot_envs + c.first;
+            const int *cids = d_ids + c.first;
+            const dim3 bgrid((unsigned)c.count), bblock(FS_BOUND_THREADS);
+            switch (kind) {
+                case K_BOUND_FIRST: hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, 0); break;
+                case K_BOUND_MID: hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip); break;
+                case K_BOUND_LAST: hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip); break;
+                case K_PREDICT: hipLaunchKernelGGL(fs_k_predict, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
+                case K_SCAN: hipLaunchKernelGGL(fs_k_grid_scan, bgrid, dim3(1024), 0, c.st, tab, cids); break;
+                case K_SCATTER: hipLaunchKernelGGL(fs_k_grid_scatter, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
+                case K_FIND: hipLaunchKernelGGL(fs_k_find_neighbors, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
+                case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_shapes, cids, sub, flip, c.gx, c.count); break;
+                default: hipLaunchKernelGGL(fs_k_finalize, c.grid, block, 0, c.st, tab, cids, flip, c.gx, c.count); break;
+            }
+        }
+    };
     for (int f = 0; f < n_steps; ++f) {
         for (int sub = 0; sub < substeps; ++sub) {
             if (merged) {
-                if (f == 0 && sub == 0)
-                    hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, tab, d_ids, 0);
-                else  // the finalize of the previous substep (also the previous frame's last one) rides along
-                    hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, tab, d_ids, iters & 1);
+                // (K_BOUND_MID: the finalize of the previous substep -- also the previous frame's last one -- rides along)
+                launch(f == 0 && sub == 0 ? K_BOUND_FIRST : K_BOUND_MID, sub, flip_end);
             } else {
-                hipLaunchKernelGGL(fs_k_predict, grid, block, 0, st, tab, d_ids, gx, ne);
-                hipLaunchKernelGGL(fs_k_grid_scan, dim3((unsigned)ids.size()), dim3(1024), 0, st, tab, d_ids);
-                hipLaunchKernelGGL(fs_k_grid_scatter, grid, block, 0, st, tab, d_ids, gx, ne);
+                launch(K_PREDICT, sub, 0);
+                launch(K_SCAN, sub, 0);
+                launch(K_SCATTER, sub, 0);
             }
-            hipLaunchKernelGGL(fs_k_find_neighbors, grid, block, 0, st, tab, d_ids, gx, ne);
-            for (int it = 0; it < iters; ++it) {
-                auto kern = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
-                if (grid_form) kern = fs_k_iterate_grid;
-                if (gridl_form) kern = gridl_posk ? fs_k_iterate_gridl<true> : fs_k_iterate_gridl<false>;
-                hipLaunchKernelGGL(kern, grid, block, 0, st, tab, ctx->d_shapes, d_ids, sub, it & 1, gx, ne);
-            }
-            if (!merged) hipLaunchKernelGGL(fs_k_finalize, grid, block, 0, st, tab, d_ids, iters & 1, gx, ne);
+            launch(K_FIND, sub, 0);
+            for (int it = 0; it < iters; ++it) launch(K_ITER, sub, it & 1);
+            if (!merged) launch(K_FINALIZE, sub, flip_end);
         }
     }
-    if (merged) hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, st, tab, d_ids, iters & 1);
+    if (merged) launch(K_BOUND_LAST, 0, flip_end);
+    if (groups > 1)
+        for (int g = 0; g < groups; ++g) {
+            HIP_TRY(hipEventRecord(ctx->aux_events[g], chain[g].st));
+            HIP_TRY(hipStreamWaitEvent(st, ctx->aux_events[g], 0));
+        }
+    ctx->last_stream_groups = groups;
     HIP_TRY(hipGetLastError());
     return FS_OK;
 }

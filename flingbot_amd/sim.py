@@ -59,6 +59,8 @@ def load_library(build_if_missing=True):
         "fs_set_solver": (ci, [vp, ci]),
         "fs_get_solver": (ci, [vp]),
         "fs_last_kernel_form": (ci, [vp]),
+        "fs_set_stream_groups": (ci, [vp, ci]),
+        "fs_last_stream_groups": (ci, [vp]),
         "fs_set_scene": (ci, [vp, ci, fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
         "fs_step": (ci, [vp, ci, ci]),
         "fs_step_list": (ci, [vp, ci, ip, ci]),
@@ -190,6 +192,13 @@ class FlingSim:
     def last_kernel_form(self):
         """FS_FORM_* of the most recent solver launch (white box for the parity tests)."""
         return self._ck(self.lib.fs_last_kernel_form(self.h))
+
+    def set_stream_groups(self, groups):
+        """Concurrent launch chains of the streaming back-end: 0 = measured default, 1..4 = forced (fs_set_stream_groups)."""
+        self._ck(self.lib.fs_set_stream_groups(self.h, int(groups)))
+
+    def last_stream_groups(self):
+        return self._ck(self.lib.fs_last_stream_groups(self.h))
 
     def env(self, i=0):
         return EnvView(self, i)

@@ -138,6 +138,12 @@ int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
 #define FS_FORM_STREAM_GRIDL 9   /* fs_k_iterate_gridl: canonical grid cloths, rest lengths from the per-particle table */
 #define FS_FORM_FUSED_GRID64 8   /* fs_k_fused_grid64: 64-wide grid cloths, packed two-particle springs, no adjacency */
 int fs_last_kernel_form(const fs_ctx *ctx);
+/* Streaming back-end: a launch list that cannot fill the chip is split into `groups` slot ranges whose launch chains run
+   concurrently on streams of their own (episodes are independent; results do not change).  0 = the library's measured
+   default (1 below ~40 x 4096 particles, 2 from there, 3 from ~112 x 4096), 1..4 = forced.  fs_last_stream_groups: the
+   number of chains of the most recent streaming launch (white box for the tests). */
+int fs_set_stream_groups(fs_ctx *ctx, int groups);
+int fs_last_stream_groups(const fs_ctx *ctx);
 /* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */
 void *fs_device_positions(fs_ctx *ctx, int env);
 

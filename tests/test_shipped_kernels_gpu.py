@@ -64,14 +64,17 @@ def _assert_bits(ctx, e, orc, what):
         f"{what}: velocities not bit-exact (max abs diff {np.abs(vh - vo).max():.3e})"
 
 
-def _bench_batch(n_envs, solver, steps, sample, expect_form):
+def _bench_batch(n_envs, solver, steps, sample, expect_form, groups=0, expect_groups=None):
     from flingbot_amd import sim as fsim
 
     ctx = fsim.FlingSim(n_envs=n_envs, solver=solver)
+    ctx.set_stream_groups(groups)
     for e in range(n_envs):
         bench.setup_episode(ctx.env(e), seed=e)  # exactly the episodes bench.py times
     ctx.step(steps)  # one launch (fused) / one launch sequence (streaming) for all episodes
     assert ctx.last_kernel_form() == expect_form, ctx.last_kernel_form()
+    if expect_groups is not None:
+        assert ctx.last_stream_groups() == expect_groups, ctx.last_stream_groups()
     orcs = _oracle_runs([lambda o, s=s: bench.setup_episode(o, seed=s) for s in sample], steps)
     for s, o in zip(sample, orcs):
         _assert_bits(ctx, s, o, f"{n_envs} episodes, form {expect_form}, episode {s}")
@@ -245,8 +248,22 @@ def test_streaming_64_episode_launch_bit_exact(gpu_required, solver, form):
     its finalize + predict form)."""
     from flingbot_amd import sim as fsim
 
-    contacts = _bench_batch(64, solver, 40, [0, 1, 31, 63], getattr(fsim, form))
+    # 64 x 4096 particles: the launch list is split into two concurrent chains (slots 0..31 and 32..63)
+    contacts = _bench_batch(64, solver, 40, [0, 1, 31, 32, 63], getattr(fsim, form), expect_groups=2)
     assert contacts > 50
+
+
+@pytest.mark.parametrize("n_envs,groups", [(20, 3), (64, 1), (64, 4), (130, 0)])
+def test_streaming_concurrent_chains_bit_exact(gpu_required, n_envs, groups):
+    """The streaming launch list split into 1..4 slot ranges whose launch chains run concurrently on their own streams
+    (fs_set_stream_groups; 0 = the default, three chains at 130 x 4096 particles): slot ranges of 8 / 8 / 4 episodes,
+    the unsplit launch, four ranges, and ranges that end inside the last block of eight -- first / boundary / last episodes
+    equal the oracle."""
+    from flingbot_amd import sim as fsim
+
+    sample = sorted({0, 7, 8, 15, 16, n_envs // 2, n_envs - 1} & set(range(n_envs)))
+    _bench_batch(n_envs, fsim.FS_SOLVER_STREAM, 30, sample, fsim.FS_FORM_STREAM_GRIDL, groups=groups,
+                 expect_groups=groups if groups else 3)
 
 
 def test_streaming_small_and_large_launch_forms_bit_exact(gpu_required):
