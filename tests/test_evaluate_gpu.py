@@ -100,17 +100,20 @@ def _policy(env, seed=1):
     from flingbot_amd import nets
 
     torch.manual_seed(seed)
-    return nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+    return nets.MaximumValuePolicy(action_primitives=list(env.actions), num_rotations=12, scale_factors=list(env.scale_factors),
                                    obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
                                    depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
                                    value_expl_decay=1.0, device="cuda:0")
 
 
-def test_async_task_loop_equals_lockstep_loop(gpu_required):
+@pytest.mark.parametrize("actions", [("fling",), ("fling", "stretchdrag", "drag", "place")])
+def test_async_task_loop_equals_lockstep_loop(gpu_required, actions):
     """evaluate.run_tasks -- every slot runs reset / act / step on its own and pulls the next task when its episode ends
     (run_sim.py:46-60 with utils.step_env's ray.wait asynchrony, utils.py:394-418) -- against evaluate.run_episodes, the
     lock-step loop, on the same six generated tasks: once with one slot per task and once with TWO slots for the six tasks
-    (continuous batching: tasks land in slots the lock-step run never used for them).  Coverage after every step, episode
+    (continuous batching: tasks land in slots the lock-step run never used for them); with the fling-only policy of the
+    reference's released model and with all four primitives in the action space (each episode then runs whichever program
+    its own arg-max picked, side by side).  Coverage after every step, episode
     lengths, action counts and the simulation-step total are identical."""
     from flingbot_amd import sim as fsim, tasks as ftasks
     from flingbot_amd.env import BatchedFlingEnv
@@ -125,7 +128,7 @@ def test_async_task_loop_equals_lockstep_loop(gpu_required):
     results = []
     for mode, slots in (("lockstep", n), ("async", n), ("async", 2)):
         ctx = fsim.FlingSim(n_envs=slots, solver=0)
-        env = BatchedFlingEnv(ctx, image_dim=128, episode_length=3)
+        env = BatchedFlingEnv(ctx, action_primitives=actions, image_dim=128, episode_length=3)
         policy = _policy(env)
         stats = (run_episodes if mode == "lockstep" else run_tasks)(policy, env, tasks)
         assert all(net._hip is not None for net in policy.value_nets.values())

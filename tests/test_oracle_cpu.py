@@ -756,6 +756,63 @@ def test_env_step_bookkeeping_reproduces_reference_golden():
                     lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
 
 
+def test_scheduler_requests_and_services_on_the_oracle():
+    """schedule.run_programs itself, no GPU: programs that mix plain steps, wait_until_stable with DIFFERENT tolerances and
+    budgets, a movep and a host-side service, against the same operations done one episode after the other."""
+    from fling_helpers import OracleBatch, load_fling_golden
+    from flingbot_amd import schedule as sch
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+
+    def lifted(sim, n):
+        for e in range(n):
+            p = sim.sims[e].get_positions().reshape(-1, 4).copy()
+            p[:, 1] += np.float32(0.05 + 0.02 * e)
+            sim.sims[e].set_positions(p.ravel())
+
+    n = 3
+    a, b = OracleBatch(n, g["scene_params"], g["init_pos"]), OracleBatch(n, g["scene_params"], g["init_pos"])
+    lifted(a, n); lifted(b, n)
+    prim = FlingPrimitives(a, range(n))
+    seen = []
+
+    def program(ep, k):
+        yield ("step", 3 + k)
+        got = yield ("tag", k)                       # a service of the caller's
+        assert got == 10 * k
+        yield from sch._movep(ep, [[0.1 * k, 0.2, 0.0], [-0.1, 0.2, 0.05 * k]], speed=2e-2)
+        res = yield ("wait", 20 + 5 * k, 0.3 / (k + 1))
+        stats = yield ("stats",)
+        return res, float(stats[1])
+
+    def tag(reqs):
+        seen.append(sorted(e for e, _ in reqs))
+        return [10 * args[0] for _, args in reqs]
+
+    out = sch.run_programs(prim, {e: program(sch.Episode(prim, e), e) for e in range(n)}, cap_min=2, cap=5, services={"tag": tag})
+    assert sum(len(s) for s in seen) == n
+    steps = 0
+    for e in range(n):  # the same, sequentially, on the second batch
+        b.step_list([e], 3 + e)
+        steps += 3 + e
+        b.movep([e], np.array([[[0.1 * e, 0.2, 0.0], [-0.1, 0.2, 0.05 * e]]]), [[False, False]], speed=2e-2)
+        steps += b.last_movep_steps
+        stable, st = b.wait_until_stable([e], max_steps=20 + 5 * e, tolerance=0.3 / (e + 1))
+        steps += int(st[0])
+        assert out[e][0] == (bool(stable[0]), int(st[0])), e
+        assert out[e][1] == float(b.cloth_stats([e])[0, 1])
+        assert np.array_equal(a.get_positions(e).view(np.uint32), b.get_positions(e).view(np.uint32)), e
+        assert np.array_equal(np.asarray(a.get_shape_states(e), np.float32).view(np.uint32),
+                              np.asarray(b.get_shape_states(e), np.float32).view(np.uint32)), e
+    assert prim.sim_steps == steps and len({out[e][0][1] for e in range(n)}) > 1
+    def bad():
+        yield ("nonsense",)
+
+    with pytest.raises(ValueError):
+        sch.run_programs(prim, {0: bad()})
+
+
 def test_env_step_bookkeeping_scheduled_reproduces_reference_golden():
     """The same golden with BatchedFlingEnv's default execution: action handler + postaction of every episode as one
     program each, scheduled together (flingbot_amd/schedule.py)."""
