@@ -811,13 +811,3 @@ def test_scheduler_requests_and_services_on_the_oracle():
 
     with pytest.raises(ValueError):
         sch.run_programs(prim, {0: bad()})
-
-
-def test_env_step_bookkeeping_scheduled_reproduces_reference_golden():
-    """The same golden with BatchedFlingEnv's default execution: action handler + postaction of every episode as one
-    program each, scheduled together (flingbot_amd/schedule.py)."""
-    from fling_helpers import OracleBatch, load_step_golden, run_step_golden
-
-    g = load_step_golden()
-    run_step_golden(lambda n: OracleBatch(n, g["scene_params"], g["init_pos"], pickers=False),
-                    lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k), scheduled=True)
