@@ -129,13 +129,14 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32):
     }
 
 
-def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=run_episodes, **kwargs):
+def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=None, **kwargs):
     """BASELINE.json configs[3] for the evaluation loop: global episode g runs on rank g // episodes_per_rank (one process
     per GPU, launched with torch.distributed.run); the only exchange is the all_gather of the per-episode initial / final
     coverages at the end (RCCL over xGMI, 4 bytes per episode).  Returns this rank's statistics plus `all_init_coverage`
     / `all_final_coverage` ordered by global episode id."""
     from . import distributed as fdist
 
+    runner = run_tasks if runner is None else runner  # (run_tasks streams the rank's tasks through its GPU context's slots)
     rank, _, world = fdist.init_from_env()
     mine = [tasks[g] for g in fdist.episode_range(rank, episodes_per_rank)]
     stats = runner(policy, env, mine, **kwargs)
