@@ -363,7 +363,8 @@ def run_rank(args):
             out["cpu_baseline"] = cpu_baseline(args.preroll + args.warmup)
         if world == 1 and not args.no_secondary:
             out["perception"] = perception_leg(torch.device("cuda", local_rank))
-            out["eval_loop"] = eval_loop_leg(local_rank)
+            if not args.no_eval_loop:
+                out["eval_loop"] = eval_loop_leg(local_rank)
         print(json.dumps(out), flush=True)
     fdist.barrier()
     if world > 1:
@@ -440,6 +441,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: no 64-episode figure, no perception leg")
+    ap.add_argument("--no-eval-loop", action="store_true", help="skip the evaluation-loop leg (configs[4], ~50 s)")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")

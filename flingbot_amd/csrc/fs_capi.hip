@@ -263,6 +263,7 @@ static int phase_find_mode(const int *phase, int n, int restnear_ok) {
 }
 
 static int push_env_desc(fs_ctx *ctx, int env) {
+    ctx->desc_epoch++;  // the streaming back-end's launch table (fs_k_slot_table) is stale now
     HIP_TRY(hipMemcpyAsync(ctx->d_envs + env, &ctx->envs[env].dev, sizeof(FsEnvDev), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return FS_OK;

@@ -95,6 +95,11 @@ struct fs_ctx {
     FsEnvDev *d_slot_envs = nullptr;  // [n_envs] launch table of the streaming kernels (fs_k_slot_table)
     int *d_ids = nullptr;             // [n_envs] launch list
     int *h_ids = nullptr;             // pinned
+    std::vector<int> uploaded_ids;    // what d_ids holds (upload_ids skips an identical list)
+    std::vector<int> table_ids;       // the list d_slot_envs was built for
+    bool d_ids_valid = false;
+    unsigned long long desc_epoch = 0;   // bumped whenever a descriptor in d_envs is rewritten
+    unsigned long long table_epoch = ~0ull;  // desc_epoch the launch table in d_slot_envs was built at, for uploaded_ids (~0: none)
     void *h_stage = nullptr;          // pinned staging for accessors
     size_t h_stage_bytes = 0;
     std::vector<std::weak_ptr<FsTopologyDev>> topo_cache;

@@ -141,6 +141,7 @@ static int upload_list(fs_ctx *ctx, int n, const int *envs, int **d_ids) {
         }
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // h_ids may still be read by an earlier copy
     for (int k = 0; k < n; ++k) ctx->h_ids[k] = envs[k];
+    ctx->d_ids_valid = false;  // (the solver's upload_ids caches what d_ids holds)
     HIP_TRY(hipMemcpyAsync(ctx->d_ids, ctx->h_ids, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
     *d_ids = ctx->d_ids;
     return FS_OK;

@@ -19,20 +19,26 @@
 static int fs_default_stream_groups(int ne, size_t particles) {
     static const int env_groups = [] { const char *v = getenv("FLINGSIM_STREAM_GROUPS"); return v ? atoi(v) : 0; }();
     if (env_groups > 0) return env_groups;
-    // measured on crumpled 64x64 cloths (scripts/boundary_timing.py with FLINGSIM_STREAM_GROUPS = 1 / 2 / 3 / 4, ms per step):
-    //   32 episodes 1.03 / 1.04 / 1.97 / 1.89   64: 1.39 / 1.19 / 1.36 / 2.11   128: 2.27 / 1.86 / 1.74 / 2.73   256: 4.36 / 3.70 / 3.57 / 4.34
-    // -- nothing to hide below ~40 x 4096 particles (the launch is at its latency floor), two chains from there, three
-    // from ~112 x 4096; four chains (five queues with the context's own) are slower everywhere
+    // measured on crumpled 64x64 cloths (scripts/boundary_timing.py with FLINGSIM_STREAM_GROUPS = 1 / 2 / 3, ms per step; chain 0
+    // on the context's own stream):  32 episodes 1.03 / 0.99 / 1.09   64: 1.39 / 1.14 / 1.18   128: 2.25 / 1.76 / 1.74   256: 4.16 / 3.51 / 3.59
+    // -- two chains from ~24 x 4096 particles on; a third hardware queue gains nothing, a fourth (and a fifth: the first
+    // version kept the context's stream idle next to the chains') makes everything slower
     (void)ne;
-    if (particles >= (size_t)112 * 4096) return 3;
-    if (particles >= (size_t)40 * 4096) return 2;
+    if (particles >= (size_t)24 * 4096) return 2;
     return 1;
 }
 
 static int upload_ids(fs_ctx *ctx, const std::vector<int> &ids) {
+    // the same list as last time (a loop of fs_step calls): ctx->d_ids still holds it -- nothing on the device writes there --
+    // and skipping the upload skips the synchronisation below, so the host can queue the next frame while this one runs
+    static const bool no_cache = getenv("FLINGSIM_NO_ID_CACHE") != nullptr;  // (experiment switch)
+    if (!no_cache && ctx->d_ids_valid && ctx->uploaded_ids == ids) return FS_OK;
+    ctx->d_ids_valid = false;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // h_ids may still be read by an earlier copy
     for (size_t k = 0; k < ids.size(); ++k) ctx->h_ids[k] = ids[k];
     HIP_TRY(hipMemcpyAsync(ctx->d_ids, ctx->h_ids, sizeof(int) * ids.size(), hipMemcpyHostToDevice, ctx->stream));
+    ctx->uploaded_ids = ids;
+    ctx->d_ids_valid = true;
     return FS_OK;
 }
 
@@ -87,7 +93,14 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
                      : grid_form ? FS_FORM_STREAM_GRID
                                  : (eager ? FS_FORM_STREAM_EAGER : (coded ? FS_FORM_STREAM_CODED : FS_FORM_STREAM_ELL));
     // slot-indexed copies of the listed episodes' descriptors: one scalar indirection less in front of every kernel below
-    hipLaunchKernelGGL(fs_k_slot_table, dim3((unsigned)ne), dim3(64), 0, st, ctx->d_envs, d_ids, ctx->d_slot_envs);
+    // (built once for a loop of calls with the context's own, unchanged list and unchanged descriptors; a caller's device
+    // list -- fs_advance, fs_wait_until_stable: slots retire on the device -- rebuilds it every call)
+    const bool table_ok = !d_ids_in && ctx->table_epoch == ctx->desc_epoch && ctx->table_ids == ids;
+    if (!table_ok) {
+        hipLaunchKernelGGL(fs_k_slot_table, dim3((unsigned)ne), dim3(64), 0, st, ctx->d_envs, d_ids, ctx->d_slot_envs);
+        ctx->table_epoch = d_ids_in ? ~0ull : ctx->desc_epoch;
+        if (!d_ids_in) ctx->table_ids = ids;
+    }
     // substep boundaries in one launch each (finalize + predict + bucket sort, fs_k_boundary) when every cloth fits it
     // (one workgroup per episode: launches of fewer than 16 episodes are 2-3 % faster with the four small kernels spread
     // over the chip -- measured, scripts/boundary_timing.py -- and keep them unless FS_SOLVER_STREAM_MERGED asks otherwise)
@@ -125,15 +138,15 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             c.st = st;
         }
     }
-    if (groups > 1) {
-        for (int g = 0; g < groups; ++g) {
+    if (groups > 1) {  // chain 0 stays on the context's stream, the others fork from it
+        for (int g = 1; g < groups; ++g) {
             if (!ctx->aux_streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_streams[g], hipStreamNonBlocking));
             if (!ctx->aux_events[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->aux_events[g], hipEventDisableTiming));
             chain[g].st = ctx->aux_streams[g];
         }
         if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->fork_event, st));
-        for (int g = 0; g < groups; ++g) HIP_TRY(hipStreamWaitEvent(chain[g].st, ctx->fork_event, 0));
+        for (int g = 1; g < groups; ++g) HIP_TRY(hipStreamWaitEvent(chain[g].st, ctx->fork_event, 0));
     }
     auto iter_kernel = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
     if (grid_form) iter_kernel = fs_k_iterate_grid;
@@ -177,11 +190,10 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         }
     }
     if (merged) launch(K_BOUND_LAST, 0, flip_end);
-    if (groups > 1)
-        for (int g = 0; g < groups; ++g) {
-            HIP_TRY(hipEventRecord(ctx->aux_events[g], chain[g].st));
-            HIP_TRY(hipStreamWaitEvent(st, ctx->aux_events[g], 0));
-        }
+    for (int g = 1; g < groups; ++g) {
+        HIP_TRY(hipEventRecord(ctx->aux_events[g], chain[g].st));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_events[g], 0));
+    }
     ctx->last_stream_groups = groups;
     HIP_TRY(hipGetLastError());
     return FS_OK;

@@ -140,7 +140,7 @@ int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
 int fs_last_kernel_form(const fs_ctx *ctx);
 /* Streaming back-end: a launch list that cannot fill the chip is split into `groups` slot ranges whose launch chains run
    concurrently on streams of their own (episodes are independent; results do not change).  0 = the library's measured
-   default (1 below ~40 x 4096 particles, 2 from there, 3 from ~112 x 4096), 1..4 = forced.  fs_last_stream_groups: the
+   default (1 below ~24 x 4096 particles, 2 from there), 1..4 = forced.  fs_last_stream_groups: the
    number of chains of the most recent streaming launch (white box for the tests). */
 int fs_set_stream_groups(fs_ctx *ctx, int groups);
 int fs_last_stream_groups(const fs_ctx *ctx);
