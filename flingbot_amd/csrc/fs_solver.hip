@@ -31,8 +31,7 @@ static int fs_default_stream_groups(int ne, size_t particles) {
 static int upload_ids(fs_ctx *ctx, const std::vector<int> &ids) {
     // the same list as last time (a loop of fs_step calls): ctx->d_ids still holds it -- nothing on the device writes there --
     // and skipping the upload skips the synchronisation below, so the host can queue the next frame while this one runs
-    static const bool no_cache = getenv("FLINGSIM_NO_ID_CACHE") != nullptr;  // (experiment switch)
-    if (!no_cache && ctx->d_ids_valid && ctx->uploaded_ids == ids) return FS_OK;
+    if (ctx->d_ids_valid && ctx->uploaded_ids == ids) return FS_OK;
     ctx->d_ids_valid = false;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // h_ids may still be read by an earlier copy
     for (size_t k = 0; k < ids.size(); ++k) ctx->h_ids[k] = ids[k];
