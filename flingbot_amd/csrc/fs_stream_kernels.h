@@ -684,6 +684,14 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
     fs_iterate_particle_gridl<POSK>(E, shapes[e], i, sub, flip);
 }
 
+// (A CONTACT-SORTED form was built and measured in round 2 as well: springs in id order, then accumulator, particle and first
+// candidate ids through LDS, the workgroup's 256 particles ordered by candidate-count class (ballots + a 4 x 4 table), thread t
+// finishing the t-th particle of that order, so that the lanes of a wave carry equal numbers of contacts -- on oracle states of
+// the bench workload the sum over a workgroup's waves of the largest candidate count drops from 17.2 to 7.4.  Bit-identical,
+// and SLOWER: 64 episodes 1.129 -> 1.280 ms per step, one episode 0.856 -> 0.955, 256 episodes 3.425 -> 3.385.  Most candidate
+// evaluations end at the wave-uniform `distance < solidRestDistance` test after ~20 instructions, so the candidate loop is a
+// much smaller share of the 886 VALU instructions per wave than count x 74 suggests, and two more barriers plus an LDS hop in
+// a kernel that lives on its critical path cost more than the divergence they remove.  Removed.)
 // (A GRID-T form -- this kernel with the 256 + 4 dimx positions a workgroup's particles and their spring neighbours occupy
 // staged in LDS by coalesced loads, 2.6 dwordx4 loads per thread instead of 13 gathers -- was built and measured in round 2:
 // bit-identical and SLOWER at every launch size (64x64 x 64 episodes 1.480 -> 1.504 ms per step, x 8: 1.05 -> 1.17, x 256:
