@@ -41,16 +41,18 @@ def test_run_episodes_statistics(gpu_required):
     ctx.close()
 
 
-def test_full_size_eval_loop_config5(gpu_required):
+@pytest.mark.parametrize("loop", ["run_tasks", "run_episodes"])
+def test_full_size_eval_loop_config5(gpu_required, loop):
     """BASELINE.json configs[4] at the reference's own sizes (README.md:194, environment/simEnv.py:56-71 defaults): 12 rotations
     x 8 scales, 720 x 720 render -> 400 x 400 observation with adaptive scaling, cloth sides 64..104 ('hard' tasks of the
     reference's generator, environment/tasks.py:105-275), 8 episodes x up to 3 actions, seeded random-init fling policy (no
-    flingbot.pth in this image).  Checks the loop's invariants, that every stage ran on its device path (hand-written value
+    flingbot.pth in this image), through the asynchronous loop (evaluate.run_tasks: what bench.py's eval_loop entry times) and
+    the lock-step one.  Checks the loop's invariants, that every stage ran on its device path (hand-written value
     net, fs_observe_batch, fs_prepare_image, fs_select_action, streaming / fused solver forms) and reports the rates."""
     import time
     from flingbot_amd import nets, sim as fsim, tasks as ftasks
     from flingbot_amd.env import BatchedFlingEnv
-    from flingbot_amd.evaluate import run_episodes
+    from flingbot_amd import evaluate
 
     random.seed(5); np.random.seed(5); torch.manual_seed(5)
     n, actions = 8, 3
@@ -69,7 +71,7 @@ def test_full_size_eval_loop_config5(gpu_required):
                                      depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
                                      value_expl_decay=1.0, device="cuda:0")
     t0 = time.perf_counter()
-    stats = run_episodes(policy, env, tasks)
+    stats = getattr(evaluate, loop)(policy, env, tasks)
     dt = time.perf_counter() - t0
     # stages on their device paths
     assert all(net._hip is not None for net in policy.value_nets.values())
@@ -89,7 +91,7 @@ def test_full_size_eval_loop_config5(gpu_required):
     assert flings >= 1 and stats["simulation_steps"] > 300 * flings
     flat = np.array([t["flatten_area"] for t in tasks])
     assert np.allclose(np.array(ctx.coverage())[:n] / flat, stats["final_coverage"])
-    print(f"\n  config 5 (8 episodes, sides {sides.min()}..{sides.max()}, 12 x 8 transforms, 720 -> 400): {dt:.2f} s, "
+    print(f"\n  config 5, {loop} (8 episodes, sides {sides.min()}..{sides.max()}, 12 x 8 transforms, 720 -> 400): {dt:.2f} s, "
           f"{flings} flings ({flings / dt:.1f} /s), {stats['simulation_steps']} episode-steps "
           f"({stats['simulation_steps'] / dt:.0f} /s), coverage {stats['mean']['init_coverage']:.3f} -> "
           f"{stats['mean']['final_coverage']:.3f}")
