@@ -162,3 +162,38 @@ def test_scheduled_equals_lockstep_on_mixed_cloths(gpu_required):
         assert np.array_equal(a["vel"][e].view(np.uint32), b["vel"][e].view(np.uint32)), e
         assert np.array_equal(a["shapes"][e].view(np.uint32), b["shapes"][e].view(np.uint32)), e
     assert len({p.size for p in a["pos"]}) > 1  # the cloths really differ in size
+
+
+def test_advance_argument_errors(gpu_required):
+    """fs_advance refuses what it cannot run: an episode listed twice, an unknown request kind, chunk bounds out of order, a
+    movep before fs_picker_reset -- FlingSimError, and the episodes are left untouched."""
+    from flingbot_amd import sim as fsim
+
+    g = load_fling_golden()
+    ctx = _make(g, 2)
+    before = [ctx.get_positions(e).copy() for e in range(2)]
+    z = np.zeros((2, 2, 3))
+    gr = np.zeros((2, 2), int)
+    with pytest.raises(fsim.FlingSimError):
+        ctx.advance([0, 0], [1, 1], z, gr, [0.0, 0.0], [5, 5], [-1, -1], [0, 0], [0, 0])
+    with pytest.raises(fsim.FlingSimError):
+        ctx.advance([0, 1], [1, 7], z, gr, [0.0, 0.0], [5, 5], [-1, -1], [0, 0], [0, 0])
+    with pytest.raises(fsim.FlingSimError):
+        ctx.advance([0, 1], [1, 1], z, gr, [0.0, 0.0], [5, 5], [-1, -1], [0, 0], [0, 0], cap_min=9, cap=4)
+    fresh = fsim.FlingSim(n_envs=1, solver=0)
+    fresh.env(0).set_scene(g["scene_params"])
+    with pytest.raises(fsim.FlingSimError):
+        fresh.advance([0], [0], z[:1], gr[:1], [0.1], [5], [-1], [0], [0])  # no pickers set up
+    fresh.close()
+    for e in range(2):
+        assert np.array_equal(ctx.get_positions(e), before[e])
+    # plain steps: kind 2 takes exactly `limit` frames, resumable
+    prog, status, steps = ctx.advance([0, 1], [2, 2], z, gr, [0.0, 0.0], [3, 9], [-1, -1], [0, 0], [0, 0], cap_min=4, cap=4)
+    assert prog.tolist() == [3, 4] and status.tolist() == [1, 0] and steps.tolist() == [3, 4]
+    prog, status, steps = ctx.advance([1], [2], z[:1], gr[:1], [0.0], [9], [-1], [0], [4], cap_min=8, cap=8)
+    assert prog.tolist() == [9] and status.tolist() == [1] and steps.tolist() == [5]
+    ref = _make(g, 2)
+    ref.step_list([0], 3)
+    ref.step_list([1], 9)
+    for e in range(2):
+        assert np.array_equal(ctx.get_positions(e).view(np.uint32), ref.get_positions(e).view(np.uint32)), e
