@@ -187,5 +187,6 @@ def test_bench_starts_its_own_ranks_without_world_size():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode != 0
-    assert out.stderr.count("no HIP device visible") == 2, out.stderr[-2000:]
+    # (the launcher terminates the other ranks as soon as one fails, so the second rank's message may or may not get out)
+    assert 1 <= out.stderr.count("no HIP device visible") <= 2, out.stderr[-2000:]
     assert "launch with torch.distributed.run" not in out.stderr
