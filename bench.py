@@ -19,7 +19,7 @@ batch that was timed, compared with the C oracle after the timed region), `confi
 BASELINE.json configs[2] / configs[3] next to the headline) and, at N=1, `cpu_baseline` (the C oracle on the host
 cores this process may use, one independent episode of the same workload per core, about 15 s), `perception` (the
 value network's forward of one observation) and `eval_loop` (BASELINE.json configs[4]: the run_sim.py evaluation loop
-on 32 generated tasks at the reference's sizes, and 128 tasks streamed through 64 slots), both measured after the timed
+on 32 generated tasks at the reference's sizes, and 192 tasks streamed through 96 slots), both measured after the timed
 region.
 """
 import argparse
@@ -373,7 +373,7 @@ def run_rank(args):
         torch.distributed.destroy_process_group()
 
 
-def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=128, stream_slots=64):
+def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=192, stream_slots=96):
     """Secondary, after the timed region (rank 0, N = 1): BASELINE.json configs[4] at the reference's own sizes -- the
     run_sim.py evaluation loop on generated 'hard' tasks with cloth sides 64..103 (environment/tasks.py:105-275), 720 x 720
     render -> 400 x 400 observation with adaptive scaling, 12 rotations x 8 scales, seeded random-init fling policy
