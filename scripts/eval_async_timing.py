@@ -26,8 +26,9 @@ for label in ("lock-step", "scheduled steps", "async slots"):
         continue
     torch.manual_seed(0)
     ctx = fsim.FlingSim(n_envs=S, solver=int(os.environ.get("EVAL_SOLVER", "0")))  # 7: separate boundary kernels, 1: streaming only
-    env = BatchedFlingEnv(ctx, episode_length=steps, scheduled=label != "lock-step")
-    policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+    prims = os.environ.get("EVAL_PRIMITIVES", "fling").split(",")  # e.g. fling,stretchdrag,drag,place
+    env = BatchedFlingEnv(ctx, action_primitives=prims, episode_length=steps, scheduled=label != "lock-step")
+    policy = nets.MaximumValuePolicy(action_primitives=prims, num_rotations=12, scale_factors=list(env.scale_factors),
                                      obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
                                      depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
                                      value_expl_decay=1.0, device="cuda:0")
