@@ -73,6 +73,9 @@ extern "C" int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, i
             memcpy(out, packed, sizeof(packed));
             return FS_OK;
         }
+        case FS_SCENE_RESTNEAR: src = s.restnear_w.data(); count = s.restnear_ok ? s.restnear_w.size() : 0; break;
+        case FS_SCENE_STREAM_CODES: src = s.scode.data(); count = s.sdict_size > 0 ? s.scode.size() : 0; break;
+        case FS_SCENE_STREAM_DICT: src = s.sdict.data(); count = s.sdict_size > 0 ? (size_t)4 * s.sdict_size : 0; break;
         default: fs_set_error("unknown scene array id"); return FS_ERR_ARG;
     }
     if ((size_t)n_elems < count) { fs_set_error("buffer too small"); return FS_ERR_ARG; }

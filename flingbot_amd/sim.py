@@ -560,6 +560,11 @@ def host_scene(scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear
                  "spring_stiffness": m, "triangles": 3 * t, "tri_normals": 3 * t, "adj_offsets": n + 1,
                  "adj_neighbors": 2 * m, "bounds": 6, "params": 32}
         out = {"n": n, "m": m, "t": t, "max_deg": deg}
+        for name, code, size in (("restnear", 12, 8 * n), ("stream_codes", 13, 4 * n), ("stream_dict", 14, 4 * 256)):
+            a = np.full(max(size, 1), 0xffffffff, np.uint32)  # derived tables of the kernels (empty when the cloth has none)
+            if lib.fs_host_scene_copy(h, code, a.ctypes.data_as(C.c_void_p), a.size) < 0:
+                raise FlingSimError(lib.fs_last_error().decode())
+            out[name] = a[:size]
         for name, (code, dt) in SCENE_ARRAYS.items():
             a = np.zeros(max(sizes[name], 1), dt)
             rc = lib.fs_host_scene_copy(h, code, a.ctypes.data_as(C.c_void_p), a.size)

@@ -315,6 +315,11 @@ typedef struct fs_host_scene fs_host_scene;
 #define FS_SCENE_ADJ_NEIGHBORS 9    /* int[2M] */
 #define FS_SCENE_BOUNDS 10          /* float[6] lower, upper */
 #define FS_SCENE_PARAMS 11          /* float[32] packed parameter table */
+/* derived tables of the kernels (white box for the CPU tests; empty when the cloth does not have them) */
+#define FS_SCENE_RESTNEAR 12        /* uint32[8][n]: per particle up to 16 ids (16 bits each, 0xffff = none) of the particles closer
+                                       than the collision radius in the rest pose (SelfCollideFilter, NvFlex.h:166) */
+#define FS_SCENE_STREAM_CODES 13    /* uint32[n][4]: one byte per spring slot of the particle, 255 = none */
+#define FS_SCENE_STREAM_DICT 14     /* float[entries][4]: bits(j - i), rest length, stiffness, 0 */
 fs_host_scene *fs_host_scene_build(const float *scene_params, int n_params, const float *verts, int n_vert_floats,
                                    const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints,
                                    const int *shear, int n_shear_ints, const int *faces, int n_face_ints);

@@ -811,3 +811,60 @@ def test_scheduler_requests_and_services_on_the_oracle():
 
     with pytest.raises(ValueError):
         sch.run_programs(prim, {0: bad()})
+
+
+def test_host_scene_derived_tables_match_brute_force():
+    """The kernels' derived topology tables, built by fs_scene.cpp (no GPU): the rest-near ids of the SelfCollideFilter test
+    (NvFlex.h:166: particles closer than the collision radius in the rest pose) against an all-pairs computation, and the
+    streaming kernels' one-byte spring codes + dictionary against the adjacency they encode -- for a grid cloth, a cloth with
+    per-type stiffnesses and the .obj mesh of the task golden."""
+    from flingbot_amd import sim as fsim
+
+    def check(h, what, expect_mesh_neighbours=True):
+        n = h["n"]
+        pos = h["positions"].reshape(-1, 4)[:, :3].astype(np.float32)
+        par = h["params"]
+        r = np.float32(par[6]) + np.float32(par[10])  # radius + particleCollisionMargin
+        rn = h["restnear"].reshape(8, n)
+        ids = np.stack([rn & 0xffff, rn >> 16], axis=1).reshape(16, n)  # slot q of particle i: word q // 2, half q % 2
+        d = pos[:, None, :] - pos[None, :, :]
+        e2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        near = e2 < r * r
+        np.fill_diagonal(near, False)
+        for i in range(n):
+            got = {int(v) for v in ids[:, i] if v != 0xffff}
+            assert got == set(np.nonzero(near[i])[0].tolist()), (what, i)
+        if expect_mesh_neighbours:
+            assert near.sum(axis=1).max() >= 8  # interior particles of a grid cloth see their 8 mesh neighbours
+        # spring codes: slot s of particle i -> dictionary entry (j - i, length, stiffness) = its s-th incident spring
+        codes = h["stream_codes"].reshape(n, 4)
+        dic = h["stream_dict"].reshape(-1, 4)
+        springs, lens, ks = h["springs"].reshape(-1, 2), h["spring_lengths"], h["spring_stiffness"]
+        off, adj = h["adj_offsets"], h["adj_neighbors"]
+        by_pair = {}
+        for sid, (a, b) in enumerate(springs):
+            by_pair.setdefault((int(a), int(b)), []).append(sid)
+            by_pair.setdefault((int(b), int(a)), []).append(sid)
+        used = 0
+        for i in range(0, n, max(1, n // 300)):
+            deg = off[i + 1] - off[i]
+            for s_ in range(16):
+                c = (int(codes[i, s_ // 4]) >> (8 * (s_ % 4))) & 255
+                if s_ >= deg:
+                    assert c == 255, (what, i, s_)
+                    continue
+                j = int(adj[off[i] + s_])
+                ent = dic[c]
+                assert int(ent[0].view(np.int32)) == j - i, (what, i, s_)
+                assert any(lens[sid].view(np.uint32) == ent[1] and ks[sid].view(np.uint32) == ent[2] for sid in by_pair[(i, j)]), (what, i, s_)
+                used += 1
+        assert used > 100
+
+    from conftest import cloth_params
+    check(fsim.host_scene(cloth_params(37, 23)), "grid 37 x 23")
+    check(fsim.host_scene(cloth_params(24, 30, stiff=(0.8, 1.0, 0.6))), "grid 24 x 30, per-type stiffness")
+    g = np.load(os.path.join(GOLD, "task_golden.npz"))
+    if True:
+        sp = cloth_params(0, 0)
+        check(fsim.host_scene(sp, g["obj_vertices"].reshape(-1), g["obj_stretch"].reshape(-1), g["obj_bend"].reshape(-1),
+                              g["obj_shear"].reshape(-1), g["obj_faces"].reshape(-1)), "obj mesh", expect_mesh_neighbours=False)
