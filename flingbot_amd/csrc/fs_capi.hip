@@ -715,6 +715,16 @@ extern "C" int fs_render(fs_ctx *ctx, int env, unsigned char *rgba, int n_bytes,
     return fs_render_env(ctx, env, rgba, depth);
 }
 
+extern "C" int fs_get_sphere_mesh(fs_ctx *ctx, int env, float *verts, float *normals, int n_floats, int *tris, int n_ints) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e) return FS_ERR_ARG;
+    const int s = e->shapes.count;
+    if (verts || normals) CHECK_LEN(n_floats, 4 * 441 * s);
+    if (tris) CHECK_LEN(n_ints, 3 * 800 * s);
+    HIP_TRY(hipSetDevice(ctx->device));
+    return fs_sphere_mesh_env(ctx, env, verts, normals, tris);
+}
+
 extern "C" int fs_coverage(fs_ctx *ctx, double *out, int n_doubles) {
     if (!ctx || !out) return FS_ERR_ARG;
     CHECK_LEN(n_doubles, ctx->n_envs);

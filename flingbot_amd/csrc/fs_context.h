@@ -131,4 +131,5 @@ bool fs_fused_supported(const fs_ctx *ctx, const FsEnv &env);
 int fs_render_env(fs_ctx *ctx, int env, unsigned char *rgba, float *depth);
 int fs_render_device(fs_ctx *ctx, int env, unsigned char **d_rgba_out, float **d_depth_out);
 int fs_normals_env(fs_ctx *ctx, int env, float *out4n);
+int fs_sphere_mesh_env(fs_ctx *ctx, int env, float *verts4, float *nrms4, int *tris);
 int fs_coverage_all(fs_ctx *ctx, double *out);

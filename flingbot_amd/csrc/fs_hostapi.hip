@@ -5,6 +5,7 @@
 #include "../../include/flingsim.h"
 #include "fs_context.h"
 #include "fs_camera.h"
+#include "fs_sphere_mesh.h"
 
 struct fs_host_scene {
     FsHostScene s;
@@ -95,5 +96,26 @@ extern "C" int fs_camera_matrices(const float *cam_pos3, const float *cam_angle3
     memcpy(out54 + 32, fr.light_vp, 64);
     memcpy(out54 + 48, fr.light_pos, 12);
     memcpy(out54 + 51, fr.light_dir, 12);
+    return FS_OK;
+}
+
+// The mesh fs_render rasterises for ONE kinematic sphere, computed by the same functions on the host
+// (fs_raster_kernels.h: fs_sphere_trig, fs_quat_axes, fs_sphere_vertex, fs_sphere_tri) = what the reference draws
+// (core/mesh.cpp:858-902 + main.cpp:1739-1751).  verts / normals: float[4 * 441], tris: int[3 * 800]; each may be null.
+extern "C" int fs_host_sphere_mesh(float radius, const float *prev_pos3, const float *prev_quat4, float *verts,
+                                   float *normals, int *tris) {
+    if (!prev_pos3 || !prev_quat4) return FS_ERR_ARG;
+    FsSphereTrig trig;
+    fs_sphere_trig(trig);
+    float a[9];
+    fs_quat_axes(prev_quat4, a);
+    for (int v = 0; v < FS_SPHERE_VERTS; ++v) {
+        FsVec4 p, n;
+        fs_sphere_vertex(trig, a, radius, prev_pos3[0], prev_pos3[1], prev_pos3[2], v, p, n);
+        if (verts) memcpy(verts + 4 * v, &p, 16);
+        if (normals) memcpy(normals + 4 * v, &n, 16);
+    }
+    if (tris)
+        for (int t = 0; t < FS_SPHERE_TRIS; ++t) fs_sphere_tri(t, tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]);
     return FS_OK;
 }

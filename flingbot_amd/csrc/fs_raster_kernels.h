@@ -1,7 +1,7 @@
 // fs_raster_kernels.h -- HIP software rasteriser standing in for the reference's OpenGL path
 // (pyflex_render PyFlex/bindings/pyflex.cpp:924-1133, RenderScene main.cpp:1339-1582, GLSL shadersGL.cpp:692-839).
 //
-// Pipeline per frame: sphere meshes for the pickers (core/mesh.cpp:858-902, drawn at their PREVIOUS position,
+// Pipeline per frame: sphere meshes for the pickers (core/mesh.cpp:858-902, drawn at their PREVIOUS transform,
 // main.cpp:1737-1751) -> 2048^2 shadow depth from the light (polygon offset 8,8; shadersGL.cpp:1002-1004) -> camera
 // depth + primitive id with one 64-bit atomicMin per covered pixel -> per-pixel shading (Lambert x PCF shadow x spot
 // attenuation + ambient, fog, gamma; shadersGL.cpp:795-839) -> RGBA8 + linearised depth (pyflex.cpp:1046-1054).
@@ -16,13 +16,10 @@
 #include "fs_types.h"
 
 #define FS_SHADOW_RES 2048
-#define FS_SPHERE_SLICES 20
-#define FS_SPHERE_SEGMENTS 20
-#define FS_SPHERE_VERTS ((FS_SPHERE_SLICES + 1) * (FS_SPHERE_SEGMENTS + 1))
-#define FS_SPHERE_TRIS (FS_SPHERE_SLICES * FS_SPHERE_SEGMENTS * 2)
 #define FS_DEPTH_MAX 16777215.0  // 2^24 - 1
 
 #include "fs_camera.h"
+#include "fs_sphere_mesh.h"
 
 // ---------------------------------------------------------------- device
 struct FsClipVert { float x, y, z, w; };
@@ -36,29 +33,13 @@ __host__ __device__ inline FsClipVert fs_xform(const float *m, float x, float y,
     return c;
 }
 
-// picker sphere meshes at the previous shape position (core/mesh.cpp:858-902)
-__global__ void fs_k_sphere_mesh(const FsShapesDev *sh, FsVec4 *verts, FsVec4 *nrms) {
+__global__ void fs_k_sphere_mesh(const FsShapesDev *sh, const FsSphereTrig trig, const FsSphereRot rot, FsVec4 *verts,
+                                 FsVec4 *nrms) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= sh->count * FS_SPHERE_VERTS) return;
-    const int q = g / FS_SPHERE_VERTS, v = g % FS_SPHERE_VERTS;
-    const int i = v / (FS_SPHERE_SEGMENTS + 1), j = v % (FS_SPHERE_SEGMENTS + 1);
-    const float kPi = 3.141592653589f;
-    const float theta = (kPi / FS_SPHERE_SLICES) * i, phi = (2.0f * kPi / FS_SPHERE_SEGMENTS) * j;
-    const float x = sinf(theta) * cosf(phi), y = cosf(theta), z = sinf(theta) * sinf(phi);
-    const float r = sh->pos[q].w;
-    verts[g] = FsVec4{sh->prev[q].x + x * r, sh->prev[q].y + y * r, sh->prev[q].z + z * r, 1.0f};
-    nrms[g] = FsVec4{x, y, z, 0.0f};
-}
-
-__host__ __device__ inline void fs_sphere_tri(int t, int &a, int &b, int &c) {
-    // quad (i, j), i in 1..slices, j in 1..segments; tris (b,a,d) and (b,d,c)
-    const int q = t / FS_SPHERE_TRIS, r = t % FS_SPHERE_TRIS;
-    const int quad = r >> 1, half = r & 1;
-    const int i = quad / FS_SPHERE_SEGMENTS + 1, j = quad % FS_SPHERE_SEGMENTS + 1;
-    const int row = FS_SPHERE_SEGMENTS + 1, base = q * FS_SPHERE_VERTS;
-    const int va = i * row + j, vb = (i - 1) * row + j, vc = (i - 1) * row + j - 1, vd = i * row + j - 1;
-    if (half == 0) { a = base + vb; b = base + va; c = base + vd; }
-    else { a = base + vb; b = base + vd; c = base + vc; }
+    const int q = g / FS_SPHERE_VERTS;
+    fs_sphere_vertex(trig, rot.a[q], sh->pos[q].w, sh->prev[q].x, sh->prev[q].y, sh->prev[q].z, g % FS_SPHERE_VERTS, verts[g],
+                     nrms[g]);
 }
 
 struct FsSetupTri {

@@ -180,6 +180,44 @@ int fs_coverage_all(fs_ctx *ctx, double *out) {
     return FS_OK;
 }
 
+// picker meshes of `env` into d_sv / d_sn (float4[441 * shapes]); the shapes' previous rotations are host state
+// (pyflex.add_sphere / set_shape_states; the device-side picker moves centres only)
+static int launch_sphere_mesh(fs_ctx *ctx, int env, FsVec4 *d_sv, FsVec4 *d_sn) {
+    const FsEnv &e = ctx->envs[env];
+    static const FsSphereTrig trig = [] { FsSphereTrig t; fs_sphere_trig(t); return t; }();
+    FsSphereRot rot;
+    memset(&rot, 0, sizeof(rot));
+    for (int q = 0; q < e.shapes.count && q < FS_MAX_SHAPES; ++q) fs_quat_axes(e.shape_prev_rot[q], rot.a[q]);
+    const size_t sph_verts = size_t(e.shapes.count) * FS_SPHERE_VERTS;
+    hipLaunchKernelGGL(fs_k_sphere_mesh, dim3((unsigned)((sph_verts + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->d_shapes + env, trig, rot, d_sv, d_sn);
+    HIP_TRY(hipGetLastError());
+    return FS_OK;
+}
+
+// The picker meshes alone (test hook of the render path: what fs_render_device rasterises for the shapes).
+// verts4 / nrms4: float[4 * 441 * shapes]; tris: int[3 * 800 * shapes] (either may be null).
+int fs_sphere_mesh_env(fs_ctx *ctx, int env, float *verts4, float *nrms4, int *tris) {
+    const FsEnv &e = ctx->envs[env];
+    const int n_sph = e.shapes.count;
+    if (n_sph <= 0) return FS_OK;
+    const size_t nv = size_t(n_sph) * FS_SPHERE_VERTS, bytes = nv * 16;
+    int rc = ensure_scratch(ctx, 2 * bytes + 512);
+    if (rc != FS_OK) return rc;
+    FsVec4 *d_sv = (FsVec4 *)ctx->render_scratch, *d_sn = d_sv + nv;
+    rc = launch_sphere_mesh(ctx, env, d_sv, d_sn);
+    if (rc != FS_OK) return rc;
+    char *stg = (char *)fs_stage(ctx, 2 * bytes);
+    if (!stg) return FS_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(stg, d_sv, 2 * bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (verts4) memcpy(verts4, stg, bytes);
+    if (nrms4) memcpy(nrms4, stg + bytes, bytes);
+    if (tris)
+        for (int t = 0; t < n_sph * FS_SPHERE_TRIS; ++t) fs_sphere_tri(t, tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]);
+    return FS_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // pyflex.render -- see fs_raster_kernels.h
 // Renders into the context's scratch and leaves the frame there: *d_rgba_out (uint8 RGBA, bottom-up rows) and
@@ -218,9 +256,10 @@ int fs_render_device(fs_ctx *ctx, int env, unsigned char **d_rgba_out, float **d
     if (rc != FS_OK) return rc;
     HIP_TRY(hipMemsetAsync(d_z, 0xff, size_t(8) * W * H, st));
     HIP_TRY(hipMemsetAsync(d_shadow, 0xff, size_t(4) * FS_SHADOW_RES * FS_SHADOW_RES, st));
-    if (n_sph > 0)
-        hipLaunchKernelGGL(fs_k_sphere_mesh, dim3((unsigned)((sph_verts + 255) / 256)), dim3(256), 0, st,
-                           ctx->d_shapes + env, d_sv, d_sn);
+    if (n_sph > 0) {
+        rc = launch_sphere_mesh(ctx, env, d_sv, d_sn);
+        if (rc != FS_OK) return rc;
+    }
     const int n_sph_tris = n_sph * FS_SPHERE_TRIS;
     // shadow pass (depth only, from the light), then camera pass (depth + primitive id), then shading
     const int total_tris = T + n_sph_tris;

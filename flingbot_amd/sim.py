@@ -92,6 +92,7 @@ def load_library(build_if_missing=True):
         "fs_get_camera_params": (ci, [vp, ci, fp]),
         "fs_set_camera_params": (ci, [vp, ci, fp]),
         "fs_render": (ci, [vp, ci, u8p, ci, fp, ci]),
+        "fs_get_sphere_mesh": (ci, [vp, ci, fp, fp, ci, ip, ci]),
         "fs_coverage": (ci, [vp, C.POINTER(C.c_double), ci]),
         "fs_step_timed": (ci, [vp, ci, ci, fp]),
         "fs_picker_reset": (ci, [vp, ci, C.c_double, C.c_double]),
@@ -129,6 +130,7 @@ def load_library(build_if_missing=True):
         "fs_host_scene_free": (None, [vp]),
         "fs_host_scene_counts": (ci, [vp, ip, ip, ip, ip]),
         "fs_host_scene_copy": (ci, [vp, ci, vp, ci]),
+        "fs_host_sphere_mesh": (ci, [cf, fp, fp, fp, fp, ip]),
         "fs_camera_matrices": (ci, [fp, fp, ci, ci, fp, fp, fp]),
         "fs_get_last_neighbors": (ci, [vp, ci, ip, ip]),
         "fs_device_positions": (vp, [vp, ci]),
@@ -455,6 +457,15 @@ class FlingSim:
                                     depth.size))
         return rgba, depth
 
+    def sphere_mesh(self, env=0):
+        """(verts float32[441 S, 4], normals float32[441 S, 4], tris int32[800 S, 3]): the picker meshes `render`
+        rasterises (white-box access for tests)."""
+        s_ = self.n_shapes(env)
+        verts, nrms = np.empty((441 * s_, 4), np.float32), np.empty((441 * s_, 4), np.float32)
+        tris = np.empty((800 * s_, 3), np.int32)
+        self._ck(self.lib.fs_get_sphere_mesh(self.h, env, _fp(verts), _fp(nrms), verts.size, _ip(tris), tris.size))
+        return verts, nrms, tris
+
     def observe(self, env, image_dim, want_mask=False):
         """get_image + get_cloth_mask + preprocess_obs on the device (fs_observe, csrc/fs_observe.hip): renders episode
         `env` with its camera and returns (obs float32 CUDA tensor [4, S, S], bbox int[5] = x.min, x.max, y.min, y.max and
@@ -541,6 +552,15 @@ SCENE_ARRAYS = {"positions": (0, np.float32), "velocities": (1, np.float32), "ph
                 "springs": (3, np.int32), "spring_lengths": (4, np.float32), "spring_stiffness": (5, np.float32),
                 "triangles": (6, np.int32), "tri_normals": (7, np.float32), "adj_offsets": (8, np.int32),
                 "adj_neighbors": (9, np.int32), "bounds": (10, np.float32), "params": (11, np.float32)}
+
+
+def host_sphere_mesh(radius, prev_pos, prev_quat):
+    """The mesh `render` rasterises for one kinematic sphere, from the library's host code (no GPU needed)."""
+    lib = load_library()
+    verts, nrms, tris = np.empty((441, 4), np.float32), np.empty((441, 4), np.float32), np.empty((800, 3), np.int32)
+    rc = lib.fs_host_sphere_mesh(C.c_float(radius), _fp(_f(prev_pos)), _fp(_f(prev_quat)), _fp(verts), _fp(nrms), _ip(tris))
+    assert rc == 0
+    return verts, nrms, tris
 
 
 def host_scene(scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):

@@ -120,6 +120,11 @@ int fs_set_camera_params(fs_ctx *ctx, int env, const float *in8);
 /* pyflex.render (pyflex.cpp:924-1133): RGBA8 bottom-up [h*w*4] and linear depth [h*w] of env. */
 int fs_render(fs_ctx *ctx, int env, unsigned char *rgba, int n_bytes, float *depth, int n_floats);
 
+/* white-box access for tests: the triangle meshes fs_render rasterises for env's kinematic spheres = what the reference
+   draws for them (main.cpp:1739-1751: CreateSphere(20, 20, r) core/mesh.cpp:858-902, transformed by the shape's PREVIOUS
+   position and rotation).  verts / normals: float[4 * 441 * S], tris: int[3 * 800 * S]; any of them may be null. */
+int fs_get_sphere_mesh(fs_ctx *ctx, int env, float *verts, float *normals, int n_floats, int *tris, int n_ints);
+
 /* coverage reward of every env (flex_utils.py:358-395 get_current_covered_area with pos=None, particle radius
    0.00625), out[n_envs] in float64 like the reference's return value; envs without a scene report 0. */
 int fs_coverage(fs_ctx *ctx, double *out, int n_doubles);
@@ -326,6 +331,9 @@ fs_host_scene *fs_host_scene_build(const float *scene_params, int n_params, cons
 void fs_host_scene_free(fs_host_scene *h);
 int fs_host_scene_counts(const fs_host_scene *h, int *n, int *m, int *t, int *max_deg);
 int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, int n_elems);
+/* host-only: the mesh of ONE kinematic sphere exactly as fs_render rasterises it (see fs_get_sphere_mesh) */
+int fs_host_sphere_mesh(float radius, const float *prev_pos3, const float *prev_quat4, float *verts, float *normals,
+                        int *tris);
 /* RenderScene camera / light set-up (main.cpp:1411-1438; core/maths.h:507-598): out[0:16] view, [16:32] proj,
    [32:48] lightTransform (row-major, column vectors), [48:51] lightPos, [51:54] lightDir. */
 int fs_camera_matrices(const float *cam_pos3, const float *cam_angle3, int width, int height,

@@ -45,6 +45,8 @@ def build_oracle(force=False):
                               [f"liboracle_{v}.so" for v in VARIANTS])
     if os.path.isdir("/root/reference/PyFlex/core") and os.path.exists(os.path.join(_HERE, "ref_camera_probe.cpp")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "_ref/camera_ref"])
+        if os.path.exists(os.path.join(_HERE, "ref_sphere_probe.cpp")):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "_ref/sphere_ref"])
     return lib
 
 

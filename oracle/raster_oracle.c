@@ -116,6 +116,58 @@ static void sphere_tri(int t, int *a, int *b, int *c) {
     else { *a = base + vb; *b = base + vd; *c = base + vc; }
 }
 
+/*
+ * The mesh the reference draws for a kinematic sphere shape (bindings/main.cpp:1739-1751):
+ *   CreateSphere(20, 20, radius)                    core/mesh.cpp:858-902  (unit direction * radius, normal = direction)
+ *   ->Transform(Translation(prevPos) * Rotation(prevQuat))   core/mesh.cpp:650-657, maths.h:555-573, quat.h:162-165
+ * spheres: float[11 * ns] = current xyz, previous xyz, radius, previous rotation quaternion (x, y, z, w).
+ * FlingBot adds its pickers with the quaternion [1, 0, 0, 0] (flex_utils.py:82-83) -- half a turn about x -- so the
+ * mesh it draws starts at the SOUTH pole.  Pinned against the reference's own mesh.cpp (tests/golden/sphere_golden.json).
+ * verts / nrms: float4[441 * ns] (w = 1 / 0); tris (may be NULL): int[3 * 800 * ns], indices into the concatenated meshes.
+ */
+static void quat_axes(const float *q, float *R /* R[3 * c + r]: image of unit axis c */) {
+    /* quat.h:162-165  Rotate(q, x) = x (2 w w - 1) + cross(q.xyz, x) w 2 + q.xyz dot(q.xyz, x) 2, summed left to right */
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const float s = 2.0f * qw * qw - 1.0f;
+    for (int c = 0; c < 3; ++c) {
+        const float ex = c == 0 ? 1.0f : 0.0f, ey = c == 1 ? 1.0f : 0.0f, ez = c == 2 ? 1.0f : 0.0f;
+        const float cx = qy * ez - qz * ey, cy = qz * ex - qx * ez, cz = qx * ey - qy * ex;
+        const float d = qx * ex + qy * ey + qz * ez;
+        R[3 * c + 0] = ex * s + cx * qw * 2.0f + qx * d * 2.0f;
+        R[3 * c + 1] = ey * s + cy * qw * 2.0f + qy * d * 2.0f;
+        R[3 * c + 2] = ez * s + cz * qw * 2.0f + qz * d * 2.0f;
+    }
+}
+void orc_sphere_mesh(const float *spheres, int ns, float *verts, float *nrms, int *tris) {
+    const float kPi = 3.141592653589f; /* core/maths.h */
+    const float dTheta = kPi / SPH_SLICES, dPhi = (2.0f * kPi) / SPH_SEGS;
+    for (int q = 0; q < ns; ++q) {
+        const float *S = spheres + 11 * q;
+        const float r = S[6];
+        float R[9];
+        quat_axes(S + 7, R);
+        for (int i = 0; i <= SPH_SLICES; ++i)
+            for (int j = 0; j <= SPH_SEGS; ++j) {
+                const float theta = dTheta * i, phi = dPhi * j;
+                const float x = sinf(theta) * cosf(phi), y = cosf(theta), z = sinf(theta) * sinf(phi);
+                const float px = x * r, py = y * r, pz = z * r;
+                float *V = verts + 4 * (q * SPH_VERTS + i * (SPH_SEGS + 1) + j);
+                float *N = nrms + 4 * (q * SPH_VERTS + i * (SPH_SEGS + 1) + j);
+                /* mat44.h:181-201: v.x m[0] + v.y m[4] + v.z m[8] (+ m[12]), left to right */
+                V[0] = px * R[0] + py * R[3] + pz * R[6] + S[3];
+                V[1] = px * R[1] + py * R[4] + pz * R[7] + S[4];
+                V[2] = px * R[2] + py * R[5] + pz * R[8] + S[5];
+                V[3] = 1.0f;
+                N[0] = x * R[0] + y * R[3] + z * R[6];
+                N[1] = x * R[1] + y * R[4] + z * R[7];
+                N[2] = x * R[2] + y * R[5] + z * R[8];
+                N[3] = 0.0f;
+            }
+    }
+    if (tris)
+        for (int t = 0; t < ns * SPH_TRIS; ++t) sphere_tri(t, &tris[3 * t], &tris[3 * t + 1], &tris[3 * t + 2]);
+}
+
 typedef struct {
     const float *view, *vp, *light_vp, *cam_pos, *light_dir;
     float znear, zfar, fog, tan_half_fov, aspect;
@@ -177,7 +229,7 @@ static unsigned char to_u8(float c) {
 
 /*
  * mats: [0:16] view, [16:32] proj, [32:48] light view-proj (row-major, column vectors), [48:51] lightPos, [51:54] lightDir
- * pos/nrm: float4[n]; tris int[3t]; spheres: float[7*ns] = current xyz, previous xyz, radius.
+ * pos/nrm: float4[n]; tris int[3t]; spheres: float[11*ns] = current xyz, previous xyz, radius, previous quaternion xyzw (see orc_sphere_mesh).
  * Outputs rgba[W*H*4] (bottom-up) and linear depth[W*H].
  */
 int orc_render(const float *mats, const float *cam_pos, int W, int H, const float *pos, const float *nrm, int n,
@@ -214,15 +266,7 @@ int orc_render(const float *mats, const float *cam_pos, int W, int H, const floa
     /* picker meshes */
     int nsv = ns * SPH_VERTS, nst = ns * SPH_TRIS;
     v4 *sv = (v4 *)malloc(sizeof(v4) * (nsv + 1)), *sn = (v4 *)malloc(sizeof(v4) * (nsv + 1));
-    for (int g = 0; g < nsv; ++g) {
-        int q = g / SPH_VERTS, v = g % SPH_VERTS, i = v / (SPH_SEGS + 1), j = v % (SPH_SEGS + 1);
-        const float kPi = 3.141592653589f;
-        float theta = (kPi / SPH_SLICES) * i, phi = (2.0f * kPi / SPH_SEGS) * j;
-        float x = sinf(theta) * cosf(phi), y = cosf(theta), z = sinf(theta) * sinf(phi), r = spheres[7 * q + 6];
-        sv[g].x = spheres[7 * q + 3] + x * r; sv[g].y = spheres[7 * q + 4] + y * r; sv[g].z = spheres[7 * q + 5] + z * r;
-        sv[g].w = 1.0f;
-        sn[g].x = x; sn[g].y = y; sn[g].z = z; sn[g].w = 0.0f;
-    }
+    orc_sphere_mesh(spheres, ns, (float *)sv, (float *)sn, NULL);
     size_t npx = (size_t)W * H;
     unsigned long long *zb = (unsigned long long *)malloc(sizeof(unsigned long long) * npx);
     unsigned *shm = (unsigned *)malloc(sizeof(unsigned) * (size_t)SHADOW_RES * SHADOW_RES);

@@ -5,6 +5,7 @@ container (/root/reference is read-only and never travels to the GPU box; only t
 
 Sources:  environment/flex_utils.py get_current_covered_area (stubs for pyflex, cv2),
           oracle/_ref/camera_ref  (compiled from the reference's PyFlex/core/maths.h by oracle/Makefile),
+          oracle/_ref/sphere_ref  (compiled from the reference's PyFlex/core/mesh.cpp, same Makefile),
           learning/nets.py (stubs for cv2, ray), environment/utils.py (stubs for cv2, trimesh, ...).
 """
 import json
@@ -79,6 +80,35 @@ def camera_vectors():
     with open(os.path.join(HERE, "camera_golden.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("camera:", len(out), "cases")
+
+
+def sphere_vectors():
+    """The mesh the reference draws for a kinematic sphere: oracle/_ref/sphere_ref = the reference's own core/mesh.cpp
+    CreateSphere(20, 20, r) + Mesh::Transform(Translation(prev pos) * Rotation(prev quat)) (main.cpp:1739-1751)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "sphere_ref")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "_ref/sphere_ref"])
+    cases = [
+        # the pickers as FlingBot adds them (flex_utils.py:82-83: quat [1, 0, 0, 0] = half a turn about x), parked
+        # where reset_end_effectors leaves them (simEnv.py:771-772), radius simEnv.py:129-134
+        dict(radius=0.02, pos=[0.5, 0.5, -0.5], quat=[1, 0, 0, 0]),
+        dict(radius=0.02, pos=[-0.5, 0.5, -0.5], quat=[1, 0, 0, 0]),
+        dict(radius=0.02, pos=[0.04, 0.3, 0.0], quat=[0, 0, 0, 1]),
+        dict(radius=0.05, pos=[0.123, 0.456, -0.789], quat=[0.18257419, 0.36514837, 0.54772256, 0.73029674]),
+        dict(radius=0.031, pos=[-0.3, 0.07, 0.2], quat=[0.5, -0.5, 0.5, 0.5]),
+    ]
+    out = []
+    for c in cases:
+        f32 = lambda v: [float(np.float32(x)) for x in v]
+        rec = dict(radius=float(np.float32(c["radius"])), pos=f32(c["pos"]), quat=f32(c["quat"]))
+        txt = subprocess.check_output([exe] + [repr(x) for x in (rec["radius"], *rec["pos"], *rec["quat"])]).decode()
+        for line in txt.strip().split("\n"):
+            name, *vals = line.split()
+            rec[name] = [int(v) for v in vals] if name in ("counts", "indices") else [float(v) for v in vals]
+        assert rec["counts"] == [441, 441, 2400]
+        out.append(rec)
+    with open(os.path.join(HERE, "sphere_golden.json"), "w") as fh:
+        json.dump(out, fh)
+    print("sphere:", len(out), "cases")
 
 
 def nets_vectors():
@@ -885,11 +915,13 @@ def task_vectors():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "nets", "envutils", "picker", "fling", "action", "task", "step"]
+    which = sys.argv[1:] or ["coverage", "camera", "sphere", "nets", "envutils", "picker", "fling", "action", "task", "step"]
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:
         camera_vectors()
+    if "sphere" in which:
+        sphere_vectors()
     if "nets" in which and "nets_vectors" in globals():
         nets_vectors()
     if "envutils" in which:

@@ -868,3 +868,33 @@ def test_host_scene_derived_tables_match_brute_force():
         sp = cloth_params(0, 0)
         check(fsim.host_scene(sp, g["obj_vertices"].reshape(-1), g["obj_stretch"].reshape(-1), g["obj_bend"].reshape(-1),
                               g["obj_shear"].reshape(-1), g["obj_faces"].reshape(-1)), "obj mesh", expect_mesh_neighbours=False)
+
+
+def test_sphere_mesh_pinned_to_reference_mesh():
+    """oracle/_ref/sphere_ref -- the reference's own core/mesh.cpp CreateSphere(20, 20, r) + Mesh::Transform, compiled where
+    it lies -- recorded five spheres in tests/golden/sphere_golden.json (FlingBot's pickers with their [1, 0, 0, 0]
+    quaternion, an identity rotation, two general ones).  The oracle's restatement (raster_oracle.c orc_sphere_mesh) and
+    the product's host code (the functions fs_render's kernel runs, through fs_host_sphere_mesh) both give the same 2 400
+    indices, 441 positions and 441 normals EXACTLY."""
+    import json
+
+    from flingbot_amd import sim as fsim
+    from oracle.render import sphere_mesh as orc_sphere_mesh
+
+    with open(os.path.join(GOLD, "sphere_golden.json")) as fh:
+        gold = json.load(fh)
+    assert len(gold) == 5
+    for c in gold:
+        assert c["counts"] == [441, 441, 2400]
+        gp = np.array(c["positions"], np.float32).reshape(441, 3)
+        gn = np.array(c["normals"], np.float32).reshape(441, 3)
+        gi = np.array(c["indices"], np.int32).reshape(800, 3)
+        st = np.zeros(14, np.float32)
+        st[0:3], st[3:6], st[6:10], st[10:14] = [7.0, 8.0, 9.0], c["pos"], [0.0, 0.0, 0.0, 1.0], c["quat"]
+        for name, (v, n, t) in (("oracle", orc_sphere_mesh(st, [c["radius"]])),
+                                ("product", fsim.host_sphere_mesh(c["radius"], c["pos"], c["quat"]))):
+            assert np.array_equal(t, gi), name
+            assert np.array_equal(v[:, :3], gp), (name, np.abs(v[:, :3] - gp).max())
+            assert np.array_equal(n[:, :3], gn), (name, np.abs(n[:, :3] - gn).max())
+    # FlingBot's pickers are drawn upside down: vertex 0 is the south pole (quaternion x = 1 is half a turn about x)
+    assert gold[0]["quat"] == [1.0, 0.0, 0.0, 0.0] and gold[0]["normals"][:3] == [0.0, -1.0, 0.0]

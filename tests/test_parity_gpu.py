@@ -74,6 +74,48 @@ def test_drop_32_bit_exact_every_step(gpu_required, solver):
         _assert_state_equal(hip, orc, f"drop step {k}")
 
 
+def set_to_flatten_positions(dimx, dimz, cloth_particle_radius=0.00625):
+    """The array flex_utils.set_to_flatten (flex_utils.py:398-415) hands to pyflex.set_positions, expression by
+    expression: linspace over dim * radius (so the pitch is dim / (dim - 1) * radius), y = radius, w = 1, then the
+    mean of x, y, z subtracted -- which puts the sheet at y = 0, inside the ground's collision distance."""
+    px = np.linspace(0, dimx * cloth_particle_radius, dimx)
+    py = np.linspace(0, dimz * cloth_particle_radius, dimz)
+    xx, yy = np.meshgrid(px, py)
+    new_pos = np.empty(shape=(dimx * dimz, 4), dtype=np.float64)
+    new_pos[:, 0] = xx.flatten()
+    new_pos[:, 1] = cloth_particle_radius
+    new_pos[:, 2] = yy.flatten()
+    new_pos[:, 3] = 1.
+    new_pos[:, :3] -= np.mean(new_pos[:, :3], axis=0)
+    return new_pos
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
+def test_config1_flat_32_200_steps_bit_exact(gpu_required, solver):
+    """BASELINE.json configs[0] / SURVEY 8(d) C1 verbatim: one 32 x 32 cloth, scene_params = [0,1,0, 32,32, .9,.9,.9, 2,
+    0,2,0, pi/2,-pi/2,0, 720,720, 0.5, 0], set_scene + its one step (flex_utils.py:343-354), flattened with the
+    set_to_flatten formula, then 200 pyflex.step() without rendering: HIP == oracle bit for bit after EVERY step."""
+    from oracle.coverage import covered_area
+
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    params = np.array([0, 1, 0, 32, 32, 0.9, 0.9, 0.9, 2, 0, 2, 0, np.pi / 2, -np.pi / 2, 0, 720, 720, 0.5, 0], np.float64)
+    flat = set_to_flatten_positions(32, 32)
+    assert flat[:, 1].max() == 0.0 and abs(flat[1, 0] - flat[0, 0] - 0.2 / 31) < 1e-15
+    for s in (hip, orc):
+        s.set_scene(params)
+        s.step()
+        s.set_positions(flat.flatten())  # float64 in, float32 at the boundary (pybind11 force-cast, pyflex.cpp:464)
+    assert covered_area(hip.get_positions()) == ctx.coverage()[0]
+    for k in range(200):
+        hip.step()
+        orc.step()
+        _assert_state_equal(hip, orc, f"C1 step {k}")
+    p = hip.get_positions().reshape(-1, 4)
+    assert np.isfinite(p).all() and 0.0049 < p[:, 1].min() and p[:, 1].max() <= 0.005  # lifted to the ground's collision distance
+    assert np.array_equal(p[:, 3], np.ones(1024, np.float32))
+
+
 @pytest.mark.parametrize("solver", SOLVERS)
 def test_crumple_bit_exact_and_neighbors(gpu_required, solver):
     ctx, orc = _sims(solver)

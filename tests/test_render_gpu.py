@@ -130,16 +130,60 @@ def test_render_pickers_visible_and_idempotent(gpu_required):
     assert img[sph][:, :3].mean() > 120  # 0.9 grey spheres
 
 
-def test_render_matches_raster_oracle(gpu_required):
+def test_sphere_mesh_equals_reference_mesh(gpu_required):
+    """The picker meshes the rasteriser draws == the reference's own CreateSphere(20, 20, r) + Mesh::Transform
+    (core/mesh.cpp:858-902, 650-657; main.cpp:1739-1751), recorded from the reference's mesh.cpp compiled here
+    (oracle/_ref/sphere_ref -> tests/golden/sphere_golden.json): 2 400 indices, 441 positions and 441 normals, all exact.
+    The mesh follows the shape's PREVIOUS position and rotation; FlingBot's pickers carry the quaternion [1, 0, 0, 0]
+    (flex_utils.py:82-83), so their vertex 0 is the south pole."""
+    import json
+
+    from flingbot_amd import sim as fsim
+    from oracle.render import sphere_mesh as orc_sphere_mesh
+
+    with open(os.path.join(GOLD, "sphere_golden.json")) as fh:
+        gold = json.load(fh)
+    ctx = fsim.FlingSim(n_envs=1)
+    env = ctx.env(0)
+    env.set_scene(cloth_params(8, 8, pos=(0.0, 2.0, 0.0)))
+    for c in gold:  # current transform = something else: only the previous one may show
+        env.add_sphere(c["radius"], [0.9, 0.8, 0.7], [0.0, 0.0, 0.0, 1.0])
+    st = env.get_shape_states().reshape(-1, 14).copy()
+    for q, c in enumerate(gold):
+        st[q, 3:6], st[q, 10:14] = c["pos"], c["quat"]
+    env.set_shape_states(st.ravel())
+    verts, nrms, tris = env.sphere_mesh()
+    o_verts, o_nrms, o_tris = orc_sphere_mesh(env.get_shape_states(), [c["radius"] for c in gold])
+    for q, c in enumerate(gold):
+        gp = np.array(c["positions"], np.float32).reshape(441, 3)
+        gn = np.array(c["normals"], np.float32).reshape(441, 3)
+        gi = np.array(c["indices"], np.int32).reshape(800, 3)
+        sl = slice(441 * q, 441 * (q + 1))
+        assert np.array_equal(tris[800 * q:800 * (q + 1)] - 441 * q, gi)
+        assert np.array_equal(verts[sl, :3], gp), np.abs(verts[sl, :3] - gp).max()
+        assert np.array_equal(nrms[sl, :3], gn), np.abs(nrms[sl, :3] - gn).max()
+        assert (verts[sl, 3] == 1.0).all() and (nrms[sl, 3] == 0.0).all()
+    assert np.array_equal(verts, o_verts) and np.array_equal(nrms, o_nrms) and np.array_equal(tris, o_tris)
+    # the pickers exactly as Picker.reset adds them: add_sphere(radius, pos, [1, 0, 0, 0]) -> half a turn about x
+    env.clear_shapes()
+    env.add_sphere(gold[0]["radius"], gold[0]["pos"], gold[0]["quat"])
+    verts, nrms, _ = env.sphere_mesh()
+    assert np.array_equal(verts[:, :3], np.array(gold[0]["positions"], np.float32).reshape(441, 3))
+    assert nrms[0, 1] == -1.0  # south pole first
+
+
+@pytest.mark.parametrize("side,seed", [(32, 7), (64, 3)])
+def test_render_matches_raster_oracle(gpu_required, side, seed):
     """HIP rasteriser vs the scalar C restatement (oracle/raster_oracle.c) on a crumpled cloth with both pickers in view:
-    depth bit-exact, alpha exact, colour within 1 LSB (device expf/powf vs libm differ in the last ulp)."""
+    depth bit-exact, alpha exact, colour within 1 LSB (device expf/powf vs libm differ in the last ulp).  side = 64 is
+    BASELINE.json configs[1] ("64x64 cloth + depth render") at its own size."""
     from flingbot_amd import sim as fsim
     from oracle.render import render as orc_render
     import scenarios as sc
 
     ctx = fsim.FlingSim(n_envs=1)
     env = ctx.env(0)
-    sc.scenario_crumple(env, 32, 32, seed=7, lift_steps=25, settle_steps=20)
+    sc.scenario_crumple(env, side, side, seed=seed, lift_steps=25, settle_steps=20)
     env.add_sphere(0.02, [0.35, 0.4, -0.3], [1, 0, 0, 0])
     env.add_sphere(0.02, [-0.2, 0.1, 0.25], [1, 0, 0, 0])
     st = env.get_shape_states().reshape(-1, 14).copy()
@@ -162,4 +206,4 @@ def test_render_matches_raster_oracle(gpu_required):
     # the scene really contains all three kinds of primitives
     d = depth.reshape(720, 720)
     assert ((d > 1.55) & (d < 1.65)).sum() > 50 and ((d > 1.85) & (d < 1.95)).sum() > 50  # spheres at y = 0.4 and 0.1
-    assert (d < 1.999).sum() > 1500
+    assert (d < 1.999).sum() > 1500 * (side // 32) ** 2
