@@ -15,8 +15,9 @@ state the timed window should see whatever --steps is: the sheet crumpled on the
 self-collision, the expensive regime).
 The JSON line carries `roofline` (algorithmic HBM bytes per launch / HIP-event kernel time vs the 8 TB/s peak; `basis`
 and `limiter` say what that number is and what really bounds the LDS-resident kernel), `parity` (one episode of the
-batch that was timed, compared with the C oracle after the timed region), `configs` (the 64-episodes-per-GPU figure of
-BASELINE.json configs[2] / configs[3] next to the headline) and, at N=1, `cpu_baseline` (the C oracle on the host
+batch that was timed, compared with the C oracle after every timed region), `valu_roofline` (lane-operations/s against the
+39.3 T/s non-packed VALU issue peak: the roofline that physically bounds the kernel), `configs` (the 64-episodes-per-GPU
+figure of BASELINE.json configs[2] / configs[3] next to the headline: median of three 100-frame windows over the same frames) and, at N=1, `cpu_baseline` (the C oracle on the host
 cores this process may use, one independent episode of the same workload per core, about 15 s), `perception` (the
 value network's forward of one observation) and `eval_loop` (BASELINE.json configs[4]: the run_sim.py evaluation loop
 on 32 generated tasks at the reference's sizes, and 192 tasks streamed through 96 slots), both measured after the timed
@@ -140,14 +141,14 @@ def traffic_from_profile(episodes):
 def limiter_from_profile():
     """What the committed PMC counters say actually limits the fused kernel (it keeps the iterations in LDS, so the
     contract's algorithmic-bytes `roofline` is an equivalent streamed bandwidth, not HBM traffic)."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
         try:
             with open(path) as fh:
                 rec = json.load(fh)
             c = rec["counters"]
             valu = c["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] / c["SQ_WAVE_CYCLES"]["avg_per_launch"]
-            return {"bound": "valu-issue", "source": f"profiles/{tag}_pmc.json",
+            return {"bound": "valu-issue", "source": f"profiles/{tag}_pmc.json", "episodes": rec.get("episodes", 256),
                     "valu_active_per_wave_cycle": valu, "ceiling_per_wave_cycle": 1.0 / rec.get("waves_per_simd", 4),
                     "frac": valu * rec.get("waves_per_simd", 4),
                     "valu_instructions_per_launch": c["SQ_INSTS_VALU"]["avg_per_launch"],
@@ -155,6 +156,45 @@ def limiter_from_profile():
                     "hbm_gbs": rec["hbm_bytes_per_launch"]["total_corrected"] / (rec["average_us"] * 1e-6) / 1e9,
                     "hbm_frac_of_peak": rec["hbm_bytes_per_launch"]["total_corrected"] / (rec["average_us"] * 1e-6) / 1e9
                                         / HBM_PEAK_GBS}
+        except Exception:
+            continue
+    return None
+
+
+VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s (one
+                                                    # non-packed fp32 VALU instruction per SIMD and 4 cycles per wave64)
+
+
+def valu_roofline(limiter, episodes, kern_ms):
+    """The roofline that physically bounds the LDS-resident kernel: VALU lane-operations per second against the
+    non-packed issue peak.  Instructions per launch come from the committed PMC pass (`limiter`), scaled per episode;
+    the time is this run's HIP-event kernel time."""
+    if not limiter or "valu_instructions_per_launch" not in limiter:
+        return None
+    per_ep = limiter["valu_instructions_per_launch"] / limiter.get("episodes", 256)
+    lane_ops = per_ep * episodes * 64
+    achieved = lane_ops / (kern_ms * 1e-3) / 1e12
+    return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+            "frac": achieved / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": per_ep * episodes,
+            "source": f"SQ_INSTS_VALU of {limiter['source']} (per episode) x 64 lanes / this run's kernel time; peak = "
+                      f"256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz"}
+
+
+def stream_limiter_from_profile():
+    """What the committed profiles say about the 64-episodes-per-GPU launch shape (streaming back-end, two launch
+    chains): per-kernel share and duration of one frame's 129 dependent launches."""
+    import csv
+    for tag in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_stream64_kernel_stats.csv")
+        try:
+            rows = list(csv.reader(open(path)))[1:]
+            ker = [{"kernel": r[0].split("(")[0].replace("void ", ""), "calls": int(r[1]), "average_us": float(r[3]),
+                    "percent": float(r[4])} for r in rows if float(r[4]) >= 1.0]
+            return {"bound": "launch-latency", "source": f"profiles/{tag}_stream64_kernel_stats.csv",
+                    "dependent_launches_per_frame": 129, "kernels": ker,
+                    "note": "each launch is one wave's critical path (~890 VALU instructions at 0.233 of the 0.25 "
+                            "VALU-active ceiling) plus dispatch/drain; two concurrent chains hide part of the turn-around "
+                            "(DESIGN 4.2)"}
         except Exception:
             continue
     return None
@@ -221,6 +261,38 @@ def timed_batch(ctx, fdist, torch, steps, warmup, preroll):
     return elapsed, kern_ms_total, cov_all
 
 
+def timed_windows(ctx, fdist, torch, steps, warmup, preroll, windows=3):
+    """The 64-episodes-per-GPU figure: pre-roll + warm-up (untimed), then `windows` timed windows of `steps` frames that
+    all start from the SAME state (positions and velocities of every episode are put back in between), each bracketed by
+    barrier + synchronize like the headline.  Identical work per window, so their spread is run-to-run noise of the
+    launch-bound path and nothing else.  Returns a list of (wall seconds MAX over ranks, HIP-event kernel ms) and the
+    gathered coverage of the last window."""
+    def barrier():
+        fdist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(preroll + warmup):
+        ctx.step(1)
+    ctx.sync()
+    snap = [(ctx.get_positions(e), ctx.get_velocities(e)) for e in range(ctx.n_envs)]
+    out, cov_all = [], None
+    for w in range(windows):
+        for e, (p, v) in enumerate(snap):  # device state is the truth: both calls upload at once, nothing is deferred
+            ctx.set_positions(e, p)        # into the timed region
+            ctx.set_velocities(e, v)
+        barrier()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(steps):
+            ctx.step(1)
+        kern_ms_total = ctx.timer_stop()
+        cov_all = fdist.gather_rewards(ctx.coverage(), device="cuda")
+        barrier()
+        out.append((fdist.max_over_ranks(time.perf_counter() - t0, device="cuda"), kern_ms_total))
+    return out, cov_all
+
+
 class ParityCheck:
     """The checker after the timed region: episode `env` of the batch that was just timed against the C oracle.
     Full trajectory from the initial state when that is affordable on one host core (the oracle then runs in a thread
@@ -233,10 +305,11 @@ class ParityCheck:
 
         self.seed, self.thread, self.ref = int(seed), None, None
         if total_steps <= max_oracle_steps:
+            # the oracle thread is only CREATED here (the GPU state is captured now); start() runs it -- after every
+            # timed region of this process, so that no checker shares the host with a launch-bound timed loop
             self.mode = f"full trajectory, {total_steps} frames from the initial state"
             self.gpu = (ctx.get_positions(env), ctx.get_velocities(env))
             self.thread = threading.Thread(target=self._run, args=(seed, total_steps), daemon=True)
-            self.thread.start()
         else:
             self.mode = f"5 frames from the state after {total_steps} frames"
             o = OracleSim()
@@ -251,8 +324,13 @@ class ParityCheck:
     def _run(self, seed, steps):
         self.ref = oracle_trajectory(seed, steps)
 
+    def start(self):
+        if self.thread is not None and not self.thread.is_alive() and self.ref is None:
+            self.thread.start()
+
     def result(self):
         if self.thread is not None:
+            self.start()
             self.thread.join()
         (ph, vh), (po, vo) = self.gpu, self.ref
         exact = bool(np.array_equal(ph.view(np.uint32), po.view(np.uint32)) and
@@ -321,6 +399,9 @@ def run_rank(args):
         }
         if fused:
             out["limiter"] = limiter_from_profile()
+            out["valu_roofline"] = valu_roofline(out["limiter"], E, kern_ms)
+            if out["valu_roofline"]:
+                out["valu_frac_of_peak"] = out["valu_roofline"]["frac"]
         if not args.no_parity:
             parity_main = ParityCheck(ctx, E // 2, E // 2, args.preroll + args.warmup + args.steps)
     ctx.close()
@@ -328,24 +409,30 @@ def run_rank(args):
     # ---- secondary figure, every rank, after the headline's timed region: 64 episodes per GPU (BASELINE.json configs[2];
     #      at 8 GPUs this is configs[3]: 512 episodes sharded 8 x 64 with the coverage gather over RCCL)
     if not args.no_secondary:
-        E2, K2, W2 = 64, max(10, min(args.steps, 40)), max(3, min(args.warmup, 10))
+        E2, K2, W2, NW = 64, 100, max(3, min(args.warmup, 10)), 3
         ctx2 = fsim.FlingSim(n_envs=E2, device=local_rank, solver=fsim.FS_SOLVER_AUTO)
         for e, g in enumerate(fdist.episode_range(rank, E2)):
             setup_episode(ctx2.env(e), seed=g)
         ctx2.sync()
-        el2, k2_ms, cov2 = timed_batch(ctx2, fdist, torch, K2, W2, args.preroll)
+        wins, cov2 = timed_windows(ctx2, fdist, torch, K2, W2, args.preroll, NW)
         form2 = ctx2.last_kernel_form()
         if rank == 0:
+            rates = sorted(E2 * world * K2 / el for el, _ in wins)
+            el2, k2_ms = sorted(wins)[len(wins) // 2]          # the median window
             rate2 = E2 * world * K2 / el2
             entry = {"name": "64 x 64x64 episodes per GPU" + (f", {E2 * world} episodes over {world} GPUs" if world > 1 else ""),
                      "baseline_config": "configs[2]" + (" / configs[3] at 8 GPUs" if world == 8 else ""),
                      "value": rate2, "unit": "sim steps/s", "episodes_per_gpu": E2, "steps": K2, "warmup": W2,
+                     "windows": NW, "value_min": rates[0], "value_max": rates[-1],
+                     "timing": f"median of {NW} windows of {K2} frames, every window from the same state (frame "
+                               f"{args.preroll + W2}); no checker or other host work runs during them",
                      "ms_per_step": el2 / K2 * 1e3, "gpu_ms_per_step": k2_ms / K2,
                      "solver": "stream (AUTO)" if form2 in (fsim.FS_FORM_STREAM_EAGER, fsim.FS_FORM_STREAM_CODED, fsim.FS_FORM_STREAM_ELL,
                                                             fsim.FS_FORM_STREAM_GRID, fsim.FS_FORM_STREAM_GRIDL) else "fused (AUTO)",
                      "kernel_form": int(form2), "concurrent_launch_chains": int(ctx2.last_stream_groups()),
                      "calls": "one fs_step call per frame (as pyflex.step() is called); frames batched into one call run ~5 % faster",
                      "roofline_frac_equivalent": BYTES_PER_STEP * E2 / (k2_ms / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "limiter": stream_limiter_from_profile(),
                      "mean_coverage": float(cov2.mean().item())}
             if not args.no_parity:
                 parity_2 = ParityCheck(ctx2, E2 // 2, E2 // 2, args.preroll + W2 + K2)
@@ -356,6 +443,11 @@ def run_rank(args):
         ctx2.close()
 
     if rank == 0:
+        # every timed region of the solver is over: now the checkers run (one host core each, side by side), then the
+        # CPU baseline (all cores, nothing else running), then the perception and evaluation-loop legs
+        for chk in (parity_main, parity_2):
+            if chk is not None:
+                chk.start()
         if parity_main is not None:
             out["parity"] = parity_main.result()
             out["parity_checked"] = bool(out["parity"]["bit_exact"])

@@ -6,12 +6,14 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r"""
 import os, sys, json
 import numpy as np
+import pytest
 sys.path.insert(0, os.environ["FS_ROOT"])
 import torch
 from flingbot_amd import distributed as fdist
@@ -85,6 +87,7 @@ def test_single_rank_helpers_need_no_process_group():
 SHARDED_WORKER = r"""
 import os, sys, json
 import numpy as np
+import pytest
 sys.path.insert(0, os.environ["FS_ROOT"])
 import torch
 from flingbot_amd import distributed as fdist
@@ -190,3 +193,142 @@ def test_bench_starts_its_own_ranks_without_world_size():
     # (the launcher terminates the other ranks as soon as one fails, so the second rank's message may or may not get out)
     assert 1 <= out.stderr.count("no HIP device visible") <= 2, out.stderr[-2000:]
     assert "launch with torch.distributed.run" not in out.stderr
+
+
+BENCH_WORKER = r"""
+# One rank of `bench.py --gpus 2` on a machine without a GPU: bench.run_rank's OWN control flow (barriers, timed windows,
+# gathers, rank-0-only JSON) with the solver context replaced at the fsim.FlingSim seam by a recording stub, torch.cuda's
+# three calls made no-ops and the process group on gloo.  Nothing in bench.py knows about this.
+import json, os, sys, time, types
+import numpy as np
+import pytest
+sys.path.insert(0, os.environ["FS_ROOT"])
+import torch
+from flingbot_amd import distributed as fdist
+from flingbot_amd import sim as fsim
+
+RANK = int(os.environ["RANK"])
+LOG = []                                             # (event, detail) in program order of THIS rank
+
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: LOG.append(("set_device", int(d)))
+torch.cuda.synchronize = lambda *a, **k: LOG.append(("cuda_sync", None))
+_init, _gather, _max, _barrier = fdist.init_from_env, fdist.gather_rewards, fdist.max_over_ranks, fdist.barrier
+def init_from_env(backend=None):
+    LOG.append(("init", backend))
+    return _init("gloo")
+def gather_rewards(r, device=None):
+    LOG.append(("gather", device)); return _gather(r, None)
+def max_over_ranks(v, device=None):
+    LOG.append(("max", device)); return _max(v, None)
+def barrier():
+    LOG.append(("barrier", None)); return _barrier()
+fdist.init_from_env, fdist.gather_rewards, fdist.max_over_ranks, fdist.barrier = init_from_env, gather_rewards, max_over_ranks, barrier
+
+
+class StubSim:
+    instances = []
+    def __init__(self, n_envs=1, device=0, solver=0, **kw):
+        self.n_envs, self.device, self.solver = n_envs, device, solver
+        self.pos = [None] * n_envs
+        self.first_pos = [None] * n_envs
+        self.steps = 0
+        StubSim.instances.append(self)
+        LOG.append(("create", (n_envs, device, solver)))
+    def env(self, e):
+        sim = self
+        class View:
+            def set_scene(self, p): pass
+            def get_positions(self): return np.full(4 * 4096, 8192.0, np.float32)
+            def set_positions(self, p):
+                sim.pos[e] = np.array(p, np.float32)
+                if sim.first_pos[e] is None: sim.first_pos[e] = sim.pos[e].copy()
+            def set_velocities(self, v): pass
+        return View()
+    def sync(self): LOG.append(("ctx_sync", None))
+    def step(self, n=1):
+        self.steps += n; LOG.append(("step", n)); time.sleep(0.001 * (1 + 2 * RANK))      # rank 1 is the slow one
+    def timer_start(self): LOG.append(("timer_start", None)); self._t = time.perf_counter()
+    def timer_stop(self): LOG.append(("timer_stop", None)); return (time.perf_counter() - self._t) * 1e3
+    def coverage(self): return np.arange(self.n_envs, dtype=np.float64) + 1000.0 * RANK
+    def last_kernel_form(self): return fsim.FS_FORM_FUSED_GRID64 if self.n_envs != 64 else fsim.FS_FORM_STREAM_GRIDL
+    def last_stream_groups(self): return 2
+    def get_positions(self, e=0): return self.pos[e]
+    def get_velocities(self, e=0): return np.zeros(3 * 4096, np.float32)
+    def set_positions(self, e, p): self.pos[e] = np.array(p, np.float32)
+    def set_velocities(self, e, v): pass
+    def close(self): LOG.append(("close", self.n_envs))
+
+fsim.FlingSim = StubSim
+import bench
+args = types.SimpleNamespace(episodes=4, steps=3, warmup=1, preroll=2, solver=2, no_parity=True, no_cpu_baseline=True,
+                             no_secondary=False, no_eval_loop=True, gpus=2)
+bench.run_rank(args)
+seeds_ok = all(np.array_equal(s.first_pos[e], bench.initial_state(RANK * s.n_envs + e, 8192.0).ravel())
+               for s in StubSim.instances for e in range(s.n_envs))
+with open(os.path.join(os.environ["FS_OUT"], f"rank{RANK}.json"), "w") as fh:
+    json.dump({"log": LOG, "seeds_ok": bool(seeds_ok), "sizes": [s.n_envs for s in StubSim.instances]}, fh)
+"""
+
+
+def test_bench_run_rank_control_flow_two_ranks(tmp_path):
+    """8-GPU readiness without the hardware: `bench.run_rank` itself runs as two gloo ranks with the solver context stubbed
+    at the fsim.FlingSim seam (inside this test only).  Checked: one JSON line, from rank 0 only; n_gpus / weak scaling /
+    whole-job value from the MAX over ranks; every rank sets its own global episodes up (rank r: seeds r E .. r E + E - 1);
+    the headline's timed region is barrier + synchronize -> timer -> exactly K steps -> timer -> coverage gather ->
+    barrier + synchronize -> max-over-ranks; the secondary entry is 64 episodes per rank = 128 over 2 GPUs (configs[3]'s
+    shape: 512 at 8), three windows of 100 frames, on every rank."""
+    import json
+
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FS_ROOT=ROOT, FS_OUT=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(out)
+    lines0 = [l for l in outs[0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]   # rank 0 prints, rank 1 is silent
+    rec = json.loads(lines0[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["episodes_per_gpu"] == 4 and rec["config"]["parallelism"] == "episodes x2"
+    assert rec["unit"] == "sim steps/s" and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    # whole-job value = all ranks' episode-steps / the SLOWEST rank's time: rank 1 sleeps 3 ms per step, rank 0 1 ms
+    assert rec["value"] == pytest.approx(4 * 2 * 3 / (rec["ms_per_step"] * 3e-3))
+    assert rec["ms_per_step"] >= 3.0
+    assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["kernel"] == "fs_k_fused_grid64"
+    assert rec["mean_coverage"] == pytest.approx(np.mean([0, 1, 2, 3, 1000, 1001, 1002, 1003]))   # both ranks' rewards, gathered
+    assert "cpu_baseline" not in rec and "eval_loop" not in rec                                 # N = 1 only
+    sec = rec["configs"][1]
+    assert sec["episodes_per_gpu"] == 64 and "128 episodes over 2 GPUs" in sec["name"] and sec["windows"] == 3
+    assert sec["steps"] == 100 and sec["value_min"] <= sec["value"] <= sec["value_max"]
+    assert sec["value"] == pytest.approx(64 * 2 * 100 / (sec["ms_per_step"] * 0.1)) and sec["ms_per_step"] >= 3.0
+    assert sec["mean_coverage"] == pytest.approx((np.arange(64).sum() * 2 + 1000.0 * 64) / 128)
+    for r in range(2):
+        got = json.load(open(tmp_path / f"rank{r}.json"))
+        assert got["seeds_ok"] and got["sizes"] == [4, 64]
+        log = [tuple(x) for x in got["log"]]
+        assert log[0] == ("set_device", r) and log[1] == ("init", "nccl")
+        ev = [e for e, _ in log]
+        # headline: pre-roll + warm-up, then the bracketed window of exactly K = 3 steps
+        t0 = ev.index("timer_start")
+        assert ev[:t0].count("step") == 2 + 1
+        assert ev[t0 - 3:t0] == ["barrier", "ctx_sync", "cuda_sync"]
+        assert ev[t0:t0 + 10] == ["timer_start", "step", "step", "step", "timer_stop", "gather", "barrier", "ctx_sync",
+                                  "cuda_sync", "max"]
+        assert log[t0 + 5] == ("gather", "cuda") and log[t0 + 9] == ("max", "cuda")
+        # secondary: three bracketed windows of 100 steps each on the 64-episode context
+        starts = [i for i, e in enumerate(ev) if e == "timer_start"][1:]
+        assert len(starts) == 3
+        for i in starts:
+            assert ev[i - 3:i] == ["barrier", "ctx_sync", "cuda_sync"]
+            assert ev[i + 1:i + 101] == ["step"] * 100 and ev[i + 101:i + 107] == ["timer_stop", "gather", "barrier", "ctx_sync",
+                                                                                "cuda_sync", "max"]
+        assert ev[-1] == "barrier" or ev[-2:] == ["close", "barrier"] or "barrier" in ev[-3:]
