@@ -536,6 +536,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: no 64-episode figure, no perception leg")
     ap.add_argument("--no-eval-loop", action="store_true", help="skip the evaluation-loop leg (configs[4], ~50 s)")
+    ap.add_argument("--timeout", type=float, default=1800.0,
+                    help="seconds after which self-launched ranks (--gpus N without WORLD_SIZE) are stopped: a hung rendezvous ends")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -544,7 +546,7 @@ def main():
         # made any GPU call (it never makes one: flingbot_amd.launch is standard library only)
         from flingbot_amd.launch import launch_local_ranks
 
-        sys.exit(launch_local_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+        sys.exit(launch_local_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], timeout=args.timeout))
     if int(world_env or "1") != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run, or leave "
                          f"WORLD_SIZE unset and bench.py starts the ranks itself")

@@ -27,9 +27,17 @@ FsTopologyDev::~FsTopologyDev() {
     if (slab) (void)hipFree(slab);
 }
 
+// every stream the context launches on: its own and the concurrent launch chains' (fs_step_stream).  The chains join the
+// context's stream through events after a complete launch sequence; after an error in the middle of one they may not have.
+void fs_sync_all_streams(fs_ctx *ctx) {
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int g = 0; g < FS_MAX_STREAM_GROUPS; ++g)
+        if (ctx->aux_streams[g]) (void)hipStreamSynchronize(ctx->aux_streams[g]);
+}
+
 fs_ctx::~fs_ctx() {
     (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize(stream);
+    fs_sync_all_streams(this);
     for (auto &e : envs) {
         if (e.slab) (void)hipFree(e.slab);
         if (e.d_picked) (void)hipFree(e.d_picked);
@@ -52,6 +60,8 @@ fs_ctx::~fs_ctx() {
         if (aux_events[g]) (void)hipEventDestroy(aux_events[g]);
     }
     if (fork_event) (void)hipEventDestroy(fork_event);
+    if (adv_ev0) (void)hipEventDestroy(adv_ev0);
+    if (adv_ev1) (void)hipEventDestroy(adv_ev1);
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
     if (stream) (void)hipStreamDestroy(stream);
@@ -72,7 +82,7 @@ void *fs_stage(fs_ctx *ctx, size_t bytes) {
 // synchronises the device, which a call per chunk of a few simulation steps cannot afford
 void *fs_loop_scratch(fs_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->loop_scratch_bytes) return ctx->loop_scratch;
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    fs_sync_all_streams(ctx);
     if (ctx->loop_scratch) (void)hipFree(ctx->loop_scratch);
     ctx->loop_scratch = nullptr;
     ctx->loop_scratch_bytes = 0;
@@ -281,7 +291,7 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     FsEnv *e = get_env(ctx, env, false);
     if (!e) return FS_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    fs_sync_all_streams(ctx);  // the episode's slab is about to be freed: nothing may still run on it, on any stream
     FsHostScene scene;
     std::string err = fs_build_scene(scene, scene_params, n_params, verts, n_vert_floats, stretch, n_stretch_ints, bend,
                                      n_bend_ints, shear, n_shear_ints, faces, n_face_ints);

@@ -111,6 +111,10 @@ struct fs_ctx {
     size_t loop_scratch_bytes = 0;
     double *d_coverage = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // fs_timer_start / fs_timer_stop
+    // fs_advance's own stopwatch (fs_advance_timing): device time between its first and last launch, wall time of the call
+    hipEvent_t adv_ev0 = nullptr, adv_ev1 = nullptr;
+    double adv_gpu_ms = 0.0, adv_wall_ms = 0.0, adv_prep_ms = 0.0;
+    long long adv_calls = 0, adv_sequences = 0;
 
     ~fs_ctx();
 };
@@ -118,6 +122,7 @@ struct fs_ctx {
 void fs_set_error(const std::string &msg);
 bool fs_hip_ok(hipError_t e, const char *what);
 void *fs_stage(fs_ctx *ctx, size_t bytes);
+void fs_sync_all_streams(fs_ctx *ctx);  // the context's stream and the launch chains' streams
 void *fs_loop_scratch(fs_ctx *ctx, size_t bytes);
 
 // solver back-ends

@@ -13,11 +13,14 @@
 //     their registers and their address arithmetic are gone.
 //   * Positions are SoA planes in LDS (x | y | z | invMass, 16 KiB each).  The thread's particles are rows w, w+16,
 //     w+32, w+48; rows 16 apart are 16 x 256 B apart, so ONE ds_read2st64_b32 returns the same neighbour slot of TWO
-//     of the thread's particles in a register PAIR -- the operand shape of the packed-fp32 VALU instructions.
-//   * Two particles per trip on v_pk_add/mul/fma_f32: the whole spring (difference, length^2, the spelled-out
-//     reciprocal root, scale, accumulation) is evaluated for both at once, bit for bit the operations of fs_spring in
-//     the same order per particle.  A packed instruction costs ~1.6 scalar ones on this part (scripts/ubench), and two
-//     slots are interleaved per scheduling region to cover its latency.
+//     of the thread's particles (P, Q) in a register PAIR: 36 LDS instructions per pair of particles and iteration
+//     instead of 2 x 24, conflict-free (a wave reads one row).
+//   * Two particles per trip as TWO INDEPENDENT SCALAR STREAMS (fg_spring_pq: .x = P, .y = Q): the whole spring
+//     (difference, length^2, the spelled-out reciprocal root, scale, accumulation) is evaluated for both, bit for bit the
+//     operations of fs_spring_fast in the same order per particle, and each stream fills the other's dependency stalls.
+//     (The register pairs are also the operand shape of v_pk_add/mul/fma_f32, and the kernel was first written on those:
+//     bit-identical and 14 % slower -- a packed multiply / add costs 1.5-1.7 scalar ones on this part, scripts/ubench --
+//     so the packed form is NOT what ships; EXPERIMENTS.md "packed fp32".)
 //   * No per-spring bookkeeping.  A slot that leaves the grid gets stiffness 0 (its scale becomes +-0, which leaves
 //     the accumulators untouched), the constraint count of a particle is its number of in-grid slots, and the
 //     `length > 0` test of fs_spring -- false only for coincident particles -- is a minimum over the squared lengths
@@ -85,7 +88,7 @@ __device__ __forceinline__ float fg_load1(unsigned a) {
 // kh = stiffness / 2, or 0 for a slot outside the grid: the scale then is +-0 and the accumulators stay as they are.
 // (A packed version on v_pk_add/mul/fma_f32 -- the (P, Q) register pairs are exactly its operand shape -- was built and
 // measured: bit-identical, 14 % SLOWER.  On this part a packed fp32 instruction occupies the VALU for as long as two
-// scalar ones, so packing buys no throughput and lengthens the dependent chains)
+// scalar ones, so packing buys no throughput and lengthens the dependent chains; EXPERIMENTS.md "packed fp32".)
 __device__ __forceinline__ void fg_spring_pq(FgAcc2 &acc, fs_f2 xi0, fs_f2 xi1, fs_f2 xi2, fs_f2 xj0, fs_f2 xj1, fs_f2 xj2, float LP,
                                              float LQ, float kP, float kQ, fs_f2 &lprev, bool fold) {
     const float ex = xi0.x - xj0.x, fx = xi0.y - xj0.y;

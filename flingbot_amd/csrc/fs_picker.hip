@@ -12,6 +12,8 @@
 // ones still moving.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -271,6 +273,7 @@ Plan plan_movep(const FsShapesDev &shapes, const double *targets, const int *gra
 // (MoveJointsException in the reference); the trajectories are executed up to the limit in that case.
 static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *targets, const int *grasp, double speed,
                             int limit, int min_steps, double eps, int *iterations_out, bool f32_targets) {
+    if (ctx) ctx->last_movep_steps = 0;  // an early error return must not leave the previous call's count behind
     if (!ctx || n <= 0 || !envs || !targets || !grasp) { fs_set_error("fs_movep: bad arguments"); return FS_ERR_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
     int S = -1;
@@ -415,13 +418,16 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
         return FS_ERR_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));
+    const auto wall0 = std::chrono::steady_clock::now();
+    ctx->last_movep_steps = 0;
     std::vector<int> movers, waiters;
+    std::vector<char> listed((size_t)ctx->n_envs, 0);
     int S = -1;
     for (int a = 0; a < n; ++a) {
         FsEnv *e = picker_env(ctx, envs[a]);
         if (!e) return FS_ERR_ARG;
-        for (int b = 0; b < a; ++b)
-            if (envs[b] == envs[a]) { fs_set_error("fs_advance: an episode is listed twice"); return FS_ERR_ARG; }
+        if (listed[envs[a]]) { fs_set_error("fs_advance: an episode is listed twice"); return FS_ERR_ARG; }
+        listed[envs[a]] = 1;
         if (kind[a] == 0) {
             if (!targets || !grasp || !speed || !min_steps || !f32) { fs_set_error("fs_advance: movep arguments missing"); return FS_ERR_ARG; }
             if (!e->picker_ready) { fs_set_error("fs_advance: call fs_picker_reset first"); return FS_ERR_STATE; }
@@ -513,6 +519,12 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
     if (!dev) return FS_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(dev, blob.data(), off, hipMemcpyHostToDevice));
+    if (!ctx->adv_ev0) {
+        HIP_TRY(hipEventCreate(&ctx->adv_ev0));
+        HIP_TRY(hipEventCreate(&ctx->adv_ev1));
+    }
+    HIP_TRY(hipEventRecord(ctx->adv_ev0, ctx->stream));
+    const auto wall1 = std::chrono::steady_clock::now();
     int **d_picked = (int **)(dev + o_picked);
     float **d_saved = (float **)(dev + o_saved);
     const double *d_tol = (const double *)(dev + o_tol);
@@ -548,9 +560,20 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
     hipError_t err = hipSuccess;
     if (rc == FS_OK && nw > 0)
         err = hipMemcpyAsync(w_out.data(), d_w_steps, sizeof(int) * 2 * nw, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess) err = hipEventRecord(ctx->adv_ev1, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     if (rc != FS_OK) return rc;
     HIP_TRY(err);
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->adv_ev0, ctx->adv_ev1) == hipSuccess) ctx->adv_gpu_ms += ms;
+        const auto wall2 = std::chrono::steady_clock::now();
+        ctx->adv_wall_ms += std::chrono::duration<double, std::milli>(wall2 - wall0).count();
+        ctx->adv_prep_ms += std::chrono::duration<double, std::milli>(wall1 - wall0).count();
+        ctx->adv_calls += 1;
+        ctx->adv_sequences += (long long)n_seq;
+    }
+    for (int q = 0; q < nm; ++q) ctx->last_movep_steps += (long long)plans[q].cmds.size();
     for (int q = 0; q < nw; ++q) {
         const int a = waiters[q];
         if (w_budget[q] == 0) continue;
@@ -571,6 +594,16 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
             e.shapes.pos[k] = FsVec4{cm.back().new_pos[k][0], cm.back().new_pos[k][1], cm.back().new_pos[k][2], r};
         }
     }
+    return FS_OK;
+}
+
+// fs_advance's stopwatch since the context was created: out[0] calls, [1] launch sequences, [2] wall ms inside the calls,
+// [3] device ms between a call's first and last launch (the stream is idle when a call starts), [4] wall ms a call spends
+// before its first launch (planning, tables, upload)
+extern "C" int fs_advance_timing(const fs_ctx *ctx, double *out5) {
+    if (!ctx || !out5) return FS_ERR_ARG;
+    out5[0] = (double)ctx->adv_calls; out5[1] = (double)ctx->adv_sequences; out5[2] = ctx->adv_wall_ms;
+    out5[3] = ctx->adv_gpu_ms; out5[4] = ctx->adv_prep_ms;
     return FS_OK;
 }
 

@@ -137,6 +137,16 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             c.st = st;
         }
     }
+    // From the fork to the join an early return would leave chains running on the episodes' slabs while the caller believes
+    // the context's stream is all there is to wait for: every error in between waits for ALL streams before it returns.
+    bool forked = false;
+#define FORK_TRY(call)                                    \
+    do {                                                  \
+        if (!fs_hip_ok((call), #call)) {                  \
+            if (forked) fs_sync_all_streams(ctx);         \
+            return FS_ERR_HIP;                            \
+        }                                                 \
+    } while (0)
     if (groups > 1) {  // chain 0 stays on the context's stream, the others fork from it
         for (int g = 1; g < groups; ++g) {
             if (!ctx->aux_streams[g]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_streams[g], hipStreamNonBlocking));
@@ -145,7 +155,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         }
         if (!ctx->fork_event) HIP_TRY(hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(ctx->fork_event, st));
-        for (int g = 1; g < groups; ++g) HIP_TRY(hipStreamWaitEvent(chain[g].st, ctx->fork_event, 0));
+        forked = true;
+        for (int g = 1; g < groups; ++g) FORK_TRY(hipStreamWaitEvent(chain[g].st, ctx->fork_event, 0));
     }
     auto iter_kernel = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
     if (grid_form) iter_kernel = fs_k_iterate_grid;
@@ -174,6 +185,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         }
     };
     for (int f = 0; f < n_steps; ++f) {
+        if (f > 0) FORK_TRY(hipGetLastError());  // a failed launch shows up here, one frame (129 launches) later at most
         for (int sub = 0; sub < substeps; ++sub) {
             if (merged) {
                 // (K_BOUND_MID: the finalize of the previous substep -- also the previous frame's last one -- rides along)
@@ -190,11 +202,12 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     }
     if (merged) launch(K_BOUND_LAST, 0, flip_end);
     for (int g = 1; g < groups; ++g) {
-        HIP_TRY(hipEventRecord(ctx->aux_events[g], chain[g].st));
-        HIP_TRY(hipStreamWaitEvent(st, ctx->aux_events[g], 0));
+        FORK_TRY(hipEventRecord(ctx->aux_events[g], chain[g].st));
+        FORK_TRY(hipStreamWaitEvent(st, ctx->aux_events[g], 0));
     }
     ctx->last_stream_groups = groups;
-    HIP_TRY(hipGetLastError());
+    FORK_TRY(hipGetLastError());
+#undef FORK_TRY
     return FS_OK;
 }
 

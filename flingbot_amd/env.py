@@ -183,12 +183,13 @@ class BatchedFlingEnv:
         self.init_coverage = np.zeros(self.sim.n_envs)
         self.unpaid_steps = 0  # simulation steps the lock-step path does not count either (the step inside set_scene)
 
-    def episode_program(self, e, task):
+    def episode_program(self, e, task, max_actions=None):
         """One episode in slot e -- SimEnv.reset (simEnv.py:663-697: set_scene(config, state), initial coverage, pickers,
         reset_end_effectors, one step, grasp off) and then SimEnv.step (simEnv.py:477-515) until it terminates -- written as
         the reference's straight-line code with a request wherever it needs the simulator, the policy or a reduction (see
         schedule.run_programs; evaluate.run_tasks provides the services "observe", "act", "coverage", "snapshot",
-        "max_disp").  Returns {'coverage': [initial, after step 1, ...] (absolute areas), 'actions': [primitive or None, ...]}."""
+        "max_disp").  max_actions: the episode also ends after that many actions (None: episode_length alone).
+        Returns {'coverage': [initial, after step 1, ...] (absolute areas), 'actions': [primitive or None, ...]}."""
         from . import schedule as sch
 
         e = int(e)
@@ -229,7 +230,8 @@ class BatchedFlingEnv:
                 prim.terminate[e] = True
             curr = yield ("coverage",)
             self.timestep[e] += 1
-            self.terminate[e] = prim.terminate[e] or self.timestep[e] >= self.episode_length
+            limit = self.episode_length if max_actions is None else min(self.episode_length, int(max_actions))
+            self.terminate[e] = prim.terminate[e] or self.timestep[e] >= limit
             rec["coverage"].append(float(curr))
             rec["actions"].append(action)
             rec.setdefault("rewards", []).append(float(curr - prev))

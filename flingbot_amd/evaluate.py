@@ -56,7 +56,7 @@ def run_episodes(policy, env, tasks, max_steps=None, fold=True):
     }
 
 
-def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32):
+def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32, max_steps=None):
     """The evaluation loop the way the reference actually runs it: every environment steps on its own, the policy acts for
     whichever environments are ready (utils.step_env, utils.py:394-418: `ray.wait` on the step futures), and an environment
     whose episode ends pulls the NEXT task by itself (SimEnv.step -> on_episode_end -> reset -> get_task_fn, tasks.py
@@ -66,7 +66,14 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32):
     simulation step (fs_advance).  Episodes are independent and every stage is deterministic per episode, so the
     statistics equal run_episodes' on the same tasks exactly (tests/test_evaluate_gpu.py); what changes is that no episode
     waits for another one -- neither inside an action nor between actions nor at the end of an episode.
-    Returns run_episodes' dictionary (arrays ordered by task index)."""
+    PRECONDITION of "equal to run_episodes exactly": the value nets' forward must not depend on which episodes share a
+    batch -- the "act" service batches whichever slots are ready.  The hand-written forward (fs_value_net_forward, `_hip`
+    set: obs_dim 64) computes every image on its own and is batch-invariant; the PyTorch / MIOpen fallback may pick another
+    algorithm for another batch size and flip an arg-max, so with a net on the fallback every episode gets a forward of its
+    own here (slower, same guarantee) and a warning says so.
+    max_steps: at most that many actions per episode (run_episodes' argument of the same name; None = env.episode_length).
+    Returns run_episodes' dictionary (arrays ordered by task index) plus `scheduler` (launch statistics of the run);
+    `simulation_steps` excludes the step inside every set_scene, as the lock-step path's count does."""
     from collections import deque
 
     from . import nets, schedule as sch
@@ -81,10 +88,16 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32):
     queue = deque(enumerate(tasks))
     records = {}
 
+    batch_invariant = all(getattr(net, "_hip", None) is not None for net in policy.value_nets.values())
+    if not batch_invariant:
+        import warnings
+        warnings.warn("run_tasks: a value net runs on the PyTorch fallback (no fs_value_net_forward for its observation "
+                      "size): one forward per episode, so that results do not depend on which slots are ready together")
+
     def slot_program(slot):
         while queue:
             ti, task = queue.popleft()
-            records[ti] = yield from env.episode_program(slot, task)
+            records[ti] = yield from env.episode_program(slot, task, max_actions=max_steps)
 
     def observe(reqs):
         es = [e for e, _ in reqs]
@@ -93,7 +106,10 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32):
 
     def act(reqs):
         with torch.no_grad():
-            maps = policy.act([a[0] for _, a in reqs], keep_on_device=True)
+            if batch_invariant:
+                maps = policy.act([a[0] for _, a in reqs], keep_on_device=True)
+            else:
+                maps = [policy.act([a[0]], keep_on_device=True)[0] for _, a in reqs]
         return [{k: v.to(env.device) for k, v in m.items()} for m in maps]
 
     def coverage(reqs):
@@ -133,7 +149,8 @@ def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=None, **k
     """BASELINE.json configs[3] for the evaluation loop: global episode g runs on rank g // episodes_per_rank (one process
     per GPU, launched with torch.distributed.run); the only exchange is the all_gather of the per-episode initial / final
     coverages at the end (RCCL over xGMI, 4 bytes per episode).  Returns this rank's statistics plus `all_init_coverage`
-    / `all_final_coverage` ordered by global episode id."""
+    / `all_final_coverage` ordered by global episode id.  kwargs go to the runner: both run_tasks (the default; returns the
+    extra key `scheduler`) and run_episodes take `max_steps`."""
     from . import distributed as fdist
 
     runner = run_tasks if runner is None else runner  # (run_tasks streams the rank's tasks through its GPU context's slots)

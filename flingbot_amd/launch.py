@@ -25,16 +25,51 @@ def free_port(host="127.0.0.1"):
     return port
 
 
-def launch_local_ranks(n_ranks, script, argv, env=None, timeout=None, master_addr="127.0.0.1", master_port=None):
+def exit_status(returncode):
+    """A child's returncode as an exit status for sys.exit: a rank killed by signal s (returncode -s) becomes 128 + s, the
+    shell's convention, instead of whatever sys.exit would make of a negative number."""
+    return 128 - returncode if returncode < 0 else returncode
+
+
+def launch_local_ranks(n_ranks, script, argv, env=None, timeout=None, master_addr="127.0.0.1", master_port=None,
+                       attempts=3):
     """Start `n_ranks` copies of `python script argv...`, rank r with RANK = LOCAL_RANK = r, and wait for all of them.
     stdout / stderr are inherited (rank 0 prints the result line).  If a rank fails the others are terminated.
-    Returns the first non-zero exit code, or 0."""
+    Returns the first non-zero exit status (128 + signal for a rank that was killed; 124 after `timeout` seconds), or 0.
+    master_port: the rendezvous port (default: MASTER_PORT of `env` if set, else a free one found here).  A port found
+    here can be taken by somebody else before rank 0 binds it; the ranks then fail within seconds and the launch is
+    repeated on another port (`attempts` times; never when the caller chose the port)."""
     if n_ranks < 1:
         raise ValueError("n_ranks must be >= 1")
-    base = dict(os.environ if env is None else env)
+    src = os.environ if env is None else env
+    chosen = master_port or src.get("MASTER_PORT")
+    rc = 0
+    for attempt in range(1 if chosen else max(1, attempts)):
+        port = int(chosen) if chosen else free_port(master_addr)
+        rc = _launch_once(n_ranks, script, argv, src, timeout, master_addr, port)
+        # a rendezvous that lost its port dies with EADDRINUSE in rank 0 and the port is still somebody else's afterwards;
+        # any other failure is the script's own and is not repeated
+        if rc == 0 or rc == 124 or chosen or not _port_in_use(master_addr, port):
+            break
+    return rc
+
+
+def _port_in_use(host, port):
+    s = socket.socket()
+    try:
+        s.bind((host, port))
+        return False
+    except OSError:
+        return True
+    finally:
+        s.close()
+
+
+def _launch_once(n_ranks, script, argv, env, timeout, master_addr, master_port):
+    base = dict(env)
     base["WORLD_SIZE"] = str(n_ranks)
     base["MASTER_ADDR"] = master_addr
-    base["MASTER_PORT"] = str(master_port or free_port(master_addr))
+    base["MASTER_PORT"] = str(master_port)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this image (see README)
     procs = []
     for r in range(n_ranks):
@@ -51,7 +86,7 @@ def launch_local_ranks(n_ranks, script, argv, env=None, timeout=None, master_add
                     continue
                 pending.remove(p)
                 if code != 0 and rc == 0:
-                    rc = code
+                    rc = exit_status(code)
             if rc != 0 or (deadline is not None and time.monotonic() > deadline):
                 if rc == 0:
                     rc = 124

@@ -239,10 +239,16 @@ class SpatialValueNet(nn.Module):
         return lib, (params.to(dev) if dev.type == 'cuda' else params)
 
 
+def _centre_window(size, extent):
+    """First index of the `extent`-wide window that crop_center cuts out of `size` samples."""
+    return size // 2 - extent // 2
+
+
 def crop_center(img, crop):
-    startx = img.shape[1] // 2 - (crop // 2)
-    starty = img.shape[0] // 2 - (crop // 2)
-    return img[starty:starty + crop, startx:startx + crop, ...]
+    """Module surface of learning/nets.py (:144-147), semantics fixed by it: the crop x crop window around the centre of
+    the first two axes (centre = size // 2, window start = centre - crop // 2)."""
+    r0, c0 = _centre_window(img.shape[0], crop), _centre_window(img.shape[1], crop)
+    return img[r0:r0 + crop, c0:c0 + crop, ...]
 
 
 def pad(img, size):
@@ -260,22 +266,39 @@ def resize_nearest(img, dim):
     return img[ys][:, xs]
 
 
-def transform(img, rotation: float, scale: float, dim: int):
-    """One rotated / scaled copy of the observation (nets.py:155-174): (C,H,W) tensor -> (W,H,C) array, cubic-spline
-    rotation about the image centre (scipy.ndimage.rotate, reshape=False, mode='nearest'), centre crop (scale < 1) or
-    replicate pad (scale > 1) to int(scale * size), nearest resize to dim x dim, back to channel-first."""
-    if len(img.shape) == 3 and (img.shape[-1] == img.shape[-2]):
-        img = img.permute(2, 1, 0)
-    img = nd.rotate(input=img, angle=rotation, reshape=False, mode='nearest')
-    new_dim = int(scale * img.shape[0])
+def scale_window_indices(size, scale, dim):
+    """Which of the `size` samples of a rotated plane each of the `dim` output samples shows after the reference's
+    crop / pad + nearest-resize chain (nets.py:163-171), as ONE index vector: the chain cuts (scale < 1) or replicates
+    (scale > 1) the plane to a window [start, start + extent) and the nearest resize then picks window sample
+    floor(d * extent / dim); replicated border samples are the clamped ones.  fs_prepare_image's gather kernel uses the
+    same map (csrc/fs_image.hip)."""
+    target = int(scale * size)
     if scale < 1:
-        img = crop_center(img, new_dim)
+        start = _centre_window(size, target)
+        extent = min(target, size - start)
     elif scale > 1:
-        img = pad(img, new_dim)
-    img = resize_nearest(img, dim)
-    if len(img.shape) == 3:
-        img = img.swapaxes(-1, 0)
-    return torch.tensor(np.ascontiguousarray(img))
+        border = (target - size) // 2
+        start, extent = -border, size + 2 * border
+    else:
+        start, extent = 0, size
+    picked = np.minimum((np.arange(dim) * (extent / dim)).astype(np.int64), extent - 1)
+    return np.clip(start + picked, 0, size - 1)
+
+
+def transform(img, rotation: float, scale: float, dim: int):
+    """One rotated / scaled copy of the observation, the host form of learning/nets.py:155-174 (the hot path is
+    fs_prepare_image on the device): channel-first square tensor -> (W, H, C) array (the reference's permute(2, 1, 0)),
+    scipy's cubic-spline rotation about the centre with mode='nearest', then the crop / pad + nearest-resize chain as
+    one gather (scale_window_indices), back to channel-first."""
+    channel_first = len(img.shape) == 3 and (img.shape[-1] == img.shape[-2])
+    plane = img.permute(2, 1, 0) if channel_first else img
+    rotated = nd.rotate(input=plane, angle=rotation, reshape=False, mode='nearest')
+    rows = scale_window_indices(rotated.shape[0], scale, dim)
+    cols = scale_window_indices(rotated.shape[1], scale, dim) if rotated.shape[1] != rotated.shape[0] else rows
+    out = rotated[rows][:, cols]
+    if out.ndim == 3:
+        out = out.swapaxes(-1, 0)
+    return torch.tensor(np.ascontiguousarray(out))
 
 
 def transform_async(*args, **kwargs):

@@ -98,6 +98,7 @@ def load_library(build_if_missing=True):
         "fs_picker_reset": (ci, [vp, ci, C.c_double, C.c_double]),
         "fs_picker_set_radius": (ci, [vp, ci, C.c_double]),
         "fs_last_movep_steps": (C.c_longlong, [vp]),
+        "fs_advance_timing": (ci, [vp, C.POINTER(C.c_double)]),
         "fs_picker_get_picked": (ci, [vp, ci, ip, ci]),
         "fs_movep": (ci, [vp, ci, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
@@ -301,6 +302,12 @@ class FlingSim:
                                      _ip(lim), _ip(ms), _ip(f3), _ip(st), float(eps), tol.ctypes.data_as(dp), int(cap_min), int(cap),
                                      _ip(prog), _ip(status), _ip(steps)))
         return prog, status, steps
+
+    def advance_timing(self):
+        """fs_advance's stopwatch since the context was created: dict(calls, sequences, wall_ms, gpu_ms, prep_ms)."""
+        out = np.zeros(5, np.float64)
+        self._ck(self.lib.fs_advance_timing(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return dict(calls=int(out[0]), sequences=int(out[1]), wall_ms=float(out[2]), gpu_ms=float(out[3]), prep_ms=float(out[4]))
 
     def cloth_stats(self, envs):
         """[n,3] float32: min height, max height, max |velocity component| per episode (device reductions)."""

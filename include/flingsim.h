@@ -162,8 +162,9 @@ int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, double partic
    (flex_utils.py:154-155); without this call the threshold uses the float32 radius pyflex.add_sphere stored for shape 0.
    fs_picker_reset clears it. */
 int fs_picker_set_radius(fs_ctx *ctx, int env, double picker_radius);
-/* simulation steps, summed over the episodes, that the most recent fs_movep / fs_movep_batch* call executed (movep
-   iterations that find the pickers on their targets do not step the simulation, flex_utils.py:231-233) */
+/* simulation steps, summed over the episodes, that the most recent fs_movep / fs_movep_batch* call -- or the movep
+   entries of the most recent fs_advance call -- executed (movep iterations that find the pickers on their targets do not
+   step the simulation, flex_utils.py:231-233); 0 after a call that returned an error before launching anything */
 long long fs_last_movep_steps(const fs_ctx *ctx);
 /* One chunk (at most `cap` simulation steps) for episodes that are in different phases of their primitives, so that all of
    them share every launch sequence; the chunk ends with the first movep that completes, but takes at least cap_min steps
@@ -178,6 +179,9 @@ long long fs_last_movep_steps(const fs_ctx *ctx);
 int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
                const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start, double eps,
                const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out, int *steps_out);
+/* fs_advance's stopwatch since fs_create: out5 = calls, launch sequences, wall ms inside the calls, device ms between a
+   call's first and last launch, wall ms the calls spent before their first launch (planning, tables, upload) */
+int fs_advance_timing(const fs_ctx *ctx, double *out5);
 /* picked particle index per picker (-1 = none) */
 int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
 /* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all

@@ -147,6 +147,9 @@ fdist.barrier()
 torch.distributed.destroy_process_group()
 if "--fail-rank-1" in sys.argv and rank == 1:
     sys.exit(7)
+if "--kill-rank-1" in sys.argv and rank == 1:
+    import signal
+    os.kill(os.getpid(), signal.SIGKILL)
 """
 
 
@@ -166,6 +169,11 @@ def test_launcher_starts_ranks_that_rendezvous(tmp_path):
     for r, rec in enumerate(recs):
         assert rec == {"rank": r, "local_rank": r, "world": 2, "sum": 3.0, "argv": ["--steps", "3"]}
     assert launch_local_ranks(2, str(script), [str(tmp_path), "--fail-rank-1"], env=env, timeout=180) == 7
+    # a rank killed by a signal comes back as 128 + signal (not as a negative number handed to sys.exit), and the caller's
+    # MASTER_PORT is the one the ranks meet on
+    port = _free_port()
+    assert launch_local_ranks(2, str(script), [str(tmp_path), "--kill-rank-1"], env=dict(env, MASTER_PORT=str(port)),
+                              timeout=180) == 128 + 9
 
 
 def test_launcher_module_never_touches_the_gpu_runtime():
