@@ -24,13 +24,52 @@ extern "C" const char *fs_last_error(void) { return g_err.c_str(); }
 extern "C" int fs_version(void) { return 100; }
 
 FsTopologyDev::~FsTopologyDev() {
-    if (slab) (void)hipFree(slab);
+    if (!slab) return;
+    if (owner) fs_pool_give(owner, slab, bytes);
+    else (void)hipFree(slab);
+}
+
+// ---- buffer pool: hipFree synchronises the device and hipMalloc costs 0.1-0.3 ms, so episode slabs and topology slabs
+// of a running context are recycled by size (rounded up to 256 KiB) instead of being returned to the driver
+static size_t pool_round(size_t bytes) { return (bytes + (size_t(1) << 18) - 1) & ~((size_t(1) << 18) - 1); }
+void *fs_pool_take(fs_ctx *ctx, size_t bytes, size_t *got_bytes) {
+    const size_t want = pool_round(bytes);
+    int best = -1;
+    for (int k = 0; k < (int)ctx->pool.size(); ++k)
+        if (ctx->pool[k].bytes >= want && ctx->pool[k].bytes <= 2 * want && (best < 0 || ctx->pool[k].bytes < ctx->pool[best].bytes))
+            best = k;
+    if (best >= 0) {
+        FsPoolBuf b = ctx->pool[best];
+        ctx->pool.erase(ctx->pool.begin() + best);
+        ctx->pool_bytes -= b.bytes;
+        if (got_bytes) *got_bytes = b.bytes;
+        return b.ptr;
+    }
+    void *p = nullptr;
+    if (!fs_hip_ok(hipMalloc(&p, want), "hipMalloc(pool)")) return nullptr;
+    if (got_bytes) *got_bytes = want;
+    return p;
+}
+void fs_pool_give(fs_ctx *ctx, void *ptr, size_t bytes) {
+    if (!ptr) return;
+    ctx->pool.push_back(FsPoolBuf{ptr, bytes});
+    ctx->pool_bytes += bytes;
 }
 
 // every stream the context launches on: its own and the concurrent launch chains' (fs_step_stream).  The chains join the
 // context's stream through events after a complete launch sequence; after an error in the middle of one they may not have.
 void fs_sync_all_streams(fs_ctx *ctx) {
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->main_stream) (void)hipStreamSynchronize(ctx->main_stream);
+    if (ctx->svc_stream) (void)hipStreamSynchronize(ctx->svc_stream);
+    for (int g = 0; g < FS_MAX_STREAM_GROUPS; ++g)
+        if (ctx->aux_streams[g]) (void)hipStreamSynchronize(ctx->aux_streams[g]);
+}
+// What a call that is about to rewrite an episode has to wait for.  On the main lane: everything the solver may still be
+// running.  On the service lane (fs_service_lane) the caller guarantees that the episode is not part of a chunk in flight
+// -- that is the lane's contract -- so only the lane's own stream matters and the chunk keeps running.
+void fs_sync_lane(fs_ctx *ctx) {
+    if (ctx->on_svc) { (void)hipStreamSynchronize(ctx->svc_stream); return; }
+    if (ctx->main_stream) (void)hipStreamSynchronize(ctx->main_stream);
     for (int g = 0; g < FS_MAX_STREAM_GROUPS; ++g)
         if (ctx->aux_streams[g]) (void)hipStreamSynchronize(ctx->aux_streams[g]);
 }
@@ -39,13 +78,24 @@ fs_ctx::~fs_ctx() {
     (void)hipSetDevice(device);
     fs_sync_all_streams(this);
     for (auto &e : envs) {
-        if (e.slab) (void)hipFree(e.slab);
+        if (e.slab) fs_pool_give(this, e.slab, e.slab_bytes);
         if (e.d_picked) (void)hipFree(e.d_picked);
         if (e.d_saved_w) (void)hipFree(e.d_saved_w);
         if (e.d_snapshot) (void)hipFree(e.d_snapshot);
     }
     envs.clear();
     topo_cache.clear();
+    for (auto &b : pool) (void)hipFree(b.ptr);  // (after the episodes and their topologies gave their slabs back)
+    pool.clear();
+    for (auto &t : tickets) {
+        if (t.done) (void)hipEventDestroy(t.done);
+        if (t.d_tab) (void)hipFree(t.d_tab);
+        if (t.h_tab) (void)hipHostFree(t.h_tab);
+        if (t.h_wait) (void)hipHostFree(t.h_wait);
+    }
+    if (d_wait) (void)hipFree(d_wait);
+    if (svc_scratch) (void)hipFree(svc_scratch);
+    if (svc_event) (void)hipEventDestroy(svc_event);
     if (d_envs) (void)hipFree(d_envs);
     if (d_shapes) (void)hipFree(d_shapes);
     if (d_ids) (void)hipFree(d_ids);
@@ -64,7 +114,8 @@ fs_ctx::~fs_ctx() {
     if (adv_ev1) (void)hipEventDestroy(adv_ev1);
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_stop) (void)hipEventDestroy(ev_stop);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (svc_stream) (void)hipStreamDestroy(svc_stream);
+    if (main_stream) (void)hipStreamDestroy(main_stream);
 }
 
 void *fs_stage(fs_ctx *ctx, size_t bytes) {
@@ -76,6 +127,20 @@ void *fs_stage(fs_ctx *ctx, size_t bytes) {
     if (!fs_hip_ok(hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault), "hipHostMalloc(stage)")) return nullptr;
     ctx->h_stage_bytes = want;
     return ctx->h_stage;
+}
+
+// grow-only device scratch of the small reductions (fs_loops.hip); the calls run one after the other on one lane, so
+// one buffer serves them all.  Growing it frees the old one: only then does a call of these wait for the whole device.
+void *fs_svc_scratch(fs_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->svc_scratch_bytes) return ctx->svc_scratch;
+    fs_sync_all_streams(ctx);
+    if (ctx->svc_scratch) (void)hipFree(ctx->svc_scratch);
+    ctx->svc_scratch = nullptr;
+    ctx->svc_scratch_bytes = 0;
+    const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes * 2;
+    if (!fs_hip_ok(hipMalloc(&ctx->svc_scratch, want), "hipMalloc(service scratch)")) return nullptr;
+    ctx->svc_scratch_bytes = want;
+    return ctx->svc_scratch;
 }
 
 // grow-only device scratch of the manipulation loops (fs_advance): hipMalloc / hipFree cost ~0.1-0.3 ms each and hipFree
@@ -113,7 +178,9 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
         e.cam.width = ctx->cam_width;
         e.cam.height = ctx->cam_height;
     }
-    bool ok = fs_hip_ok(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+    bool ok = fs_hip_ok(hipStreamCreateWithFlags(&ctx->main_stream, hipStreamNonBlocking), "hipStreamCreate") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_wait, sizeof(FsWaitDev) * n_envs), "hipMalloc(wait states)") &&
+              fs_hip_ok(hipMemset(ctx->d_wait, 0, sizeof(FsWaitDev) * n_envs), "hipMemset") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_envs, sizeof(FsEnvDev) * n_envs), "hipMalloc(envs)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_shapes, sizeof(FsShapesDev) * n_envs), "hipMalloc(shapes)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_ids, sizeof(int) * n_envs), "hipMalloc(ids)") &&
@@ -122,11 +189,39 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
               fs_hip_ok(hipHostMalloc((void **)&ctx->h_ids, sizeof(int) * n_envs, hipHostMallocDefault), "hipHostMalloc") &&
               fs_hip_ok(hipMemset(ctx->d_envs, 0, sizeof(FsEnvDev) * n_envs), "hipMemset") &&
               fs_hip_ok(hipMemset(ctx->d_shapes, 0, sizeof(FsShapesDev) * n_envs), "hipMemset");
+    ctx->stream = ctx->main_stream;
     if (!ok) {
         delete ctx;
         return nullptr;
     }
     return ctx;
+}
+
+// The service lane.  While chunks queued by fs_advance_begin run on the main stream, the host keeps working for the episodes
+// that are NOT part of them -- reductions, observations, resets -- and those calls must neither queue up behind the chunk
+// nor wait for it.  Between fs_service_lane(ctx, 1) and fs_service_lane(ctx, 0) every entry point of this library runs on a
+// second, high-priority stream instead.  Contract: on the service lane the caller only touches episodes that are not in a
+// chunk in flight (or are in it as loops that have already ended).  Leaving the lane makes the main stream wait for what
+// the lane queued, so whatever is launched next sees it.
+extern "C" int fs_service_lane(fs_ctx *ctx, int on) {
+    if (!ctx) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (on && !ctx->on_svc) {
+        if (!ctx->svc_stream) {
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi is the numerically lowest = most urgent)
+            HIP_TRY(hipStreamCreateWithPriority(&ctx->svc_stream, hipStreamNonBlocking, hi));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->svc_event, hipEventDisableTiming));
+        }
+        ctx->stream = ctx->svc_stream;
+        ctx->on_svc = true;
+    } else if (!on && ctx->on_svc) {
+        HIP_TRY(hipEventRecord(ctx->svc_event, ctx->svc_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->main_stream, ctx->svc_event, 0));
+        ctx->stream = ctx->main_stream;
+        ctx->on_svc = false;
+    }
+    return FS_OK;
 }
 
 extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
@@ -222,12 +317,18 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
         topo->vt_tri = c.take<int>(size_t(3) * s.t + 1);
         return c.off;
     };
-    topo->bytes = carve(nullptr);
-    if (!fs_hip_ok(hipMalloc(&topo->slab, topo->bytes), "hipMalloc(topology)")) return nullptr;
-    carve((char *)topo->slab);
-    bool ok = true;
+    const size_t image_bytes = carve(nullptr);
+    topo->owner = ctx;
+    topo->slab = fs_pool_take(ctx, image_bytes, &topo->bytes);
+    if (!topo->slab) return nullptr;
+    // the image of the slab is assembled in the pinned staging buffer with the same carve and goes up in ONE copy (the
+    // separate arrays used to be ~17 blocking copies from pageable memory)
+    char *stage = (char *)fs_stage(ctx, image_bytes);
+    if (!stage) return nullptr;
+    bool ok = fs_hip_ok(hipStreamSynchronize(ctx->stream), "sync before staging");
+    carve(stage);
     auto up = [&](void *dst, const void *src, size_t bytes) {
-        if (bytes) ok = ok && fs_hip_ok(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(topology)");
+        if (bytes) memcpy(dst, src, bytes);
     };
     up(topo->rest, s.pos.data(), n * 16);
     up(topo->adj_off, s.adj_off.data(), (n + 1) * 4);
@@ -257,6 +358,9 @@ static std::shared_ptr<FsTopologyDev> make_topology(fs_ctx *ctx, const FsHostSce
     up(topo->tris, s.tris.data(), size_t(3) * s.t * 4);
     up(topo->vt_off, s.vt_off.data(), (n + 1) * 4);
     up(topo->vt_tri, s.vt_tri.data(), size_t(3) * s.t * 4);
+    carve((char *)topo->slab);  // the members now point into the device slab
+    ok = ok && fs_hip_ok(hipMemcpyAsync(topo->slab, stage, image_bytes, hipMemcpyHostToDevice, ctx->stream), "hipMemcpy(topology)");
+    ok = ok && fs_hip_ok(hipStreamSynchronize(ctx->stream), "hipMemcpy(topology) sync");
     if (!ok) return nullptr;
     ctx->topo_cache.push_back(topo);
     return topo;
@@ -285,21 +389,13 @@ static int push_shapes(fs_ctx *ctx, int env) {
     return FS_OK;
 }
 
-extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int n_params, const float *verts,
-                            int n_vert_floats, const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints,
-                            const int *shear, int n_shear_ints, const int *faces, int n_face_ints) {
+// Init for episode `env` from a built host scene (main.cpp:613-1122): tears down the previous solver state, buffers and
+// shapes, allocates the episode's slab (from the context's pool), uploads the initial state.
+static int set_scene_impl(fs_ctx *ctx, int env, FsHostScene &&scene) {
     FsEnv *e = get_env(ctx, env, false);
     if (!e) return FS_ERR_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    fs_sync_all_streams(ctx);  // the episode's slab is about to be freed: nothing may still run on it, on any stream
-    FsHostScene scene;
-    std::string err = fs_build_scene(scene, scene_params, n_params, verts, n_vert_floats, stretch, n_stretch_ints, bend,
-                                     n_bend_ints, shear, n_shear_ints, faces, n_face_ints);
-    if (!err.empty()) { fs_set_error(err); return FS_ERR_ARG; }
-    // Init tears down the previous solver, buffers and shapes (main.cpp:623-706)
-    if (e->slab) { (void)hipFree(e->slab); e->slab = nullptr; }
-    if (e->d_picked) { (void)hipFree(e->d_picked); e->d_picked = nullptr; }
-    if (e->d_saved_w) { (void)hipFree(e->d_saved_w); e->d_saved_w = nullptr; }
+    fs_sync_lane(ctx);  // nothing may still run on the episode's old slab (fs_sync_lane: what that means on either lane)
+    if (e->slab) { fs_pool_give(ctx, e->slab, e->slab_bytes); e->slab = nullptr; e->slab_bytes = 0; }
     e->picker_ready = false;
     e->has_scene = false;
     e->topo.reset();
@@ -307,6 +403,7 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     if (!topo) return FS_ERR_HIP;
 
     const size_t n = scene.n;
+    if (e->d_saved_w && e->saved_w_n < (int)n) { (void)hipFree(e->d_saved_w); e->d_saved_w = nullptr; e->saved_w_n = 0; }  // (grow-only)
     FsEnvDev d;
     memset(&d, 0, sizeof(d));
     auto carve = [&](char *base) {
@@ -325,11 +422,13 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
         d.cell_items = c.take<int>(n);
         return c.off;
     };
-    size_t bytes = carve(nullptr);
-    void *slab = nullptr;
-    HIP_TRY(hipMalloc(&slab, bytes));
+    const size_t bytes = carve(nullptr);
+    size_t slab_bytes = 0;
+    void *slab = fs_pool_take(ctx, bytes, &slab_bytes);
+    if (!slab) return FS_ERR_HIP;
     carve((char *)slab);
-    HIP_TRY(hipMemset(slab, 0, bytes));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(hipMemsetAsync(slab, 0, bytes, st));
     d.n = scene.n; d.m = scene.m; d.max_deg = scene.max_deg; d.has_scene = 1;
     d.rest = topo->rest; d.adj_off = topo->adj_off; d.adj_j = topo->adj_j; d.adj_len = topo->adj_len; d.adj_k = topo->adj_k;
     d.ell_j = topo->ell_j; d.ell_len = topo->ell_len; d.ell_k = topo->ell_k;
@@ -345,13 +444,16 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     for (int q = 0; q < FS_G64_SLOTS; ++q) { d.g64_kh[q] = topo->g64_k[q] * 0.5f; d.gp_k[q] = topo->g64_k[q]; }
     d.p = scene.params;
 
-    // uploads (main.cpp:1025-1085): positions, velocities (zero), phases
-    std::vector<float> vel4(n * 4, 0.0f);
-    HIP_TRY(hipMemcpy(d.pos, scene.pos.data(), n * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d.vel, vel4.data(), n * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d.phase, scene.phase.data(), n * 4, hipMemcpyHostToDevice));
+    // uploads (main.cpp:1025-1085): positions and phases (velocities are the zeros of the memset) through the pinned staging
+    // buffer, the two descriptors behind them; ONE wait at the end
+    char *stage = (char *)fs_stage(ctx, n * 20);
+    if (!stage) return FS_ERR_HIP;
+    memcpy(stage, scene.pos.data(), n * 16);
+    memcpy(stage + n * 16, scene.phase.data(), n * 4);
+    HIP_TRY(hipMemcpyAsync(d.pos, stage, n * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d.phase, stage + n * 16, n * 4, hipMemcpyHostToDevice, st));
 
-    e->slab = slab; e->slab_bytes = bytes; e->dev = d; e->topo = topo;
+    e->slab = slab; e->slab_bytes = slab_bytes; e->dev = d; e->topo = topo;
     e->host = std::move(scene);
     memset(&e->shapes, 0, sizeof(e->shapes));  // shapes wiped by Init (main.cpp:701-706)
     // CenterCamera (softgym_cloth.h:177-183)
@@ -359,9 +461,36 @@ extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int
     e->cam.width = e->host.cam_width > 0 ? e->host.cam_width : ctx->cam_width;
     e->cam.height = e->host.cam_height > 0 ? e->host.cam_height : ctx->cam_height;
     e->has_scene = true;
-    int rc = push_env_desc(ctx, env);
-    if (rc != FS_OK) return rc;
-    return push_shapes(ctx, env);
+    ctx->desc_epoch++;  // the streaming back-end's launch table (fs_k_slot_table) is stale now
+    HIP_TRY(hipMemcpyAsync(ctx->d_envs + env, &e->dev, sizeof(FsEnvDev), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ctx->d_shapes + env, &e->shapes, sizeof(FsShapesDev), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return FS_OK;
+}
+
+extern "C" int fs_set_scene(fs_ctx *ctx, int env, const float *scene_params, int n_params, const float *verts,
+                            int n_vert_floats, const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints,
+                            const int *shear, int n_shear_ints, const int *faces, int n_face_ints) {
+    if (!get_env(ctx, env, false)) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    FsHostScene scene;
+    std::string err = fs_build_scene(scene, scene_params, n_params, verts, n_vert_floats, stretch, n_stretch_ints, bend,
+                                     n_bend_ints, shear, n_shear_ints, faces, n_face_ints);
+    if (!err.empty()) { fs_set_error(err); return FS_ERR_ARG; }
+    return set_scene_impl(ctx, env, std::move(scene));
+}
+
+// fs_set_scene from a scene that fs_host_scene_build (host only: any thread, no GPU) made earlier -- the evaluation loop
+// builds the NEXT tasks' scenes on a worker thread while the current ones simulate.  Takes the scene out of `scene`
+// (which stays valid but empty; free it with fs_host_scene_free as usual).
+struct fs_host_scene { FsHostScene s; };
+extern "C" int fs_set_scene_prebuilt(fs_ctx *ctx, int env, fs_host_scene *scene) {
+    if (!get_env(ctx, env, false)) return FS_ERR_ARG;
+    if (!scene || scene->s.n <= 0) { fs_set_error("fs_set_scene_prebuilt: no scene (already consumed?)"); return FS_ERR_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    FsHostScene moved = std::move(scene->s);
+    scene->s = FsHostScene();
+    return set_scene_impl(ctx, env, std::move(moved));
 }
 
 extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {

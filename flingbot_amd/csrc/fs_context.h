@@ -13,7 +13,10 @@
 #include "fs_scene.h"
 #include "fs_types.h"
 
+struct fs_ctx;
+
 struct FsTopologyDev {  // immutable, shared by episodes with the same cloth
+    fs_ctx *owner = nullptr;  // the slab goes back to this context's buffer pool
     void *slab = nullptr;
     size_t bytes = 0;
     uint64_t key = 0;
@@ -57,9 +60,10 @@ struct FsEnv {
     float shape_rot[FS_MAX_SHAPES][4], shape_prev_rot[FS_MAX_SHAPES][4];
     // on-device picker state (fs_picker.hip): picked particle per shape (-1 none), inverse masses saved at reset
     int *d_picked = nullptr;   // [FS_MAX_SHAPES]
-    float *d_saved_w = nullptr;  // [n]
+    float *d_saved_w = nullptr;  // [saved_w_n >= n], grow-only
+    int saved_w_n = 0;
     FsVec4 *d_snapshot = nullptr;  // [snapshot_n] positions kept by fs_snapshot_positions (SimEnv.preaction)
-    int snapshot_n = 0;
+    int snapshot_n = 0, snapshot_cap = 0;  // particles of the snapshot taken / capacity of the buffer
     double picker_threshold = 0.005, particle_radius = 0.00625;
     double picker_radius = -1.0;  // < 0: use the float32 radius of shape 0 (fs_picker_set_radius)
     bool picker_ready = false;
@@ -67,6 +71,29 @@ struct FsEnv {
 };
 
 #define FS_MAX_STREAM_GROUPS 4
+#define FS_ADV_TICKETS 4  // fs_advance_begin calls that may be in flight at once
+
+struct FsPoolBuf { void *ptr; size_t bytes; };
+
+// wait_until_stable / plain-step loop state of an episode on the device, kept ACROSS fs_advance calls so that the host may
+// queue the next chunk of the loop before it has seen the result of the previous one (fs_picker.hip)
+struct FsWaitDev { int steps, stable, over, pad; };
+
+// one fs_advance_begin call whose launches may still be running
+struct FsAdvTicket {
+    bool busy = false;
+    hipEvent_t done = nullptr;
+    void *d_tab = nullptr;  // device tables of the call
+    size_t d_tab_bytes = 0;
+    void *h_tab = nullptr;  // pinned image of the tables (upload)
+    size_t h_tab_bytes = 0;
+    FsWaitDev *h_wait = nullptr;  // pinned [n_envs]: the wait states after the call's last launch
+    int n = 0;
+    std::vector<int> w_arg, w_env, w_kind, w_limit, w_start;  // the call's waiters: index in the caller's arrays, episode, ...
+    std::vector<char> w_skip;                                  // loop budget already used up when the call was made
+    size_t n_seq = 0;
+    double wall_begin_ms = 0.0;
+};
 
 struct fs_ctx {
     int device = 0;
@@ -82,7 +109,11 @@ struct fs_ctx {
     bool fused_attr_set = false;       // hipFuncAttributeMaxDynamicSharedMemorySize applied on this context's device
     int last_form = 0;                 // FS_FORM_* of the most recent solver launch (fs_last_kernel_form)
     long long last_movep_steps = 0;    // simulation steps of the most recent fs_movep* call, all episodes (fs_last_movep_steps)
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream of the CURRENT lane: main_stream, or svc_stream between fs_service_lane(1) / (0)
+    hipStream_t main_stream = nullptr;  // solver launches, fs_advance chunks
+    hipStream_t svc_stream = nullptr;   // high priority: reductions / observation / resets of episodes that are NOT part of a chunk in flight
+    hipEvent_t svc_event = nullptr;
+    bool on_svc = false;
     // concurrent chains of the streaming back-end (fs_solver.hip): streams / join events per group, the fork event
     hipStream_t aux_streams[FS_MAX_STREAM_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t aux_events[FS_MAX_STREAM_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
@@ -107,8 +138,17 @@ struct fs_ctx {
     // renderer scratch (fs_render.hip)
     void *render_scratch = nullptr;
     size_t render_scratch_bytes = 0;
-    void *loop_scratch = nullptr;     // device tables of fs_advance (fs_picker.hip), grow-only
+    void *loop_scratch = nullptr;     // device tables of fs_movep_batch (fs_picker.hip), grow-only
     size_t loop_scratch_bytes = 0;
+    void *svc_scratch = nullptr;      // device scratch of the small reductions (fs_loops.hip), grow-only
+    size_t svc_scratch_bytes = 0;
+    // device buffers kept for reuse: hipFree synchronises the whole device, which an episode reset (fs_set_scene) in the
+    // middle of a running evaluation loop cannot afford; buffers return here and are handed out again by size
+    std::vector<FsPoolBuf> pool;
+    size_t pool_bytes = 0;
+    FsWaitDev *d_wait = nullptr;      // [n_envs]
+    FsAdvTicket tickets[FS_ADV_TICKETS];
+    int tickets_busy = 0;
     double *d_coverage = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // fs_timer_start / fs_timer_stop
     // fs_advance's own stopwatch (fs_advance_timing): device time between its first and last launch, wall time of the call
@@ -122,7 +162,11 @@ struct fs_ctx {
 void fs_set_error(const std::string &msg);
 bool fs_hip_ok(hipError_t e, const char *what);
 void *fs_stage(fs_ctx *ctx, size_t bytes);
-void fs_sync_all_streams(fs_ctx *ctx);  // the context's stream and the launch chains' streams
+void fs_sync_all_streams(fs_ctx *ctx);  // both lanes' streams and the launch chains' streams
+void fs_sync_lane(fs_ctx *ctx);         // service lane: its stream; main lane: the main stream and the chains'
+void *fs_svc_scratch(fs_ctx *ctx, size_t bytes);
+void *fs_pool_take(fs_ctx *ctx, size_t bytes, size_t *got_bytes);
+void fs_pool_give(fs_ctx *ctx, void *ptr, size_t bytes);
 void *fs_loop_scratch(fs_ctx *ctx, size_t bytes);
 
 // solver back-ends

@@ -7,9 +7,7 @@
 #include "fs_camera.h"
 #include "fs_sphere_mesh.h"
 
-struct fs_host_scene {
-    FsHostScene s;
-};
+struct fs_host_scene { FsHostScene s; };  // (same definition in fs_capi.hip: fs_set_scene_prebuilt)
 
 extern "C" fs_host_scene *fs_host_scene_build(const float *scene_params, int n_params, const float *verts,
                                               int n_vert_floats, const int *stretch, int n_stretch_ints, const int *bend,

@@ -69,8 +69,8 @@ extern "C" int fs_wait_until_stable(fs_ctx *ctx, int n, const int *envs, int max
             fs_set_error("fs_wait_until_stable: bad episode id / no scene");
             return FS_ERR_ARG;
         }
-    int *d_buf = nullptr;  // ids[n] | steps[n] | stable[n] | remaining
-    HIP_TRY(hipMalloc((void **)&d_buf, sizeof(int) * (3 * n + 1)));
+    int *d_buf = (int *)fs_svc_scratch(ctx, sizeof(int) * (3 * n + 1));  // ids[n] | steps[n] | stable[n] | remaining
+    if (!d_buf) return FS_ERR_HIP;
     int *d_ids = d_buf, *d_steps = d_buf + n, *d_stable = d_buf + 2 * n, *d_remaining = d_buf + 3 * n;
     std::vector<int> init(3 * n + 1, 0);
     for (int k = 0; k < n; ++k) init[k] = ids[k];
@@ -101,7 +101,6 @@ extern "C" int fs_wait_until_stable(fs_ctx *ctx, int n, const int *envs, int max
     } else {
         (void)hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(d_buf);
     return rc;
 }
 
@@ -155,12 +154,11 @@ extern "C" int fs_cloth_stats(fs_ctx *ctx, int n, const int *envs, float *out, i
     int *d_ids = nullptr;
     int rc = upload_list(ctx, n, envs, &d_ids);
     if (rc != FS_OK) return rc;
-    float *d_out = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_out, sizeof(float) * 3 * n));
+    float *d_out = (float *)fs_svc_scratch(ctx, sizeof(float) * 3 * n);
+    if (!d_out) return FS_ERR_HIP;
     hipLaunchKernelGGL(fs_k_cloth_stats, dim3((unsigned)n), dim3(256), 0, ctx->stream, ctx->d_envs, d_ids, d_out);
     hipError_t herr = hipMemcpyAsync(out, d_out, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, ctx->stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_out);
     return fs_hip_ok(herr, "fs_cloth_stats") ? FS_OK : FS_ERR_HIP;
 }
 
@@ -214,8 +212,8 @@ extern "C" int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float
     int *d_ids = nullptr;
     int rc = upload_list(ctx, n, envs, &d_ids);
     if (rc != FS_OK) return rc;
-    float *d_buf = nullptr;  // mid[2n] | thr[n] | nearest[3n] | single[n] (ints)
-    HIP_TRY(hipMalloc((void **)&d_buf, sizeof(float) * 7 * n));
+    float *d_buf = (float *)fs_svc_scratch(ctx, sizeof(float) * 7 * n);  // mid[2n] | thr[n] | nearest[3n] | single[n] (ints)
+    if (!d_buf) return FS_ERR_HIP;
     float *d_mid = d_buf, *d_thr = d_buf + 2 * n, *d_near = d_buf + 3 * n;
     int *d_single = (int *)(d_buf + 6 * n);
     hipError_t herr = hipMemcpyAsync(d_mid, midpoint_xz, sizeof(float) * 2 * n, hipMemcpyHostToDevice, ctx->stream);
@@ -228,7 +226,6 @@ extern "C" int fs_stretch_probe(fs_ctx *ctx, int n, const int *envs, const float
     }
     if (herr == hipSuccess) herr = hipMemcpyAsync(single_grasp_out, d_single, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_buf);
     return fs_hip_ok(herr, "fs_stretch_probe") ? FS_OK : FS_ERR_HIP;
 }
 
@@ -259,11 +256,17 @@ extern "C" int fs_snapshot_positions(fs_ctx *ctx, int n, const int *envs) {
         }
         FsEnv &e = ctx->envs[envs[k]];
         const size_t bytes = sizeof(FsVec4) * (size_t)e.host.n;
-        if (e.d_snapshot && e.snapshot_n != e.host.n) { (void)hipFree(e.d_snapshot); e.d_snapshot = nullptr; }
-        if (!e.d_snapshot) {
-            HIP_TRY(hipMalloc((void **)&e.d_snapshot, bytes));
-            e.snapshot_n = e.host.n;
+        if (e.d_snapshot && e.snapshot_cap < e.host.n) {  // grow-only (hipFree synchronises the device)
+            fs_sync_all_streams(ctx);
+            (void)hipFree(e.d_snapshot);
+            e.d_snapshot = nullptr;
         }
+        if (!e.d_snapshot) {
+            const int cap = e.host.n < 16384 ? 16384 : e.host.n;  // room for every cloth of the reference's task sizes
+            HIP_TRY(hipMalloc((void **)&e.d_snapshot, sizeof(FsVec4) * (size_t)cap));
+            e.snapshot_cap = cap;
+        }
+        e.snapshot_n = e.host.n;
         HIP_TRY(hipMemcpyAsync(e.d_snapshot, e.dev.pos, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     }
     return FS_OK;
@@ -280,8 +283,8 @@ extern "C" int fs_max_displacement(fs_ctx *ctx, int n, const int *envs, float *o
         if (!e.d_snapshot || e.snapshot_n != e.host.n) { fs_set_error("fs_max_displacement: call fs_snapshot_positions first"); return FS_ERR_STATE; }
         h_snap[k] = e.d_snapshot;
     }
-    char *d_buf = nullptr;  // pointers[n] | out[n]
-    HIP_TRY(hipMalloc((void **)&d_buf, (sizeof(void *) + sizeof(float)) * n));
+    char *d_buf = (char *)fs_svc_scratch(ctx, (sizeof(void *) + sizeof(float)) * n);  // pointers[n] | out[n]
+    if (!d_buf) return FS_ERR_HIP;
     const FsVec4 **d_snap = (const FsVec4 **)d_buf;
     float *d_out = (float *)(d_buf + sizeof(void *) * n);
     hipError_t herr = hipMemcpyAsync(d_snap, h_snap.data(), sizeof(void *) * n, hipMemcpyHostToDevice, ctx->stream);
@@ -291,7 +294,6 @@ extern "C" int fs_max_displacement(fs_ctx *ctx, int n, const int *envs, float *o
         herr = hipMemcpyAsync(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (herr == hipSuccess) herr = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_buf);
     return fs_hip_ok(herr, "fs_max_displacement") ? FS_OK : FS_ERR_HIP;
 }
 
@@ -318,8 +320,8 @@ extern "C" int fs_set_particles(fs_ctx *ctx, int n, const int *envs, const int *
             fs_set_error("fs_set_particles: particle id out of range");
             return FS_ERR_ARG;
         }
-    char *d_buf = nullptr;  // pids[n] | pos4[4n]
-    HIP_TRY(hipMalloc((void **)&d_buf, (sizeof(int) + 4 * sizeof(float)) * n));
+    char *d_buf = (char *)fs_svc_scratch(ctx, (sizeof(int) + 4 * sizeof(float)) * n);  // pids[n] | pos4[4n]
+    if (!d_buf) return FS_ERR_HIP;
     int *d_pids = (int *)d_buf;
     float *d_pos = (float *)(d_buf + sizeof(int) * n);
     hipError_t herr = hipMemcpyAsync(d_pids, particle_ids, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream);
@@ -330,6 +332,5 @@ extern "C" int fs_set_particles(fs_ctx *ctx, int n, const int *envs, const int *
                            zero_velocity, n);
         herr = hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(d_buf);
     return fs_hip_ok(herr, "fs_set_particles") ? FS_OK : FS_ERR_HIP;
 }

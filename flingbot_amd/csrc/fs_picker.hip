@@ -131,7 +131,10 @@ extern "C" int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, do
     if (!e) return FS_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!e->d_picked) HIP_TRY(hipMalloc((void **)&e->d_picked, sizeof(int) * FS_MAX_SHAPES));
-    if (!e->d_saved_w) HIP_TRY(hipMalloc((void **)&e->d_saved_w, sizeof(float) * e->host.n));
+    if (!e->d_saved_w) {
+        HIP_TRY(hipMalloc((void **)&e->d_saved_w, sizeof(float) * e->host.n));
+        e->saved_w_n = e->host.n;
+    }
     e->picker_threshold = picker_threshold;
     e->particle_radius = particle_radius;
     e->picker_radius = -1.0;  // until fs_picker_set_radius says otherwise: the (float32) radius of shape 0
@@ -371,26 +374,46 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
 // without changing a bit: a movep iteration only reads the pickers' current positions and its own loop index (start[]),
 // wait_until_stable only counts its steps.
 // One device id list per launch sequence: [waiters | movers still moving at this step]; a check kernel retires a waiter
-// (id -> -1) when it is stable or its step budget is used up, the picker kernel moves the movers' pickers.
-__global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int *row, const double *tols, const int *budget,
-                                                       int *steps, int *stable, int *dead) {
+// (id -> -1) when it is stable or its loop's steps are used up, the picker kernel moves the movers' pickers.
+//
+// The loop state of a waiter (steps taken, stable, over) lives in ctx->d_wait[episode] ACROSS calls.  A call normally sets
+// it (start[a] >= 0: "the loop stands at step start[a]"); with start[a] = -1 the call continues from whatever the previous
+// call left there -- which lets a host that pipelines its calls (fs_advance_begin / fs_advance_end, flingbot_amd/schedule.py)
+// queue the NEXT chunk of a wait before it has seen the result of the previous one: if the loop ended there, the episode's
+// entries of the new chunk retire at once and nothing is stepped.
+struct FsWaitCmd {
+    double tol;   // tolerance of wait_until_stable; -1 for plain steps (never "stable")
+    int env;
+    int limit;    // steps of the whole loop (max_steps / n)
+    int start;    // >= 0: set the loop to this many steps taken at the call's first launch sequence; -1: continue
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int *row, const FsWaitCmd *cmds, FsWaitDev *state,
+                                                       int first) {
     __shared__ float red[256];
     const int slot = blockIdx.x;
-    if (dead[slot]) {  // retired in an earlier launch sequence: this sequence's list entry goes too
+    const FsWaitCmd c = cmds[slot];
+    FsWaitDev &W = state[c.env];
+    int steps = W.steps, over = W.over;
+    if (first && c.start >= 0) {
+        steps = c.start; over = 0;
+        if (threadIdx.x == 0) { W.steps = steps; W.stable = 0; W.over = 0; }
+    }
+    if (over) {  // the loop ended in an earlier launch sequence (or call): this sequence's list entry goes
         if (threadIdx.x == 0) row[slot] = -1;
         return;
     }
-    const int e = row[slot];
-    if (steps[slot] >= budget[slot]) {  // this call's (or the loop's) steps are used up: not stable, no test (flex_utils.py:441)
-        if (threadIdx.x == 0) { row[slot] = -1; dead[slot] = 1; }
+    if (steps >= c.limit) {  // the loop's steps are used up: not stable, no test (flex_utils.py:441)
+        if (threadIdx.x == 0) { row[slot] = -1; W.over = 1; }
         return;
     }
-    const FsEnvDev &E = envs[e];
+    const FsEnvDev &E = envs[c.env];
     float m = 0.0f;
     for (int i = threadIdx.x; i < E.n; i += 256) {
         const FsVec4 v = E.vel[i];
-        const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z);
-        const float q = (a != a || b != b || c != c) ? __int_as_float(0x7fc00000) : fmaxf(a, fmaxf(b, c));
+        const float a = fabsf(v.x), b = fabsf(v.y), cc = fabsf(v.z);
+        const float q = (a != a || b != b || cc != cc) ? __int_as_float(0x7fc00000) : fmaxf(a, fmaxf(b, cc));
         m = (m != m || q != q) ? __int_as_float(0x7fc00000) : fmaxf(m, q);  // numpy's max propagates NaN
     }
     red[threadIdx.x] = m;
@@ -403,21 +426,49 @@ __global__ __launch_bounds__(256) void fs_k_wait_check(const FsEnvDev *envs, int
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if ((double)red[0] < tols[slot]) { stable[slot] = 1; dead[slot] = 1; row[slot] = -1; }  // (plain steps: tolerance -1, never true)
-        else steps[slot] += 1;  // the step that follows
+        if ((double)red[0] < c.tol) { W.stable = 1; W.over = 1; row[slot] = -1; }  // (plain steps: tolerance -1, never true)
+        else W.steps = steps + 1;  // the step that follows
     }
 }
 
-extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
-                          const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start,
-                          double eps, const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out,
-                          int *steps_out) {
+static int ticket_buffers(fs_ctx *ctx, FsAdvTicket &t, size_t bytes) {
+    if (!t.done) HIP_TRY(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+    if (!t.h_wait) HIP_TRY(hipHostMalloc((void **)&t.h_wait, sizeof(FsWaitDev) * ctx->n_envs, hipHostMallocDefault));
+    if (bytes > t.d_tab_bytes) {  // (the ticket is free, i.e. its previous launches have completed)
+        const size_t want = bytes < (1u << 18) ? (1u << 18) : bytes * 2;
+        if (t.d_tab) { fs_pool_give(ctx, t.d_tab, t.d_tab_bytes); t.d_tab = nullptr; t.d_tab_bytes = 0; }
+        t.d_tab = fs_pool_take(ctx, want, &t.d_tab_bytes);
+        if (!t.d_tab) return FS_ERR_HIP;
+    }
+    if (bytes > t.h_tab_bytes) {
+        if (t.h_tab) (void)hipHostFree(t.h_tab);
+        t.h_tab = nullptr; t.h_tab_bytes = 0;
+        const size_t want = bytes < (1u << 18) ? (1u << 18) : bytes * 2;
+        HIP_TRY(hipHostMalloc(&t.h_tab, want, hipHostMallocDefault));
+        t.h_tab_bytes = want;
+    }
+    return FS_OK;
+}
+
+// Queues the chunk and returns: the movers' outputs are final (their trajectories are planned on the host), a waiter's
+// status_out is -1 until fs_advance_end.  Returns the ticket (>= 0) or an error code (< 0).  poll: the blocking form may
+// stop launching early once every waiter of a waiters-only tail has retired (it looks every 16 sequences).
+static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
+                         const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start,
+                         double eps, const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out,
+                         int *steps_out, bool poll) {
     if (!ctx || n <= 0 || n > ctx->n_envs || !envs || !kind || !limit || !start || !progress_out || !status_out || !steps_out ||
         cap <= 0 || cap_min <= 0 || cap_min > cap) {
         fs_set_error("fs_advance: bad arguments");
         return FS_ERR_ARG;
     }
     HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->on_svc) { fs_set_error("fs_advance: chunks are queued on the main lane (call fs_service_lane(ctx, 0) first)"); return FS_ERR_STATE; }
+    int tk = -1;
+    for (int k = 0; k < FS_ADV_TICKETS; ++k)
+        if (!ctx->tickets[k].busy) { tk = k; break; }
+    if (tk < 0) { fs_set_error("fs_advance_begin: too many chunks in flight (call fs_advance_end)"); return FS_ERR_STATE; }
+    FsAdvTicket &T = ctx->tickets[tk];
     const auto wall0 = std::chrono::steady_clock::now();
     ctx->last_movep_steps = 0;
     std::vector<int> movers, waiters;
@@ -437,6 +488,7 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
                 fs_set_error("fs_advance: episodes moved together need the same grasp threshold");
                 return FS_ERR_STATE;
             }
+            if (start[a] < 0) { fs_set_error("fs_advance: a movep needs its loop index (start >= 0)"); return FS_ERR_ARG; }
             movers.push_back(a);
         } else if (kind[a] == 1 || kind[a] == 2) {
             if (kind[a] == 1 && !tolerance) { fs_set_error("fs_advance: tolerance missing"); return FS_ERR_ARG; }
@@ -446,10 +498,10 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
             return FS_ERR_ARG;
         }
     }
-    const int nm = (int)movers.size(), nw = (int)waiters.size();
+    const int nm = (int)movers.size(), nw_all = (int)waiters.size();
     // movers: plan this call's part of each trajectory.  The chunk ends when the FIRST mover finishes its movep (so that its
-    // program can issue the next request without idling through the others' steps), but not before cap_min steps (the host
-    // round trip per call) and not after cap.
+    // program can issue the next request without idling through the others' steps), but not before cap_min steps and not
+    // after cap.
     std::vector<Plan> plans(nm);
     size_t n_seq = 0, shortest = (size_t)cap;
     for (int q = 0; q < nm; ++q) {
@@ -467,121 +519,27 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
         progress_out[a] = plans[q].iterations;
         status_out[a] = plans[q].capped ? 0 : (plans[q].limit_hit ? 2 : 1);
         steps_out[a] = (int)plans[q].cmds.size();
+        ctx->last_movep_steps += (long long)plans[q].cmds.size();
         if (plans[q].cmds.size() > n_seq) n_seq = plans[q].cmds.size();
     }
     const size_t mover_seq = n_seq;  // launch sequences that still have a mover
-    std::vector<int> w_budget(nw, 0);
-    for (int q = 0; q < nw; ++q) {
+    // waiters: a loop whose steps are known to be used up is answered here; the others take part for up to `chunk` sequences
+    T.w_arg.clear(); T.w_env.clear(); T.w_kind.clear(); T.w_limit.clear(); T.w_start.clear();
+    for (int q = 0; q < nw_all; ++q) {
         const int a = waiters[q];
-        const int left = limit[a] - start[a];
-        w_budget[q] = left < 0 ? 0 : (left < chunk ? left : chunk);
-        if ((size_t)w_budget[q] > n_seq) n_seq = (size_t)w_budget[q];
-        if (w_budget[q] == 0) {  // budget of the whole loop already used: wait_until_stable returns False
+        if (start[a] >= 0 && limit[a] - start[a] <= 0) {  // wait_until_stable returns False, plain steps are done
             progress_out[a] = start[a]; status_out[a] = kind[a] == 2 ? 1 : 2; steps_out[a] = 0;
+            continue;
         }
+        int budget = chunk;
+        if (start[a] >= 0 && limit[a] - start[a] < budget) budget = limit[a] - start[a];
+        if ((size_t)budget > n_seq) n_seq = (size_t)budget;
+        status_out[a] = -1; progress_out[a] = start[a]; steps_out[a] = 0;
+        T.w_arg.push_back(a); T.w_env.push_back(envs[a]); T.w_kind.push_back(kind[a]); T.w_limit.push_back(limit[a]);
+        T.w_start.push_back(start[a]);
     }
-    if (n_seq == 0) return FS_OK;
-    // device tables, ONE upload into the context's scratch.  Per launch sequence s a row of the launch list:
-    // [waiters | movers still moving at s | -1 ...]; the check kernel retires a waiter from its row and, through dead[], from
-    // every later row.
-    const int width = nm > 0 ? nm : 1, W = nw + width, n_envs = ctx->n_envs;
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~size_t(15); return o; };
-    const size_t o_picked = carve(sizeof(int *) * n_envs), o_saved = carve(sizeof(float *) * n_envs);
-    const size_t o_tol = carve(sizeof(double) * (nw > 0 ? nw : 1));
-    const size_t o_cmds = carve(sizeof(FsPickerCmd) * n_seq * width);
-    const size_t o_rows = carve(sizeof(int) * n_seq * W);
-    const size_t o_wait = carve(sizeof(int) * 4 * (nw > 0 ? nw : 1));  // budget | steps | stable | dead
-    std::vector<char> blob(off, 0);
-    int **h_picked = (int **)(blob.data() + o_picked);
-    float **h_saved = (float **)(blob.data() + o_saved);
-    double *h_tol = (double *)(blob.data() + o_tol);
-    FsPickerCmd *h_cmds = (FsPickerCmd *)(blob.data() + o_cmds);
-    int *h_rows = (int *)(blob.data() + o_rows), *h_wait = (int *)(blob.data() + o_wait);
-    std::vector<int> h_cnt(n_seq, 0);
-    for (int i = 0; i < n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
-    for (int q = 0; q < nw; ++q) {
-        h_tol[q] = kind[waiters[q]] == 1 ? tolerance[waiters[q]] : -1.0;
-        h_wait[q] = w_budget[q];
-    }
-    for (size_t s = 0; s < n_seq; ++s) {
-        int *row = h_rows + s * W;
-        for (int k = 0; k < W; ++k) row[k] = -1;
-        for (int q = 0; q < nw; ++q) row[q] = envs[waiters[q]];
-        for (int q = 0; q < nm; ++q)
-            if (s < plans[q].cmds.size()) {
-                const int slot = h_cnt[s]++;
-                row[nw + slot] = envs[movers[q]];
-                h_cmds[s * width + slot] = plans[q].cmds[s];
-            }
-    }
-    char *dev = (char *)fs_loop_scratch(ctx, off);
-    if (!dev) return FS_ERR_HIP;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipMemcpy(dev, blob.data(), off, hipMemcpyHostToDevice));
-    if (!ctx->adv_ev0) {
-        HIP_TRY(hipEventCreate(&ctx->adv_ev0));
-        HIP_TRY(hipEventCreate(&ctx->adv_ev1));
-    }
-    HIP_TRY(hipEventRecord(ctx->adv_ev0, ctx->stream));
-    const auto wall1 = std::chrono::steady_clock::now();
-    int **d_picked = (int **)(dev + o_picked);
-    float **d_saved = (float **)(dev + o_saved);
-    const double *d_tol = (const double *)(dev + o_tol);
-    const FsPickerCmd *d_cmds = (const FsPickerCmd *)(dev + o_cmds);
-    int *d_rows = (int *)(dev + o_rows), *d_wait = (int *)(dev + o_wait);
-    int *d_w_budget = d_wait, *d_w_steps = d_wait + nw, *d_w_stable = d_wait + 2 * nw, *d_w_dead = d_wait + 3 * nw;
-    int rc = FS_OK;
-    std::vector<int> ids;
-    for (size_t s = 0; s < n_seq && rc == FS_OK; ++s) {
-        const int cnt = h_cnt[s];
-        int *d_row = d_rows + s * W;
-        ids.assign(h_rows + s * W, h_rows + s * W + nw + cnt);
-        if (cnt > 0) {
-            const double thr = picker_grasp_threshold(ctx->envs[ids[nw]]);
-            hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes, d_row + nw,
-                               d_cmds + s * width, d_picked, d_saved, thr);
-        }
-        if (nw > 0)
-            hipLaunchKernelGGL(fs_k_wait_check, dim3(nw), dim3(256), 0, ctx->stream, ctx->d_envs, d_row, d_tol, d_w_budget,
-                               d_w_steps, d_w_stable, d_w_dead);
-        rc = fs_step_ids(ctx, ids, 1, d_row);
-        if (rc == FS_OK && nw > 0 && s >= mover_seq && (s & 15) == 15 && s + 1 < n_seq) {  // only waiters left: all retired?
-            int *live = (int *)fs_stage(ctx, sizeof(int) * nw);
-            hipError_t pe = live ? hipMemcpyAsync(live, d_w_dead, sizeof(int) * nw, hipMemcpyDeviceToHost, ctx->stream) : hipErrorOutOfMemory;
-            if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);
-            if (!fs_hip_ok(pe, "fs_advance poll")) { rc = FS_ERR_HIP; break; }
-            bool any = false;
-            for (int q = 0; q < nw; ++q) any = any || live[q] == 0;
-            if (!any) break;
-        }
-    }
-    std::vector<int> w_out(2 * (nw > 0 ? nw : 1), 0);
-    hipError_t err = hipSuccess;
-    if (rc == FS_OK && nw > 0)
-        err = hipMemcpyAsync(w_out.data(), d_w_steps, sizeof(int) * 2 * nw, hipMemcpyDeviceToHost, ctx->stream);
-    if (err == hipSuccess) err = hipEventRecord(ctx->adv_ev1, ctx->stream);
-    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
-    if (rc != FS_OK) return rc;
-    HIP_TRY(err);
-    {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, ctx->adv_ev0, ctx->adv_ev1) == hipSuccess) ctx->adv_gpu_ms += ms;
-        const auto wall2 = std::chrono::steady_clock::now();
-        ctx->adv_wall_ms += std::chrono::duration<double, std::milli>(wall2 - wall0).count();
-        ctx->adv_prep_ms += std::chrono::duration<double, std::milli>(wall1 - wall0).count();
-        ctx->adv_calls += 1;
-        ctx->adv_sequences += (long long)n_seq;
-    }
-    for (int q = 0; q < nm; ++q) ctx->last_movep_steps += (long long)plans[q].cmds.size();
-    for (int q = 0; q < nw; ++q) {
-        const int a = waiters[q];
-        if (w_budget[q] == 0) continue;
-        const int taken = w_out[q], stable = w_out[nw + q];
-        progress_out[a] = start[a] + taken;
-        steps_out[a] = taken;
-        status_out[a] = stable ? 1 : (progress_out[a] >= limit[a] ? (kind[a] == 2 ? 1 : 2) : 0);
-    }
+    const int nw = (int)T.w_arg.size();
+    T.n = n; T.n_seq = n_seq;
     // host mirrors of the shape states follow the planned trajectories
     for (int q = 0; q < nm; ++q) {
         FsEnv &e = ctx->envs[envs[movers[q]]];
@@ -594,7 +552,156 @@ extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, 
             e.shapes.pos[k] = FsVec4{cm.back().new_pos[k][0], cm.back().new_pos[k][1], cm.back().new_pos[k][2], r};
         }
     }
+    if (n_seq == 0) {  // nothing to launch: an empty ticket keeps the begin / end protocol uniform
+        T.busy = true; ctx->tickets_busy++;
+        int rc0 = ticket_buffers(ctx, T, 16);
+        if (rc0 != FS_OK) { T.busy = false; ctx->tickets_busy--; return rc0; }
+        HIP_TRY(hipEventRecord(T.done, ctx->stream));
+        return tk;
+    }
+    // device tables, ONE upload from the ticket's pinned image.  Per launch sequence s a row of the launch list:
+    // [waiters | movers still moving at s | -1 ...]; the check kernel retires a waiter from its row and, through the loop
+    // state, from every later row (and call).
+    const int width = nm > 0 ? nm : 1, W = nw + width, n_envs = ctx->n_envs;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~size_t(15); return o; };
+    const size_t o_picked = carve(sizeof(int *) * n_envs), o_saved = carve(sizeof(float *) * n_envs);
+    const size_t o_wcmd = carve(sizeof(FsWaitCmd) * (nw > 0 ? nw : 1));
+    const size_t o_cmds = carve(sizeof(FsPickerCmd) * n_seq * width);
+    const size_t o_rows = carve(sizeof(int) * n_seq * W);
+    int rc = ticket_buffers(ctx, T, off);
+    if (rc != FS_OK) return rc;
+    char *blob = (char *)T.h_tab;
+    memset(blob, 0, off);
+    int **h_picked = (int **)(blob + o_picked);
+    float **h_saved = (float **)(blob + o_saved);
+    FsWaitCmd *h_wcmd = (FsWaitCmd *)(blob + o_wcmd);
+    FsPickerCmd *h_cmds = (FsPickerCmd *)(blob + o_cmds);
+    int *h_rows = (int *)(blob + o_rows);
+    std::vector<int> h_cnt(n_seq, 0);
+    for (int i = 0; i < n_envs; ++i) { h_picked[i] = ctx->envs[i].d_picked; h_saved[i] = ctx->envs[i].d_saved_w; }
+    for (int q = 0; q < nw; ++q) {
+        const int a = T.w_arg[q];
+        h_wcmd[q].tol = kind[a] == 1 ? tolerance[a] : -1.0;
+        h_wcmd[q].env = envs[a]; h_wcmd[q].limit = limit[a]; h_wcmd[q].start = start[a]; h_wcmd[q].pad = 0;
+    }
+    for (size_t s = 0; s < n_seq; ++s) {
+        int *row = h_rows + s * W;
+        for (int k = 0; k < W; ++k) row[k] = -1;
+        for (int q = 0; q < nw; ++q) row[q] = T.w_env[q];
+        for (int q = 0; q < nm; ++q)
+            if (s < plans[q].cmds.size()) {
+                const int slot = h_cnt[s]++;
+                row[nw + slot] = envs[movers[q]];
+                h_cmds[s * width + slot] = plans[q].cmds[s];
+            }
+    }
+    char *dev = (char *)T.d_tab;
+    T.busy = true; ctx->tickets_busy++;
+    auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); T.busy = false; ctx->tickets_busy--; return code; };
+    if (!fs_hip_ok(hipMemcpyAsync(dev, blob, off, hipMemcpyHostToDevice, ctx->stream), "fs_advance upload")) return fail(FS_ERR_HIP);
+    if (!ctx->adv_ev0) {
+        if (!fs_hip_ok(hipEventCreate(&ctx->adv_ev0), "event") || !fs_hip_ok(hipEventCreate(&ctx->adv_ev1), "event")) return fail(FS_ERR_HIP);
+    }
+    if (poll) (void)hipEventRecord(ctx->adv_ev0, ctx->stream);
+    const auto wall1 = std::chrono::steady_clock::now();
+    int **d_picked = (int **)(dev + o_picked);
+    float **d_saved = (float **)(dev + o_saved);
+    const FsWaitCmd *d_wcmd = (const FsWaitCmd *)(dev + o_wcmd);
+    const FsPickerCmd *d_cmds = (const FsPickerCmd *)(dev + o_cmds);
+    int *d_rows = (int *)(dev + o_rows);
+    std::vector<int> ids;
+    size_t launched = 0;
+    for (size_t s = 0; s < n_seq && rc == FS_OK; ++s) {
+        const int cnt = h_cnt[s];
+        int *d_row = d_rows + s * W;
+        ids.assign(h_rows + s * W, h_rows + s * W + nw + cnt);
+        if (cnt > 0) {
+            const double thr = picker_grasp_threshold(ctx->envs[ids[nw]]);
+            hipLaunchKernelGGL(fs_k_picker_step, dim3(cnt), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_shapes, d_row + nw,
+                               d_cmds + s * width, d_picked, d_saved, thr);
+        }
+        if (nw > 0)
+            hipLaunchKernelGGL(fs_k_wait_check, dim3(nw), dim3(256), 0, ctx->stream, ctx->d_envs, d_row, d_wcmd, ctx->d_wait,
+                               s == 0 ? 1 : 0);
+        rc = fs_step_ids(ctx, ids, 1, d_row);
+        ++launched;
+        if (poll && rc == FS_OK && nw > 0 && s >= mover_seq && (s & 15) == 15 && s + 1 < n_seq) {  // only waiters left: all retired?
+            hipError_t pe = hipMemcpyAsync(T.h_wait, ctx->d_wait, sizeof(FsWaitDev) * n_envs, hipMemcpyDeviceToHost, ctx->stream);
+            if (pe == hipSuccess) pe = hipStreamSynchronize(ctx->stream);
+            if (!fs_hip_ok(pe, "fs_advance poll")) { rc = FS_ERR_HIP; break; }
+            bool any = false;
+            for (int q = 0; q < nw; ++q) any = any || T.h_wait[T.w_env[q]].over == 0;
+            if (!any) break;
+        }
+    }
+    if (rc != FS_OK) return fail(rc);
+    hipError_t err = hipSuccess;
+    if (nw > 0) err = hipMemcpyAsync(T.h_wait, ctx->d_wait, sizeof(FsWaitDev) * n_envs, hipMemcpyDeviceToHost, ctx->stream);
+    if (err == hipSuccess && poll) err = hipEventRecord(ctx->adv_ev1, ctx->stream);
+    if (err == hipSuccess) err = hipEventRecord(T.done, ctx->stream);
+    if (!fs_hip_ok(err, "fs_advance results")) return fail(FS_ERR_HIP);
+    const auto wall2 = std::chrono::steady_clock::now();
+    ctx->adv_prep_ms += std::chrono::duration<double, std::milli>(wall1 - wall0).count();
+    T.wall_begin_ms = std::chrono::duration<double, std::milli>(wall2 - wall0).count();
+    ctx->adv_calls += 1;
+    ctx->adv_sequences += (long long)launched;
+    return tk;
+}
+
+// Waits for the ticket's launches and fills in the waiters' outputs: progress = steps of the loop taken so far, status 1 =
+// ended (stable / plain steps done), 2 = ended at its limit without becoming stable, 0 = call again; steps = progress -
+// start (-1 when the call continued a loop whose position the host did not state: start = -1).
+static int advance_end(fs_ctx *ctx, int ticket, int *progress_out, int *status_out, int *steps_out, bool timed) {
+    if (!ctx || ticket < 0 || ticket >= FS_ADV_TICKETS || !ctx->tickets[ticket].busy) {
+        fs_set_error("fs_advance_end: no such chunk in flight");
+        return FS_ERR_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    FsAdvTicket &T = ctx->tickets[ticket];
+    const auto wall0 = std::chrono::steady_clock::now();
+    const hipError_t err = hipEventSynchronize(T.done);
+    T.busy = false; ctx->tickets_busy--;
+    HIP_TRY(err);
+    if (timed) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->adv_ev0, ctx->adv_ev1) == hipSuccess) ctx->adv_gpu_ms += ms;
+    }
+    const int nw = (int)T.w_arg.size();
+    for (int q = 0; q < nw && T.n_seq > 0; ++q) {
+        const int a = T.w_arg[q];
+        const FsWaitDev w = T.h_wait[T.w_env[q]];
+        if (progress_out) progress_out[a] = w.steps;
+        if (steps_out) steps_out[a] = T.w_start[q] >= 0 ? w.steps - T.w_start[q] : -1;
+        if (status_out) status_out[a] = w.stable ? 1 : ((w.over || w.steps >= T.w_limit[q]) ? (T.w_kind[q] == 2 ? 1 : 2) : 0);
+    }
+    ctx->adv_wall_ms += T.wall_begin_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return FS_OK;
+}
+
+extern "C" int fs_advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
+                                const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start,
+                                double eps, const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out,
+                                int *steps_out) {
+    return advance_begin(ctx, n, envs, kind, targets, grasp, speed, limit, min_steps, f32, start, eps, tolerance, cap_min, cap,
+                         progress_out, status_out, steps_out, false);
+}
+extern "C" int fs_advance_end(fs_ctx *ctx, int ticket, int *progress_out, int *status_out, int *steps_out) {
+    return advance_end(ctx, ticket, progress_out, status_out, steps_out, false);
+}
+extern "C" int fs_advance_in_flight(const fs_ctx *ctx) { return ctx ? ctx->tickets_busy : FS_ERR_ARG; }
+
+extern "C" int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
+                          const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start,
+                          double eps, const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out,
+                          int *steps_out) {
+    if (ctx && start)
+        for (int a = 0; a < n; ++a)
+            if (start[a] < 0) { fs_set_error("fs_advance: start < 0 (continue from the device state) is for fs_advance_begin"); return FS_ERR_ARG; }
+    const int tk = advance_begin(ctx, n, envs, kind, targets, grasp, speed, limit, min_steps, f32, start, eps, tolerance, cap_min,
+                                 cap, progress_out, status_out, steps_out, true);
+    if (tk < 0) return tk;
+    return advance_end(ctx, tk, progress_out, status_out, steps_out, ctx->tickets[tk].n_seq > 0);
 }
 
 // fs_advance's stopwatch since the context was created: out[0] calls, [1] launch sequences, [2] wall ms inside the calls,

@@ -183,19 +183,20 @@ class BatchedFlingEnv:
         self.init_coverage = np.zeros(self.sim.n_envs)
         self.unpaid_steps = 0  # simulation steps the lock-step path does not count either (the step inside set_scene)
 
-    def episode_program(self, e, task, max_actions=None):
+    def episode_program(self, e, task, max_actions=None, prebuilt=None):
         """One episode in slot e -- SimEnv.reset (simEnv.py:663-697: set_scene(config, state), initial coverage, pickers,
         reset_end_effectors, one step, grasp off) and then SimEnv.step (simEnv.py:477-515) until it terminates -- written as
         the reference's straight-line code with a request wherever it needs the simulator, the policy or a reduction (see
         schedule.run_programs; evaluate.run_tasks provides the services "observe", "act", "coverage", "snapshot",
         "max_disp").  max_actions: the episode also ends after that many actions (None: episode_length alone).
+        prebuilt: the task's sim.PrebuiltScene when its host half was built ahead (tasks.ScenePrebuilder).
         Returns {'coverage': [initial, after step 1, ...] (absolute areas), 'actions': [primitive or None, ...]}."""
         from . import schedule as sch
 
         e = int(e)
         sim, prim = self.sim, self.prim
         ep = sch.Episode(prim, e)
-        load_task_scene(sim, e, task)
+        load_task_scene(sim, e, task, prebuilt=prebuilt)
         yield ("step", 1)
         self.unpaid_steps += 1
         load_task_state(sim, e, task)

@@ -56,7 +56,7 @@ def run_episodes(policy, env, tasks, max_steps=None, fold=True):
     }
 
 
-def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32, max_steps=None):
+def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=None, pipeline=True, prebuild=True):
     """The evaluation loop the way the reference actually runs it: every environment steps on its own, the policy acts for
     whichever environments are ready (utils.step_env, utils.py:394-418: `ray.wait` on the step futures), and an environment
     whose episode ends pulls the NEXT task by itself (SimEnv.step -> on_episode_end -> reset -> get_task_fn, tasks.py
@@ -72,6 +72,10 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32, max_steps=None):
     algorithm for another batch size and flip an arg-max, so with a net on the fallback every episode gets a forward of its
     own here (slower, same guarantee) and a warning says so.
     max_steps: at most that many actions per episode (run_episodes' argument of the same name; None = env.episode_length).
+    pipeline: chunks of simulation are queued ahead (schedule.run_programs_pipelined: fs_advance_begin / fs_advance_end, the
+    services on the context's service lane) so that the device does not wait while the host serves requests; False: the
+    blocking scheduler.  cap_min / cap: bounds of a chunk (defaults 1 / 4 pipelined, 4 / 32 blocking).
+    prebuild: the host half of every task's set_scene is built ahead of its turn on a worker thread (tasks.ScenePrebuilder).
     Returns run_episodes' dictionary (arrays ordered by task index) plus `scheduler` (launch statistics of the run);
     `simulation_steps` excludes the step inside every set_scene, as the lock-step path's count does."""
     from collections import deque
@@ -94,10 +98,14 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32, max_steps=None):
         warnings.warn("run_tasks: a value net runs on the PyTorch fallback (no fs_value_net_forward for its observation "
                       "size): one forward per episode, so that results do not depend on which slots are ready together")
 
+    from .tasks import ScenePrebuilder
+    scenes = ScenePrebuilder(tasks, ahead=max(8, len(slots) // 4)) if prebuild else None
+
     def slot_program(slot):
         while queue:
             ti, task = queue.popleft()
-            records[ti] = yield from env.episode_program(slot, task, max_actions=max_steps)
+            records[ti] = yield from env.episode_program(slot, task, max_actions=max_steps,
+                                                         prebuilt=scenes.get(ti) if scenes is not None else None)
 
     def observe(reqs):
         es = [e for e, _ in reqs]
@@ -122,7 +130,17 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=4, cap=32, max_steps=None):
 
     services = {"observe": observe, "act": act, "coverage": coverage, "snapshot": snapshot,
                 "max_disp": lambda reqs: list(sim.max_displacement([e for e, _ in reqs]))}
-    sch.run_programs(env.prim, {s: slot_program(s) for s in slots}, cap_min=cap_min, cap=cap, services=services)
+    if cap_min is None:
+        cap_min = 1 if pipeline else 4
+    if cap is None:
+        cap = 4 if pipeline else 32
+    try:
+        # (run_ahead: the programs' code between two requests is host-only -- schedule.py's primitives and episode_program)
+        sch.run_programs(env.prim, {s: slot_program(s) for s in slots}, cap_min=cap_min, cap=cap, services=services,
+                         pipeline=pipeline, run_ahead=True)
+    finally:
+        if scenes is not None:
+            scenes.close()
     n = len(tasks)
     flat = np.array([float(t["flatten_area"]) for t in tasks])
     lengths = np.array([len(records[i]["actions"]) for i in range(n)], int)

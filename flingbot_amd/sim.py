@@ -99,6 +99,12 @@ def load_library(build_if_missing=True):
         "fs_picker_set_radius": (ci, [vp, ci, C.c_double]),
         "fs_last_movep_steps": (C.c_longlong, [vp]),
         "fs_advance_timing": (ci, [vp, C.POINTER(C.c_double)]),
+        "fs_advance_begin": (ci, [vp, ci, ip, ip, C.POINTER(C.c_double), ip, C.POINTER(C.c_double), ip, ip, ip, ip, C.c_double,
+                                  C.POINTER(C.c_double), ci, ci, ip, ip, ip]),
+        "fs_advance_end": (ci, [vp, ci, ip, ip, ip]),
+        "fs_advance_in_flight": (ci, [vp]),
+        "fs_service_lane": (ci, [vp, ci]),
+        "fs_set_scene_prebuilt": (ci, [vp, ci, vp]),
         "fs_picker_get_picked": (ci, [vp, ci, ip, ci]),
         "fs_movep": (ci, [vp, ci, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
         "fs_movep_batch": (ci, [vp, ci, ip, C.POINTER(C.c_double), ip, C.c_double, ci, ci, C.c_double, ip]),
@@ -303,6 +309,38 @@ class FlingSim:
                                      _ip(prog), _ip(status), _ip(steps)))
         return prog, status, steps
 
+    def advance_begin(self, envs, kind, targets, grasp, speed, limit, min_steps, f32, start, cap_min=8, cap=64, eps=1e-4,
+                      tolerance=1e-2):
+        """fs_advance_begin: queue the chunk and return at once -> (ticket, progress, status, steps).  The movep entries'
+        results are final; a wait / step entry has status -1 until advance_end(ticket) and may pass start = -1 ("continue
+        from the loop state the device keeps") so that the next chunk can be queued before the previous one has reported."""
+        ids, kd = _i(envs), _i(kind)
+        n = ids.size
+        tg = np.ascontiguousarray(np.asarray(targets, np.float64).reshape(n, -1))
+        gr = _i(np.asarray(grasp).astype(np.int32).reshape(n, -1))
+        sp = np.ascontiguousarray(np.asarray(speed, np.float64).reshape(n))
+        lim, ms, f3, st = _i(limit), _i(min_steps), _i(f32), _i(start)
+        prog, status, steps = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        tol = np.ascontiguousarray(np.broadcast_to(np.asarray(tolerance, np.float64), (n,)))
+        dp = C.POINTER(C.c_double)
+        ticket = self._ck(self.lib.fs_advance_begin(self.h, n, _ip(ids), _ip(kd), tg.ctypes.data_as(dp), _ip(gr), sp.ctypes.data_as(dp),
+                                                    _ip(lim), _ip(ms), _ip(f3), _ip(st), float(eps), tol.ctypes.data_as(dp),
+                                                    int(cap_min), int(cap), _ip(prog), _ip(status), _ip(steps)))
+        return ticket, prog, status, steps
+
+    def advance_end(self, ticket, prog, status, steps):
+        """fs_advance_end: wait for the ticket's launches; fills the wait / step entries of the arrays advance_begin returned."""
+        self._ck(self.lib.fs_advance_end(self.h, int(ticket), _ip(prog), _ip(status), _ip(steps)))
+        return prog, status, steps
+
+    def advance_in_flight(self):
+        return self._ck(self.lib.fs_advance_in_flight(self.h))
+
+    def service_lane(self, on):
+        """fs_service_lane: True -> every call of this context runs on the high-priority service stream (for episodes that
+        are not part of a chunk in flight) until service_lane(False)."""
+        self._ck(self.lib.fs_service_lane(self.h, 1 if on else 0))
+
     def advance_timing(self):
         """fs_advance's stopwatch since the context was created: dict(calls, sequences, wall_ms, gpu_ms, prep_ms)."""
         out = np.zeros(5, np.float64)
@@ -358,6 +396,11 @@ class FlingSim:
         v, st, be, sh, fa = _f(vertices), _i(stretch_edges), _i(bend_edges), _i(shear_edges), _i(faces)
         self._ck(self.lib.fs_set_scene(self.h, env, _fp(sp), sp.size, _fp(v), v.size, _ip(st), st.size, _ip(be),
                                        be.size, _ip(sh), sh.size, _ip(fa), fa.size))
+
+    def set_scene_prebuilt(self, env, scene):
+        """fs_set_scene from a PrebuiltScene (host part done earlier, possibly on another thread); consumes it."""
+        self._ck(self.lib.fs_set_scene_prebuilt(self.h, env, scene.take()))
+        scene.free()
 
     def n_particles(self, env=0):
         return self._ck(self.lib.fs_n_particles(self.h, env))
@@ -559,6 +602,36 @@ SCENE_ARRAYS = {"positions": (0, np.float32), "velocities": (1, np.float32), "ph
                 "springs": (3, np.int32), "spring_lengths": (4, np.float32), "spring_stiffness": (5, np.float32),
                 "triangles": (6, np.int32), "tri_normals": (7, np.float32), "adj_offsets": (8, np.int32),
                 "adj_neighbors": (9, np.int32), "bounds": (10, np.float32), "params": (11, np.float32)}
+
+
+class PrebuiltScene:
+    """The host half of fs_set_scene (topology, adjacency tables, spring codes: fs_host_scene_build), built without the GPU --
+    on any thread: ctypes releases the GIL for the call -- and handed to FlingSim.set_scene_prebuilt later."""
+
+    def __init__(self, scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear_edges=(), faces=()):
+        self.lib = load_library()
+        sp = _f(scene_params)
+        v, st, be, sh, fa = _f(vertices), _i(stretch_edges), _i(bend_edges), _i(shear_edges), _i(faces)
+        self.h = self.lib.fs_host_scene_build(_fp(sp), sp.size, _fp(v), v.size, _ip(st), st.size, _ip(be), be.size, _ip(sh),
+                                              sh.size, _ip(fa), fa.size)
+        if not self.h:
+            raise FlingSimError("fs_host_scene_build failed: " + self.lib.fs_last_error().decode())
+
+    def take(self):
+        if not self.h:
+            raise FlingSimError("PrebuiltScene: already consumed")
+        return self.h
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.fs_host_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def host_sphere_mesh(radius, prev_pos, prev_quat):

@@ -179,6 +179,28 @@ long long fs_last_movep_steps(const fs_ctx *ctx);
 int fs_advance(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
                const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start, double eps,
                const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out, int *steps_out);
+/* fs_advance in two halves, so that the host can work while a chunk runs (flingbot_amd/schedule.py pipelines them: the
+   next chunk is queued, and the requests of the episodes that just finished something are served, while the device is
+   still busy with the previous one).
+   fs_advance_begin: same arguments; queues the chunk's launches on the context's main stream and returns a ticket (>= 0; at
+   most 4 may be open) or an error code (< 0).  The movep entries' outputs are final when it returns -- their trajectories
+   are planned on the host -- and so are those of a wait / step loop whose steps were already used up; every other wait /
+   step entry has status -1 until fs_advance_end.  start[a] = -1 for a wait / step entry CONTINUES the loop from the state
+   the device keeps per episode: the host may queue the next chunk of a wait before it knows whether the previous chunk
+   ended it (if it did, the episode's entries retire at once and nothing is stepped).
+   fs_advance_end: waits for the ticket's launches and fills in the wait / step entries (same index a as in the begin
+   call; progress = steps of the loop taken so far, steps = progress - start, or -1 for start = -1).
+   fs_advance_in_flight: open tickets. */
+int fs_advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, const double *targets, const int *grasp,
+                     const double *speed, const int *limit, const int *min_steps, const int *f32, const int *start, double eps,
+                     const double *tolerance, int cap_min, int cap, int *progress_out, int *status_out, int *steps_out);
+int fs_advance_end(fs_ctx *ctx, int ticket, int *progress_out, int *status_out, int *steps_out);
+int fs_advance_in_flight(const fs_ctx *ctx);
+/* The service lane: between fs_service_lane(ctx, 1) and fs_service_lane(ctx, 0) every entry point of the library works on
+   a second, high-priority stream, so that reductions, observations and resets for episodes that are NOT part of a chunk
+   in flight neither queue up behind the chunk nor wait for it.  Contract: on the lane the caller touches only such
+   episodes (or ones whose wait loop in the chunk has already ended).  Leaving the lane orders the main stream behind it. */
+int fs_service_lane(fs_ctx *ctx, int on);
 /* fs_advance's stopwatch since fs_create: out5 = calls, launch sequences, wall ms inside the calls, device ms between a
    call's first and last launch, wall ms the calls spent before their first launch (planning, tables, upload) */
 int fs_advance_timing(const fs_ctx *ctx, double *out5);
@@ -335,6 +357,9 @@ fs_host_scene *fs_host_scene_build(const float *scene_params, int n_params, cons
 void fs_host_scene_free(fs_host_scene *h);
 int fs_host_scene_counts(const fs_host_scene *h, int *n, int *m, int *t, int *max_deg);
 int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, int n_elems);
+/* fs_set_scene from a scene fs_host_scene_build made earlier (on any thread, without the GPU): the scene is taken out of
+   `scene`, which stays valid but empty (free it with fs_host_scene_free).  Same result as fs_set_scene. */
+int fs_set_scene_prebuilt(fs_ctx *ctx, int env, fs_host_scene *scene);
 /* host-only: the mesh of ONE kinematic sphere exactly as fs_render rasterises it (see fs_get_sphere_mesh) */
 int fs_host_sphere_mesh(float radius, const float *prev_pos3, const float *prev_quat4, float *verts, float *normals,
                         int *tris);

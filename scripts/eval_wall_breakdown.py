@@ -13,6 +13,9 @@ from flingbot_amd.env import BatchedFlingEnv
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+PIPE = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # 0: blocking scheduler
+CAP_MIN = int(sys.argv[5]) if len(sys.argv) > 5 else 0       # 0: run_tasks' default
+CAP = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 random.seed(1); np.random.seed(1); torch.manual_seed(1)
 tasks = []
 for k in range(0, N, S):
@@ -36,7 +39,7 @@ def timed(name, fn):
             acc[name] += time.perf_counter() - t; cnt[name] += 1
     return wrap
 
-for name in ("advance", "coverage", "snapshot_positions", "max_displacement", "observe_batch", "set_scene", "set_positions",
+for name in ("advance", "advance_begin", "advance_end", "coverage", "snapshot_positions", "max_displacement", "observe_batch", "set_scene", "set_positions",
              "set_velocities", "cloth_stats", "stretch_probe"):
     if hasattr(ctx, name):
         setattr(ctx, name, timed("sim." + name, getattr(ctx, name)))
@@ -47,9 +50,10 @@ for fn in ("load_task_scene", "load_task_state"):
     import flingbot_amd.env as fenv
     setattr(fenv, fn, timed(fn, getattr(fenv, fn)))
 t0 = time.perf_counter()
-stats = evaluate.run_tasks(policy, env, tasks)
+stats = evaluate.run_tasks(policy, env, tasks, pipeline=bool(PIPE), prebuild=bool(PIPE), cap_min=CAP_MIN or None, cap=CAP or None)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 flings = sum(stats["action_primitive_counts"].values())
+print("pipeline %d cap_min %d cap %d: " % (PIPE, CAP_MIN, CAP), end="")
 print("%d tasks / %d slots: %.2f s  %d flings (%.1f /s)  %d episode-steps (%.0f /s)" % (N, S, dt, flings, flings / dt, stats["simulation_steps"], stats["simulation_steps"] / dt))
 rest = dt
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
@@ -62,4 +66,5 @@ print("  fs_advance calls %d, launch sequences %d, mean active %.1f" % (st["call
 at = ctx.advance_timing()
 print("  inside fs_advance: wall %.2f s, device busy (first to last launch) %.2f s, before the first launch %.2f s, after the last launch (drain + results) %.2f s" % (
     at["wall_ms"] / 1e3, at["gpu_ms"] / 1e3, at["prep_ms"] / 1e3, (at["wall_ms"] - at["gpu_ms"] - at["prep_ms"]) / 1e3))
-print("  GPU idle while the loop ran: %.1f %% of the wall time" % (100 * (1 - at["gpu_ms"] / 1e3 / dt)))
+if not PIPE:
+    print("  GPU idle while the loop ran: %.1f %% of the wall time" % (100 * (1 - at["gpu_ms"] / 1e3 / dt)))

@@ -63,10 +63,12 @@ class OracleBatch:
         return [covered_area(s.get_positions()) for s in self.sims]
 
     def snapshot_positions(self, envs):
+        self._touch(envs)
         for e in envs:
             self.snap[e] = self.sims[e].get_positions().reshape(-1, 4)[:, :3].copy()  # SimEnv.preaction
 
     def max_displacement(self, envs):
+        self._touch(envs)
         out = []
         for e in envs:
             post = self.sims[e].get_positions().reshape(-1, 4)[:, :3]
@@ -114,13 +116,89 @@ class OracleBatch:
                 prog[a], status[a], steps[a] = start[a] + done, (1 if st == 2 and kind[a] == 2 else st), done
         return prog, status, steps
 
+    # ---- fs_advance_begin / fs_advance_end / fs_service_lane on the CPU oracles, with the PROTOCOL checked: the work of a
+    # chunk is done at once here (an oracle has no queue), but a wait / step entry's outcome stays hidden until advance_end,
+    # start = -1 continues from the loop state kept per episode, and every call that reads or writes an episode asserts that
+    # the episode is not a live part of an open chunk and that the lane is the right one
+    def _live(self, e):
+        return any(e in t["live"] for t in getattr(self, "_open", {}).values())
+
+    def _touch(self, envs):
+        for e in envs:
+            assert not self._live(int(e)), f"episode {e} touched while it is part of a chunk in flight"
+        if getattr(self, "_open", None):
+            assert getattr(self, "_lane", False), "host-side work while chunks are open must run on the service lane"
+
+    def service_lane(self, on):
+        self._lane = bool(on)
+
+    def advance_timing(self):
+        return dict(calls=getattr(self, "advance_calls", 0), sequences=getattr(self, "_sequences", 0), wall_ms=0.0, gpu_ms=0.0, prep_ms=0.0)
+
+    def advance_in_flight(self):
+        return len(getattr(self, "_open", {}))
+
+    def advance_begin(self, envs, kind, targets, grasp, speed, limit, min_steps, f32, start, cap_min=8, cap=64, eps=1e-4,
+                      tolerance=1e-2):
+        assert not getattr(self, "_lane", False), "chunks are queued on the main lane"
+        self._open = getattr(self, "_open", {})
+        self._wait = getattr(self, "_wait", {})
+        assert len(self._open) < 4
+        n = len(envs)
+        start = [int(x) for x in start]
+        tols = np.broadcast_to(np.asarray(tolerance, np.float64), (n,))
+        for a, e in enumerate(envs):  # loop states: set (start >= 0) or continued (start = -1)
+            if kind[a] != 0 and start[a] >= 0:
+                self._wait[int(e)] = dict(steps=start[a], stable=False, over=False)
+            assert kind[a] != 0 or start[a] >= 0
+        known = [start[a] if (kind[a] == 0 or start[a] >= 0) else self._wait[int(envs[a])]["steps"] for a in range(n)]
+        gone = [kind[a] != 0 and start[a] < 0 and self._wait[int(envs[a])]["over"] for a in range(n)]
+        act = [a for a in range(n) if not gone[a]]
+        prog, status, steps = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        if act:
+            p2, s2, t2 = self.advance([envs[a] for a in act], [kind[a] for a in act], [targets[a] for a in act],
+                                      [grasp[a] for a in act], [speed[a] for a in act], [limit[a] for a in act],
+                                      [min_steps[a] for a in act], [f32[a] for a in act], [known[a] for a in act],
+                                      cap_min=cap_min, cap=cap, eps=eps, tolerance=[tols[a] for a in act])
+            for k, a in enumerate(act):
+                prog[a], status[a], steps[a] = p2[k], s2[k], t2[k]
+        self._sequences = getattr(self, "_sequences", 0) + (int(steps.max()) if n else 0)
+        hidden, live = {}, set()
+        for a, e in enumerate(envs):
+            e = int(e)
+            if kind[a] == 0:
+                live.add(e)
+                continue
+            if start[a] >= 0 and limit[a] - start[a] <= 0:
+                continue  # answered at once, like the library
+            w = self._wait[e]
+            if not gone[a]:
+                w["steps"] = int(prog[a])
+                w["stable"] = bool(kind[a] == 1 and status[a] == 1)
+                w["over"] = bool(status[a] != 0)
+                live.add(e)  # (the host cannot know yet that the loop may have ended)
+            hidden[a] = (w["steps"], 1 if w["stable"] else ((1 if kind[a] == 2 else 2) if w["over"] else 0),
+                         (w["steps"] - start[a]) if start[a] >= 0 else -1)
+            prog[a], status[a], steps[a] = max(start[a], 0), -1, 0
+        ticket = max(self._open, default=-1) + 1
+        self._open[ticket] = dict(hidden=hidden, live=live)
+        return ticket, prog, status, steps
+
+    def advance_end(self, ticket, prog, status, steps):
+        t = self._open.pop(ticket)
+        for a, (p, s, d) in t["hidden"].items():
+            prog[a], status[a], steps[a] = p, s, d
+        return prog, status, steps
+
     def get_shape_states(self, e):
         return self.sims[e].get_shape_states()
 
     def get_positions(self, e):
+        self._touch([e])
         return self.sims[e].get_positions()
 
     def cloth_stats(self, envs):
+        self._touch(envs)
         out = np.empty((len(envs), 3), np.float32)
         for k, e in enumerate(envs):
             pos = self.sims[e].get_positions().reshape(-1, 4)
@@ -128,6 +206,7 @@ class OracleBatch:
         return out
 
     def stretch_probe(self, envs, midpoints_xz, height_thr):
+        self._touch(envs)
         single, near = [], []
         for k, e in enumerate(envs):
             positions = self.sims[e].get_positions().reshape((-1, 4))[:, :3]

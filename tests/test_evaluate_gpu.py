@@ -113,7 +113,9 @@ def test_async_task_loop_equals_lockstep_loop(gpu_required, actions):
     """evaluate.run_tasks -- every slot runs reset / act / step on its own and pulls the next task when its episode ends
     (run_sim.py:46-60 with utils.step_env's ray.wait asynchrony, utils.py:394-418) -- against evaluate.run_episodes, the
     lock-step loop, on the same six generated tasks: once with one slot per task and once with TWO slots for the six tasks
-    (continuous batching: tasks land in slots the lock-step run never used for them); with the fling-only policy of the
+    (continuous batching: tasks land in slots the lock-step run never used for them), each through the pipelined scheduler
+    (the default: chunks of simulation queued ahead, host-side services on the service lane while they run, scenes prebuilt
+    on a worker thread) and through the blocking one; with the fling-only policy of the
     reference's released model and with all four primitives in the action space (each episode then runs whichever program
     its own arg-max picked, side by side).  Coverage after every step, episode
     lengths, action counts and the simulation-step total are identical."""
@@ -128,11 +130,19 @@ def test_async_task_loop_equals_lockstep_loop(gpu_required, actions):
                                         for _ in range(n)])
     gen.close()
     results = []
-    for mode, slots in (("lockstep", n), ("async", n), ("async", 2)):
+    for mode, slots in (("lockstep", n), ("async", n), ("async", 2), ("async-blocking", n), ("async-blocking", 2), ("async-deep", 2)):
         ctx = fsim.FlingSim(n_envs=slots, solver=0)
         env = BatchedFlingEnv(ctx, action_primitives=actions, image_dim=128, episode_length=3)
         policy = _policy(env)
-        stats = (run_episodes if mode == "lockstep" else run_tasks)(policy, env, tasks)
+        if mode == "lockstep":
+            stats = run_episodes(policy, env, tasks)
+        elif mode == "async":            # the default: chunks queued ahead, services on the service lane, scenes prebuilt
+            stats = run_tasks(policy, env, tasks)
+        elif mode == "async-deep":       # one-sequence chunks, three of them open
+            stats = run_tasks(policy, env, tasks, cap_min=1, cap=1)
+        else:                            # the blocking scheduler, scenes built in place
+            stats = run_tasks(policy, env, tasks, pipeline=False, prebuild=False)
+        assert ctx.advance_in_flight() == 0
         assert all(net._hip is not None for net in policy.value_nets.values())
         results.append(stats)
         ctx.close()

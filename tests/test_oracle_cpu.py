@@ -756,9 +756,13 @@ def test_env_step_bookkeeping_reproduces_reference_golden():
                     lambda sim, k: sim.get_positions(k), lambda sim, k: sim.get_shape_states(k))
 
 
-def test_scheduler_requests_and_services_on_the_oracle():
+@pytest.mark.parametrize("mode", ["blocking", "pipelined", "pipelined-run-ahead", "pipelined-short-chunks"])
+def test_scheduler_requests_and_services_on_the_oracle(mode):
     """schedule.run_programs itself, no GPU: programs that mix plain steps, wait_until_stable with DIFFERENT tolerances and
-    budgets, a movep and a host-side service, against the same operations done one episode after the other."""
+    budgets, a movep and a host-side service, against the same operations done one episode after the other -- through the
+    blocking scheduler and through the pipelined one (chunks queued ahead with fs_advance_begin / fs_advance_end; the CPU
+    stand-in checks the protocol: no episode is touched while it is a live part of an open chunk, host-side work runs on
+    the service lane while chunks are open, chunks are queued on the main lane)."""
     from fling_helpers import OracleBatch, load_fling_golden
     from flingbot_amd import schedule as sch
     from flingbot_amd.primitives import FlingPrimitives
@@ -790,8 +794,12 @@ def test_scheduler_requests_and_services_on_the_oracle():
         seen.append(sorted(e for e, _ in reqs))
         return [10 * args[0] for _, args in reqs]
 
-    out = sch.run_programs(prim, {e: program(sch.Episode(prim, e), e) for e in range(n)}, cap_min=2, cap=5, services={"tag": tag})
+    kw = {"blocking": dict(cap_min=2, cap=5), "pipelined": dict(cap_min=2, cap=5, pipeline=True),
+          "pipelined-run-ahead": dict(cap_min=2, cap=5, pipeline=True, run_ahead=True),
+          "pipelined-short-chunks": dict(cap_min=1, cap=2, pipeline=True, run_ahead=True, depth=3)}[mode]
+    out = sch.run_programs(prim, {e: program(sch.Episode(prim, e), e) for e in range(n)}, services={"tag": tag}, **kw)
     assert sum(len(s) for s in seen) == n
+    assert a.advance_in_flight() == 0 and not getattr(a, "_lane", False)
     steps = 0
     for e in range(n):  # the same, sequentially, on the second batch
         b.step_list([e], 3 + e)
