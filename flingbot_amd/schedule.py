@@ -415,7 +415,11 @@ def run_programs_pipelined(prim, programs, cap_min=1, cap=4, eps=1e-4, services=
                 return
             set_lane(bool(open_tickets))
             for kind in sorted({pending[e]["kind"] for e in ready}):
-                who = sorted(e for e in ready if pending[e]["kind"] == kind)
+                # (a program served under an earlier kind of this pass may have ended or moved on to another request)
+                who = sorted(e for e in ready if e in pending and pending[e]["kind"] == kind and
+                             (pending[e]["after"] is None or pending[e]["after"]["closed"]))
+                if not who:
+                    continue
                 out = table[kind]([(e, pending[e]["args"]) for e in who])
                 for k, e in enumerate(who):
                     resume(e, out[k])
