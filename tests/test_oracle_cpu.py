@@ -814,6 +814,19 @@ def test_scheduler_requests_and_services_on_the_oracle(mode):
         assert np.array_equal(np.asarray(a.get_shape_states(e), np.float32).view(np.uint32),
                               np.asarray(b.get_shape_states(e), np.float32).view(np.uint32)), e
     assert prim.sim_steps == steps and len({out[e][0][1] for e in range(n)}) > 1
+
+    # a program that ENDS after a service while another episode stands at a service that is served later in the same pass
+    def short(ep, k):
+        if k == 0:
+            got = yield ("stats",)
+            return float(got[0])
+        if k == 2:
+            yield ("step", 1)
+        got = yield ("tag", k)
+        return got
+    out2 = sch.run_programs(prim, {e: short(sch.Episode(prim, e), e) for e in range(n)}, services={"tag": tag}, **kw)
+    assert out2[1] == 10 and out2[2] == 20 and out2[0] == float(a.cloth_stats([0])[0, 0])
+
     def bad():
         yield ("nonsense",)
 
