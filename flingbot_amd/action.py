@@ -191,10 +191,11 @@ class ActionSelector:
         return dict(valid_action=True, p1=P1, p2=P2, pretransform_pixels=np.array([pix_1, pix_2]),
                     left_or_right=left_or_right, scale=scale, rotation=rotation, max_indices=np.array([x, y, z]))
 
-    def select(self, value_maps, adaptive_scale_factors, pretransform_depth):
+    def select(self, value_maps, adaptive_scale_factors, pretransform_depth, depth_device=None):
         """value_maps: {primitive: CUDA float32 [T, D, D]} or a stacked CUDA tensor [P, T, D, D] in self.actions order;
-        pretransform_depth: [S, S] float32 (numpy or tensor).  Returns (action, action_params) like the reference, or
-        (None, None)."""
+        pretransform_depth: [S, S] float32 (numpy or tensor); depth_device: the same plane as a CUDA tensor when the caller
+        still has it there (the observation stage leaves it on the device: saves re-uploading 640 KB per action).
+        Returns (action, action_params) like the reference, or (None, None)."""
         if isinstance(value_maps, dict):
             stacked = torch.stack(tuple(value_maps[a] for a in self.actions))
         else:
@@ -208,8 +209,12 @@ class ActionSelector:
         depth_np = pretransform_depth.detach().cpu().numpy() if torch.is_tensor(pretransform_depth) else np.asarray(pretransform_depth)
         depth_np = np.ascontiguousarray(depth_np, np.float32)
         S = depth_np.shape[0]
-        d_depth = pretransform_depth.contiguous().float() if torch.is_tensor(pretransform_depth) and pretransform_depth.is_cuda \
-            else torch.from_numpy(depth_np).to(stacked.device)
+        if depth_device is not None and depth_device.is_cuda and tuple(depth_device.shape) == depth_np.shape:
+            d_depth = depth_device.contiguous().float()
+        elif torch.is_tensor(pretransform_depth) and pretransform_depth.is_cuda:
+            d_depth = pretransform_depth.contiguous().float()
+        else:
+            d_depth = torch.from_numpy(depth_np).to(stacked.device)
         mkey = (S, D, scales.tobytes())
         mats = self._mats.get(mkey)
         if mats is None:  # adaptive scale factors change per observation, but only between a handful of values

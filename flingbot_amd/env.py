@@ -52,6 +52,7 @@ class BatchedFlingEnv:
         self.envs, self.prim = [], None
         self.timestep, self.terminate = {}, {}
         self.pretransform_depth = {}
+        self.pretransform_depth_dev = {}   # the same planes where fs_observe left them (views of the observation tensors)
         self.adaptive_scale_factors = {}
 
     # ---- SimEnv.reset for a batch of tasks (entry e of `tasks` becomes episode e)
@@ -89,6 +90,7 @@ class BatchedFlingEnv:
         preprocess_obs -- all in fs_observe; returns float32 [4, S, S] on the device."""
         obs, bbox = self.sim.observe(e, self.image_dim)
         self.pretransform_depth[e] = obs[3].cpu().numpy()
+        self.pretransform_depth_dev[e] = obs[3]
         self.adaptive_scale_factors[e] = self._adaptive_factors(bbox)
         return obs
 
@@ -100,6 +102,7 @@ class BatchedFlingEnv:
         depth = obs[:, 3].cpu().numpy() if envs else None
         for k, e in enumerate(envs):
             self.pretransform_depth[e] = depth[k]
+            self.pretransform_depth_dev[e] = obs[k, 3]
             self.adaptive_scale_factors[e] = self._adaptive_factors(bbox[k])
         return obs
 
@@ -128,7 +131,8 @@ class BatchedFlingEnv:
         # the reference takes the snapshot and the coverage BEFORE selecting (simEnv.py:477-485); selection reads neither
         chosen = {}
         for e in run:
-            action, params = self.selector.select(value_maps[e], self.adaptive_scale_factors[e], self.pretransform_depth[e])
+            action, params = self.selector.select(value_maps[e], self.adaptive_scale_factors[e], self.pretransform_depth[e],
+                                                  depth_device=self.pretransform_depth_dev.get(e))
             if action is not None:
                 d, pix = self.pretransform_depth[e], params["pretransform_pixels"]
                 params["p1_grasp_cloth"] = self._on_cloth(d, (pix[0][1], pix[0][0]))
@@ -216,7 +220,8 @@ class BatchedFlingEnv:
         obs = yield ("observe",)
         while True:
             maps = yield ("act", obs)
-            action, params = self.selector.select(maps, self.adaptive_scale_factors[e], self.pretransform_depth[e])
+            action, params = self.selector.select(maps, self.adaptive_scale_factors[e], self.pretransform_depth[e],
+                                                  depth_device=self.pretransform_depth_dev.get(e))
             body = None
             if action is not None:
                 d, pix = self.pretransform_depth[e], params["pretransform_pixels"]

@@ -74,7 +74,7 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
     max_steps: at most that many actions per episode (run_episodes' argument of the same name; None = env.episode_length).
     pipeline: chunks of simulation are queued ahead (schedule.run_programs_pipelined: fs_advance_begin / fs_advance_end, the
     services on the context's service lane) so that the device does not wait while the host serves requests; False: the
-    blocking scheduler.  cap_min / cap: bounds of a chunk (defaults 1 / 4 pipelined, 4 / 32 blocking).
+    blocking scheduler.  cap_min / cap: bounds of a chunk (defaults 2 / 4 pipelined, 4 / 32 blocking).
     prebuild: the host half of every task's set_scene is built ahead of its turn on a worker thread (tasks.ScenePrebuilder).
     Returns run_episodes' dictionary (arrays ordered by task index) plus `scheduler` (launch statistics of the run);
     `simulation_steps` excludes the step inside every set_scene, as the lock-step path's count does."""
@@ -131,7 +131,7 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
     services = {"observe": observe, "act": act, "coverage": coverage, "snapshot": snapshot,
                 "max_disp": lambda reqs: list(sim.max_displacement([e for e, _ in reqs]))}
     if cap_min is None:
-        cap_min = 1 if pipeline else 4
+        cap_min = 2 if pipeline else 4
     if cap is None:
         cap = 4 if pipeline else 32
     try:
