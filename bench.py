@@ -194,7 +194,7 @@ def stream_limiter_from_profile():
                     "dependent_launches_per_frame": 129, "kernels": ker,
                     "note": "each launch is one wave's critical path (~890 VALU instructions at 0.233 of the 0.25 "
                             "VALU-active ceiling) plus dispatch/drain; two concurrent chains hide part of the turn-around "
-                            "(DESIGN 4.2)"}
+                            "(DESIGN.md 4.2)"}
         except Exception:
             continue
     return None

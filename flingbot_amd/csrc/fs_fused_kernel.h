@@ -12,8 +12,8 @@
 //                 grid cloth has nine) in LDS; the 12 packed words of a particle are streamed from L2 one particle
 //                 ahead of their use (shared by every episode of the same cloth).
 //   * generic  -- adjacency streamed from an L2-resident ELL table (any degree, any number of distinct springs).
-// DESIGN.md 4.1 describes the stages (predict, hash, two-phase neighbour search, contact set, iterations) and what was
-// measured, tried and rejected.
+// DESIGN.md 4.1 describes the stages (predict, hash, two-phase neighbour search, contact set, iterations); what was
+// measured, tried and rejected is in EXPERIMENTS.md (round-2 notes, 4.1 / 4.15).
 #pragma once
 #include "fs_constraints.h"
 

@@ -111,7 +111,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
         ctx->bound_attr_set = true;
     }
     // Concurrent chains.  A frame is 129 DEPENDENT launches, each about one wave's critical path long whatever the amount of
-    // work, so a launch list that cannot fill the chip is split into `groups` slot ranges (multiples of 8:
+    // work (measurements in EXPERIMENTS.md), so a launch list that cannot fill the chip is split into `groups` slot ranges (multiples of 8:
     // the XCD mapping of fs_stream_tile) whose chains run on streams of their own: while one chain's kernel drains and its
     // successor starts up, the other chains' kernels compute.  The chains are launched interleaved from this thread, fork
     // from and join into the context's stream through events; episodes are independent, results are bit-identical.

@@ -136,12 +136,12 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 // thread keeps its (up to 16) predicted positions in registers from the first pass to the last.  The arithmetic is that of
 // the four kernels, statement for statement; the order of the particles INSIDE a bucket differs (it was the order of the
 // global atomics before), which the search cannot see: its lists are sorted sets.  A frame is 129 dependent launches instead
-// of 140; measured in DESIGN.md 4.2.
+// of 140; measured in EXPERIMENTS.md (round-2 notes, 4.2 "The launch floor").
 #define FS_BOUND_THREADS 1024
 #define FS_BOUND_PPT 16
 #define FS_BOUND_MAX (FS_BOUND_THREADS * FS_BOUND_PPT)
 // histogram entry of bucket b: one pad word per 32 buckets, so that the scan's 16 consecutive buckets per thread (lane
-// stride 16 words = 2 banks for a whole wave) spread over all banks (measured: fs_k_boundary 24.5 -> see DESIGN.md 4.2)
+// stride 16 words = 2 banks for a whole wave) spread over all banks (measured: fs_k_boundary 24.5 -> 17.3 us, EXPERIMENTS.md round-2 notes 4.2)
 #define FS_BOUND_IDX(b) ((b) + ((b) >> 5))
 #define FS_BOUND_HIST (FS_GRID_BUCKETS + FS_GRID_BUCKETS / 32)
 #define FS_BOUND_LDS_BYTES (FS_BOUND_HIST * 4 + 64)
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
 // staged in LDS by coalesced loads, 2.6 dwordx4 loads per thread instead of 13 gathers -- was built and measured in round 2:
 // bit-identical and SLOWER at every launch size (64x64 x 64 episodes 1.480 -> 1.504 ms per step, x 8: 1.05 -> 1.17, x 256:
 // 4.19 -> 4.38): the gathers hit the L1 / the XCD's L2 and are not what a launch waits for, while the staging adds a barrier
-// and an LDS hop to the chain of dependent latencies that is.  Removed)
+// and an LDS hop to the chain of dependent latencies that is.  Removed; EXPERIMENTS.md, round-2 notes 4.2.)
 
 // The spring dictionary of the workgroup's episode -> LDS (one entry per thread; FS_TILE = 256 = dictionary size).
 template <bool CODED>

@@ -12,7 +12,7 @@ component and the adaptive scale SimEnv.get_obs derives from it, simEnv.py:699-7
 absent from this image, so that boundary is NOT pinned to the reference's own build.
 The grasp-on-cloth flags (simEnv.py:235-255) test `depth != 2.0` on a Euclidean disc of conservative_grasp_radius, which
 is pixel for pixel the filled cv2.circle (OpenCV's midpoint fill) for radii up to 6; the reference's default is 1.
-Every other stage is pinned on its own in tests/ (see DESIGN.md 4.4-4.65).
+Every other stage is pinned on its own in tests/ (see DESIGN.md section 2 and 4.3-4.8).
 """
 import numpy as np
 import torch

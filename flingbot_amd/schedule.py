@@ -4,7 +4,7 @@
 `fs_movep_batch` call that lasts as long as its SLOWEST episode, and the stretch / lift loops, the five moves of the fling
 and the settling all wait for each other.  In the evaluation loop (32 cloths of different sizes in different poses) that
 leaves half of the episodes idle in the average launch sequence, and a launch sequence of the streaming back-end costs the
-same ~1 ms whether 16 or 32 episodes take part in it.
+same ~1 ms whether 16 or 32 episodes take part in it (EXPERIMENTS.md, section 4.7 of the round-2 notes).
 
 Here every episode runs the reference's straight-line code as its own coroutine -- the same statements in the same order
 as environment/simEnv.py, one episode at a time --

@@ -11,5 +11,7 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $ARGS > $OUT/
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python3 $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python3 $ARGS > $OUT/bench_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o sq -- python3 $ARGS > $OUT/bench_sq.log 2>&1
+# memory instructions (scratch = spill traffic shows up in the VMEM / FLAT counts; EXPERIMENTS.md R3.4)
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_INSTS_SALU SQ_WAVES -d $OUT/pmc_mem -o mem -- python3 $ARGS > $OUT/bench_mem.log 2>&1
 cd $ROOT
 find $OUT -name "*.csv" | head -30

@@ -44,8 +44,9 @@ summary = {"tag": args.tag,
            "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline "
                       "--no-secondary --no-parity",
            "kernel": dom[0], "calls": dom[1], "average_us_all_launches": dom[3], "percent_of_gpu_time": dom[4],
+           "episodes": args.episodes, "waves_per_simd": 4,
            "timed_launches": len(last), "average_us": sum(last) / len(last) / 1e3, "counters": {}}
-for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_mem"):
     try:
         c = db(sub)
     except FileNotFoundError:
