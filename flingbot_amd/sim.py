@@ -341,6 +341,10 @@ class FlingSim:
         are not part of a chunk in flight) until service_lane(False)."""
         self._ck(self.lib.fs_service_lane(self.h, 1 if on else 0))
 
+    def last_movep_steps_raw(self):
+        """fs_last_movep_steps: simulation steps of the movep entries of the most recent fs_movep* / fs_advance* call."""
+        return int(self.lib.fs_last_movep_steps(self.h))
+
     def advance_timing(self):
         """fs_advance's stopwatch since the context was created: dict(calls, sequences, wall_ms, gpu_ms, prep_ms)."""
         out = np.zeros(5, np.float64)

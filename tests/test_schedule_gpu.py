@@ -81,6 +81,104 @@ def test_advance_waiters_match_wait_until_stable_golden(gpu_required):
     assert (int(prog[0]), int(status[0]), int(steps[0])) == (5, 2, 0)
 
 
+@pytest.mark.parametrize("depth", [2, 3])
+def test_advance_begin_end_waiters_queued_ahead_match_golden(gpu_required, depth):
+    """The same wait_until_stable golden through fs_advance_begin / fs_advance_end with `depth` chunks open: every chunk after
+    an episode's first lists it with start = -1 (continue from the loop state on the device) BEFORE the previous chunk has
+    reported, so an episode that settles in chunk k still has entries in the chunks queued behind it -- they must retire
+    without stepping.  While chunks are in flight the service lane serves another context-level request (cloth statistics
+    of a finished episode).  Step counts, stability flags and final states equal the golden's bit for bit."""
+    from collections import deque
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+    n = len(g["terminate"])
+    ctx = _make(g, n)
+    prim = FlingPrimitives(ctx, range(n))
+    prim.pick_and_fling(g["p1"], g["p2"], g["g1"], g["g2"])
+    for e in range(n):
+        lifted = ctx.get_positions(e).reshape(-1, 4).copy()
+        lifted[:, 1] += np.float32(0.25)
+        ctx.set_positions(e, lifted.ravel())
+        vel = np.zeros((lifted.shape[0], 3), np.float32)
+        vel[:, 1] = -0.5
+        ctx.set_velocities(e, vel.ravel())
+    z = np.zeros((n, 2, 3))
+    live, first, total, done = list(range(n)), {e: True for e in range(n)}, {}, {}
+    open_chunks, chunks, lane_calls = deque(), 0, 0
+    while live or open_chunks:
+        if live and len(open_chunks) < depth:
+            k = len(live)
+            start = [0 if first[e] else -1 for e in live]
+            ticket, prog, status, steps = ctx.advance_begin(live, [1] * k, z[:k], np.zeros((k, 2), int), [0.0] * k, [200] * k,
+                                                            [-1] * k, [0] * k, start, cap_min=7, cap=7, tolerance=2e-2)
+            assert (status == -1).all()  # a wait's outcome is the device's to decide
+            for e in live:
+                first[e] = False
+            open_chunks.append((ticket, list(live), prog, status, steps))
+            chunks += 1
+            assert ctx.advance_in_flight() == len(open_chunks)
+            continue
+        ticket, who, prog, status, steps = open_chunks.popleft()
+        if done:  # host-side work for an episode that is NOT part of the running chunks any more, on the service lane
+            ctx.service_lane(True)
+            e0 = next(iter(done))
+            assert ctx.cloth_stats([e0]).shape == (1, 3)
+            ctx.service_lane(False)
+            lane_calls += 1
+        ctx.advance_end(ticket, prog, status, steps)
+        for q, e in enumerate(who):
+            if e in done:
+                assert status[q] != 0 and int(prog[q]) == total[e]  # a stale entry repeats the final report
+                continue
+            total[e] = int(prog[q])
+            if status[q] != 0:
+                done[e] = status[q] == 1
+                live.remove(e)
+    assert ctx.advance_in_flight() == 0 and chunks > 3 and lane_calls > 0
+    assert [total[e] for e in range(n)] == g["steps_drop"].tolist() and [done[e] for e in range(n)] == g["stable_drop"].tolist()
+    for e in range(n):
+        assert np.array_equal(ctx.get_positions(e).view(np.uint32), g["pos_final"][e].view(np.uint32)), e
+        assert np.array_equal(ctx.get_shape_states(e).view(np.uint32), g["shapes_final"][e].view(np.uint32)), e
+    # protocol errors: chunks are queued on the main lane; a ticket is closed once; the blocking call refuses start = -1
+    from flingbot_amd.sim import FlingSimError
+    ctx.service_lane(True)
+    with pytest.raises(FlingSimError):
+        ctx.advance_begin([0], [2], z[:1], [[0, 0]], [0.0], [1], [-1], [0], [0])
+    ctx.service_lane(False)
+    with pytest.raises(FlingSimError):
+        ctx.advance_end(0, np.zeros(1, np.int32), np.zeros(1, np.int32), np.zeros(1, np.int32))
+    with pytest.raises(FlingSimError):
+        ctx.advance([0], [1], z[:1], [[0, 0]], [0.0], [5], [-1], [0], [-1])
+
+
+def test_advance_begin_reports_movers_at_once(gpu_required):
+    """fs_advance_begin's movep entries are final when it returns (the trajectory is planned on the host): progress, status
+    and step counts equal the blocking fs_advance's on a twin context, chunk by chunk, and so do the final states; plain-step
+    entries ride along and report at fs_advance_end."""
+    g = load_fling_golden()
+    a, b = _make(g, 2), _make(g, 2)
+    targets = np.array([[[0.12, 0.25, -0.05], [-0.12, 0.25, -0.05]], [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]])
+    grasp = [[0, 0], [0, 0]]
+    start, wstart = 0, 0
+    for _ in range(40):
+        args = ([0, 1], [0, 2], targets, grasp, [5e-3, 0.0], [1000, 30], [-1, -1], [0, 0])
+        pa, sa, ta = a.advance(*args, [start, wstart], cap_min=4, cap=6)
+        ticket, pb, sb, tb = b.advance_begin(*args, [start, wstart], cap_min=4, cap=6)
+        assert (int(pb[0]), int(sb[0]), int(tb[0])) == (int(pa[0]), int(sa[0]), int(ta[0]))
+        assert int(sb[1]) == -1 or wstart >= 30
+        b.advance_end(ticket, pb, sb, tb)
+        assert pb.tolist() == pa.tolist() and sb.tolist() == sa.tolist() and tb.tolist() == ta.tolist()
+        start, wstart = int(pa[0]), int(pa[1])
+        if sa[0] != 0:
+            break
+    assert sa[0] == 1 and start > 10
+    for e in range(2):
+        assert np.array_equal(a.get_positions(e).view(np.uint32), b.get_positions(e).view(np.uint32))
+        assert np.array_equal(a.get_shape_states(e).view(np.uint32), b.get_shape_states(e).view(np.uint32))
+    assert a.last_movep_steps_raw() == b.last_movep_steps_raw() > 0
+
+
 def test_scheduled_drag_place_stretchdrag_match_reference_golden(gpu_required):
     """All cases of primitives_golden.npz -- three different primitives -- in ONE scheduling run."""
     g = load_primitives_golden()
