@@ -833,6 +833,17 @@ def test_scheduler_requests_and_services_on_the_oracle(mode):
     with pytest.raises(ValueError):
         sch.run_programs(prim, {0: bad()})
 
+    # an exception in the middle of a run (a program's own, or a service's) leaves nothing in flight and the lane switched back
+    def failing(ep, k):
+        yield ("step", 2)
+        if k == 1:
+            raise RuntimeError("program failed")
+        yield ("wait", 30, 1e-9)
+
+    with pytest.raises(RuntimeError, match="program failed"):
+        sch.run_programs(prim, {e: failing(sch.Episode(prim, e), e) for e in range(n)}, **kw)
+    assert a.advance_in_flight() == 0 and not getattr(a, "_lane", False)
+
 
 def test_host_scene_derived_tables_match_brute_force():
     """The kernels' derived topology tables, built by fs_scene.cpp (no GPU): the rest-near ids of the SelfCollideFilter test
