@@ -259,6 +259,22 @@ def _serve_probe(sim, reqs):
     return [(bool(single[k]), nearest[k]) for k in range(len(reqs))]
 
 
+def _request_record(prim, e, req, table):
+    """The scheduler's record of a program's request (see run_programs for the request forms)."""
+    if req[0] == "movep":
+        _, targets, speed, min_steps, limit = req
+        return dict(kind=0, targets=np.asarray(targets, np.float64).reshape(-1, 3), f32=int(targets.dtype == np.float32),
+                    grasp=[int(bool(g)) for g in prim.grasp_states[e]], speed=float(speed),
+                    min_steps=-1 if min_steps is None else int(min_steps), limit=int(limit), start=0, steps=0)
+    if req[0] == "wait":
+        return dict(kind=1, limit=int(req[1]), tolerance=float(req[2]), start=0, steps=0, known=0, open=0)
+    if req[0] == "step":
+        return dict(kind=2, limit=int(req[1]), start=0, steps=0, known=0, open=0)
+    if req[0] in table:
+        return dict(kind=req[0], args=req[1:], after=None)
+    raise ValueError(f"run_programs: unknown request {req[0]!r} from episode {e}")
+
+
 def run_programs(prim, programs, cap_min=8, cap=64, eps=1e-4, services=None, pipeline=False, depth=2, run_ahead=False):
     """Run {episode: generator} to completion on prim.sim; returns {episode: the program's return value}.  Simulation steps
     are added to prim.sim_steps.  cap_min / cap: bounds of one fs_advance chunk (see include/flingsim.h).
@@ -284,20 +300,7 @@ def run_programs(prim, programs, cap_min=8, cap=64, eps=1e-4, services=None, pip
             results[e] = stop.value
             pending.pop(e, None)
             return
-        if req[0] == "movep":
-            _, targets, speed, min_steps, limit = req
-            pending[e] = dict(kind=0, targets=np.asarray(targets, np.float64).reshape(-1, 3),
-                              f32=int(targets.dtype == np.float32), grasp=[int(bool(g)) for g in prim.grasp_states[e]],
-                              speed=float(speed), min_steps=-1 if min_steps is None else int(min_steps), limit=int(limit),
-                              start=0, steps=0)
-        elif req[0] == "wait":
-            pending[e] = dict(kind=1, limit=int(req[1]), tolerance=float(req[2]), start=0, steps=0)
-        elif req[0] == "step":
-            pending[e] = dict(kind=2, limit=int(req[1]), start=0, steps=0)
-        elif req[0] in table:
-            pending[e] = dict(kind=req[0], args=req[1:])
-        else:
-            raise ValueError(f"run_programs: unknown request {req[0]!r} from episode {e}")
+        pending[e] = _request_record(prim, e, req, table)
 
     for e in sorted(gens):
         resume(e, None)
@@ -391,20 +394,9 @@ def run_programs_pipelined(prim, programs, cap_min=1, cap=4, eps=1e-4, services=
             results[e] = stop.value
             pending.pop(e, None)
             return
-        if req[0] == "movep":
-            _, targets, speed, min_steps, limit = req
-            pending[e] = dict(kind=0, targets=np.asarray(targets, np.float64).reshape(-1, 3),
-                              f32=int(targets.dtype == np.float32), grasp=[int(bool(g)) for g in prim.grasp_states[e]],
-                              speed=float(speed), min_steps=-1 if min_steps is None else int(min_steps), limit=int(limit),
-                              start=0, steps=0)
-        elif req[0] == "wait":
-            pending[e] = dict(kind=1, limit=int(req[1]), tolerance=float(req[2]), start=0, known=0, open=0)
-        elif req[0] == "step":
-            pending[e] = dict(kind=2, limit=int(req[1]), start=0, known=0, open=0)
-        elif req[0] in table:
-            pending[e] = dict(kind=req[0], args=req[1:], after=after)
-        else:
-            raise ValueError(f"run_programs: unknown request {req[0]!r} from episode {e}")
+        pending[e] = _request_record(prim, e, req, table)
+        if isinstance(pending[e]["kind"], str):
+            pending[e]["after"] = after
 
     def serve_host():
         """One batched call per kind for every episode that stands at a host-side request and is not waiting for an open
@@ -438,7 +430,7 @@ def run_programs_pipelined(prim, programs, cap_min=1, cap=4, eps=1e-4, services=
             [r["limit"] for r in reqs], [r.get("min_steps", -1) for r in reqs], [r.get("f32", 0) for r in reqs],
             [r["start"] if (r["kind"] == 0 or r["open"] == 0) else -1 for r in reqs], cap_min=cap_min, cap=cap, eps=eps,
             tolerance=[r.get("tolerance", -1.0) for r in reqs])
-        T = dict(ticket=ticket, prog=prog, status=status, steps=steps, waiters=[], finishers=[], closed=False, size=len(order))
+        T = dict(ticket=ticket, prog=prog, status=status, steps=steps, waiters=[], finishers=[], closed=False)
         open_tickets.append(T)
         st["calls"] += 1
         for k, e in enumerate(order):
@@ -501,7 +493,5 @@ def run_programs_pipelined(prim, programs, cap_min=1, cap=4, eps=1e-4, services=
                 pass
             T["closed"] = True
         set_lane(False)
-        seq = sim.advance_timing()["sequences"] - seq0
-        st["sequences"] += int(seq)
-        st["slots"] += 0
+        st["sequences"] += int(sim.advance_timing()["sequences"] - seq0)
     return results
