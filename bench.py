@@ -248,6 +248,10 @@ def timed_batch(ctx, fdist, torch, steps, warmup, preroll):
                                            # frame per launch like the timed steps, so a profile sees launches of ONE shape
     for _ in range(warmup):
         ctx.step(1)
+    # the exchange step is warmed up like the kernels: the first collective of a process group builds RCCL's communicators
+    # (hundreds of milliseconds) and the first device tensors go through the allocator -- neither belongs in a timed window
+    fdist.gather_rewards(ctx.coverage(), device="cuda")
+    fdist.max_over_ranks(0.0, device="cuda")
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()                      # HIP events on the stream the kernels are launched on
@@ -274,6 +278,8 @@ def timed_windows(ctx, fdist, torch, steps, warmup, preroll, windows=3):
 
     for _ in range(preroll + warmup):
         ctx.step(1)
+    fdist.gather_rewards(ctx.coverage(), device="cuda")   # (warm: see timed_batch)
+    fdist.max_over_ranks(0.0, device="cuda")
     ctx.sync()
     snap = [(ctx.get_positions(e), ctx.get_velocities(e)) for e in range(ctx.n_envs)]
     out, cov_all = [], None
