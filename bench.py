@@ -477,7 +477,7 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=192, stream
     render -> 400 x 400 observation with adaptive scaling, 12 rotations x 8 scales, seeded random-init fling policy
     (flingbot.pth is not in this image), up to `actions` actions per episode.  The loop is flingbot_amd.evaluate.run_tasks:
     like the reference's (utils.step_env's ray.wait, SimEnv pulling its next task) every slot steps on its own and refills
-    itself.  Two figures: `episodes` tasks on as many slots (the configuration of the earlier rounds' figure), and
+    itself, and the device is kept busy while the host serves requests (schedule.run_programs_pipelined).  Two figures: `episodes` tasks on as many slots (the configuration of the earlier rounds' figure), and
     `continuous`: stream_tasks tasks through stream_slots slots (throughput of a long evaluation run).  Reports flings/s and
     simulated episode-steps/s of the whole loop (perception + action selection + primitives + resets)."""
     try:
@@ -520,7 +520,10 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=192, stream
                     "mean_init_coverage": stats["mean"]["init_coverage"], "mean_final_coverage": stats["mean"]["final_coverage"]}
 
         out = one(episodes, episodes, 0)
-        out.update({"baseline_config": "configs[4]", "loop": "evaluate.run_tasks (asynchronous slots, run_sim.py / utils.step_env)",
+        out.update({"baseline_config": "configs[4]",
+                    "loop": "evaluate.run_tasks (asynchronous slots like run_sim.py / utils.step_env; chunks of simulation queued "
+                            "ahead with fs_advance_begin / fs_advance_end, host-side services on the service lane, scenes "
+                            "prebuilt on a worker thread)",
                     "policy": "random-init fling value net (seeded)"})
         if stream_tasks > 0:
             out["continuous"] = one(stream_tasks, stream_slots, 1)
