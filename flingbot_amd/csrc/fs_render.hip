@@ -98,11 +98,12 @@ __device__ __forceinline__ int fs_wave_max_i(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void fs_k_coverage(const FsEnvDev *envs, double *out, float particle_radius) {
+#define FS_COV_THREADS 1024  // one workgroup per episode: 16 waves go through the three passes over the particles
+__global__ __launch_bounds__(FS_COV_THREADS) void fs_k_coverage(const FsEnvDev *envs, double *out, float particle_radius) {
     const FsEnvDev &E = envs[blockIdx.x];
     __shared__ unsigned char grid[10000];
-    __shared__ float red[4][4];
-    __shared__ int redi[2][4];
+    __shared__ float red[4][FS_COV_THREADS / 64];
+    __shared__ int redi[2][FS_COV_THREADS / 64];
     __shared__ int total;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (!E.has_scene || E.n <= 0) {
@@ -111,24 +112,24 @@ __global__ __launch_bounds__(256) void fs_k_coverage(const FsEnvDev *envs, doubl
     }
     const int n = E.n;
     float mnx = 3.402823466e+38f, mnz = 3.402823466e+38f, mxx = -3.402823466e+38f, mxz = -3.402823466e+38f;
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += FS_COV_THREADS) {
         const FsVec4 p = E.pos[i];
         mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
         mnz = fminf(mnz, p.z); mxz = fmaxf(mxz, p.z);
     }
     mnx = fs_wave_min(mnx); mnz = fs_wave_min(mnz); mxx = fs_wave_max(mxx); mxz = fs_wave_max(mxz);
     if (lane == 0) { red[0][wave] = mnx; red[1][wave] = mnz; red[2][wave] = mxx; red[3][wave] = mxz; }
-    for (int q = t; q < 10000; q += 256) grid[q] = 0;
+    for (int q = t; q < 10000; q += FS_COV_THREADS) grid[q] = 0;
     if (t == 0) total = 0;
     __syncthreads();
-    mnx = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
-    mnz = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
-    mxx = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-    mxz = fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]));
+    for (int w = 0; w < FS_COV_THREADS / 64; ++w) {  // (min / max: the order of the reduction cannot change the result)
+        mnx = fminf(mnx, red[0][w]); mnz = fminf(mnz, red[1][w]);
+        mxx = fmaxf(mxx, red[2][w]); mxz = fmaxf(mxz, red[3][w]);
+    }
     const float span0 = (mxx - mnx) / 100.0f, span1 = (mxz - mnz) / 100.0f;
     // pass A: N = max(end - start) + 1 per axis
     int ex = -2147483647, ez = -2147483647;
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += FS_COV_THREADS) {
         const FsVec4 p = E.pos[i];
         const float ox = p.x - mnx, oz = p.z - mnz;
         long long xl = (long long)rintf((ox - particle_radius) / span0), xh = (long long)rintf((ox + particle_radius) / span0);
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void fs_k_coverage(const FsEnvDev *envs, doubl
     ex = fs_wave_max_i(ex); ez = fs_wave_max_i(ez);
     if (lane == 0) { redi[0][wave] = ex; redi[1][wave] = ez; }
     __syncthreads();
-    for (int w = 0; w < 4; ++w) { ex = redi[0][w] > ex ? redi[0][w] : ex; ez = redi[1][w] > ez ? redi[1][w] : ez; }
+    for (int w = 0; w < FS_COV_THREADS / 64; ++w) { ex = redi[0][w] > ex ? redi[0][w] : ex; ez = redi[1][w] > ez ? redi[1][w] : ez; }
     const int Nx = ex + 1, Nz = ez + 1;
     // pass B: mark cells
-    for (int i = t; i < n; i += 256) {
+    for (int i = t; i < n; i += FS_COV_THREADS) {
         const FsVec4 p = E.pos[i];
         const float ox = p.x - mnx, oz = p.z - mnz;
         long long xl = (long long)rintf((ox - particle_radius) / span0), xh = (long long)rintf((ox + particle_radius) / span0);
@@ -161,14 +162,14 @@ __global__ __launch_bounds__(256) void fs_k_coverage(const FsEnvDev *envs, doubl
     }
     __syncthreads();
     int cnt = 0;
-    for (int q = t; q < 10000; q += 256) cnt += grid[q];
+    for (int q = t; q < 10000; q += FS_COV_THREADS) cnt += grid[q];
     atomicAdd(&total, cnt);
     __syncthreads();
     if (t == 0) out[blockIdx.x] = (double)total * (double)span0 * (double)span1;
 }
 
 int fs_coverage_all(fs_ctx *ctx, double *out) {
-    hipLaunchKernelGGL(fs_k_coverage, dim3(ctx->n_envs), dim3(256), 0, ctx->stream, ctx->d_envs, ctx->d_coverage,
+    hipLaunchKernelGGL(fs_k_coverage, dim3(ctx->n_envs), dim3(FS_COV_THREADS), 0, ctx->stream, ctx->d_envs, ctx->d_coverage,
                        0.00625f);
     HIP_TRY(hipGetLastError());
     const size_t bytes = sizeof(double) * ctx->n_envs;
