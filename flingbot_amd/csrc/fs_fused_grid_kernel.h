@@ -37,7 +37,7 @@
 #define FG_OFF_XX FG_PAD
 #define FG_OFF_X0 (FG_OFF_XX + 4 * FG_PLANE)   // X0x | X0y | X0z (bucket-ordered predicted positions during the search)
 #define FG_OFF_CUR (FG_OFF_X0 + 3 * FG_PLANE)
-#define FG_OFF_ITEMS (FG_OFF_CUR + FS_FUSED_BUCKETS * 4)
+#define FG_OFF_ITEMS (FG_OFF_CUR + FS_FUSED_CUR_BYTES)
 #define FG_OFF_SCAN (FG_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
 #define FG_OFF_CSET (FG_OFF_SCAN + 64)
 #define FG_OFF_CACC (FG_OFF_CSET + FS_FUSED_CSET_CAP * 2)
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
     float *X0x = (float *)(smem + FG_OFF_X0);
     float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
     float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
-    int *cursor = (int *)(smem + FG_OFF_CUR);
+    unsigned short *cursor = (unsigned short *)(smem + FG_OFF_CUR);
     unsigned short *items = (unsigned short *)(smem + FG_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FG_OFF_SCAN);
     float *rowL = (float *)(smem + FG_OFF_ROWL);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
             // ---- predict from (X0, vel); build the spatial hash (XS = bucket-ordered copy in the X0 region)
-            for (int q = t; q < FS_FUSED_BUCKETS; q += FS_FUSED_THREADS) cursor[q] = 0;
+            for (int q = t; q < FS_FUSED_BUCKETS / 2; q += FS_FUSED_THREADS) ((unsigned *)cursor)[q] = 0u;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
             for (int k = 0; k < FS_FUSED_PPT; ++k) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
                 const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};
                 g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lci)cursor, (fs_lcus)items, g_phase,
+                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
                                                                        g_rest, g_nlist, near,
                                                                        (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
             }

@@ -23,7 +23,15 @@
 #define FS_FUSED_PPT (4096 / FS_FUSED_THREADS)
 #define FS_FUSED_MAX_PARTICLES (FS_FUSED_THREADS * FS_FUSED_PPT)
 #define FS_FUSED_MAX_DEG 64
-#define FS_FUSED_BUCKETS 4096  // hashed cells (fs_fused_bucket: row hash + x)
+#ifndef FS_FUSED_BUCKET_BITS
+#define FS_FUSED_BUCKET_BITS 13
+#endif
+#define FS_FUSED_BUCKETS (1 << FS_FUSED_BUCKET_BITS)  // hashed cells (fs_fused_bucket: row hash + x).  The bucket table holds
+                               // 16-BIT entries, two per LDS word: a count or a prefix sum never exceeds the 4096 particles of
+                               // an episode, so 8192 buckets fit the 16 KiB that 4096 32-bit entries took -- a cell then
+                               // shares its bucket with another cell half as often, and every aliased particle is a candidate
+                               // the search has to test and reject (EXPERIMENTS.md R3.7)
+#define FS_FUSED_CUR_BYTES (FS_FUSED_BUCKETS * 2)
 #define FS_FUSED_SLOTS 16      // compact adjacency slots per particle
 
 // LDS carve (bytes):
@@ -31,7 +39,7 @@
 //   X    float4[4096]   current Jacobi iterate (xyz + invMass); search queues while the search runs   64 KiB
 //   X0   float[3][4096] substep-start position (own displacement + neighbours' for friction);
 //                       bucket-ordered predicted positions XS while the search runs                  48 KiB
-//   HASH cursor int[4096] | items u16[4096] | scan int[16]   (neighbour search only)           24 KiB
+//   HASH cursor u16[8192] | items u16[4096] | scan int[16]   (neighbour search only)           24 KiB
 //   contact set: cset u16[CAP] | cacc float4[CAP] | chist int[128], CAP = min(1024, threads)   18.5 KiB
 // The next iterate needs no LDS: each thread carries its four new positions in a rotating set of registers.
 // (DICT and X sit below 64 KiB so their bases fold into the 16-bit offset field of the ds_read instructions; the gather
@@ -40,7 +48,7 @@
 #define FS_FUSED_OFF_X (FS_FUSED_OFF_DICT + 256 * 8)
 #define FS_FUSED_OFF_X0 (FS_FUSED_OFF_X + FS_FUSED_MAX_PARTICLES * 16)
 #define FS_FUSED_OFF_CUR (FS_FUSED_OFF_X0 + FS_FUSED_MAX_PARTICLES * 12)
-#define FS_FUSED_OFF_ITEMS (FS_FUSED_OFF_CUR + FS_FUSED_BUCKETS * 4)
+#define FS_FUSED_OFF_ITEMS (FS_FUSED_OFF_CUR + FS_FUSED_CUR_BYTES)
 #define FS_FUSED_OFF_SCAN (FS_FUSED_OFF_ITEMS + FS_FUSED_MAX_PARTICLES * 2)
 // contact set (rebuilt every substep, used by the iterations): ids of up to 1024 particles that have contact candidates,
 // ordered by descending candidate count | their spring accumulators float4[1024] | count histogram / cursors int[128]
@@ -91,7 +99,7 @@ __device__ __forceinline__ T fs_ldo(const T *base, unsigned idx) {
 // of 27 cells; longer runs also even out the per-lane trip counts of a wave).
 __device__ __forceinline__ int fs_fused_row(int cy, int cz) {
     const unsigned h = (unsigned)cy * 0x85EBCA77u + (unsigned)cz * 0xC2B2AE3Du;
-    return (int)((h ^ (h >> 15)) * 0x2C1B3C6Du >> 20);  // 12 bits = log2(FS_FUSED_BUCKETS)
+    return (int)((h ^ (h >> 15)) * 0x2C1B3C6Du >> (32 - FS_FUSED_BUCKET_BITS));
 }
 __device__ __forceinline__ int fs_fused_bucket(int cx, int cy, int cz) {
     return (fs_fused_row(cy, cz) + cx) & (FS_FUSED_BUCKETS - 1);
@@ -170,24 +178,27 @@ __device__ __forceinline__ void fs_fused_finalize(const FsFusedConsts &c, FsVec4
 // On return cursor[b] == end of bucket b (start == cursor[b-1]) and items[] holds particle ids grouped by bucket.
 // Also writes XS: the predicted positions in bucket order (SoA, aliasing the X0 region, whose content is parked in
 // global memory during the search), so the candidate scan reads positions sequentially instead of chasing ids.
-__device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, const FsVec4 (&xp)[FS_FUSED_PPT], int *cursor,
-                                                    unsigned short *items, int *wave_tot, float *XSx, float *XSy,
-                                                    float *XSz) {
+__device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, const FsVec4 (&xp)[FS_FUSED_PPT],
+                                                    unsigned short *cursor, unsigned short *items, int *wave_tot, float *XSx,
+                                                    float *XSy, float *XSz) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned *cw = (unsigned *)cursor;  // two buckets per word; an LDS atomic adds 1 to the bucket's half (no carry: <= 4096)
     int bucket[FS_FUSED_PPT];
 #pragma unroll
     for (int k = 0; k < FS_FUSED_PPT; ++k) {
         const int i = t + k * FS_FUSED_THREADS;
         bucket[k] = fs_fused_bucket((int)floorf(xp[k].x * c.inv_rad), (int)floorf(xp[k].y * c.inv_rad),
                                     (int)floorf(xp[k].z * c.inv_rad));
-        if (i < c.n) atomicAdd(&cursor[bucket[k]], 1);
+        if (i < c.n) atomicAdd(&cw[bucket[k] >> 1], 1u << ((bucket[k] & 1) << 4));
     }
     __syncthreads();
     {
-        constexpr int PER = FS_FUSED_BUCKETS / FS_FUSED_THREADS;
-        int loc[PER], sum = 0;
+        constexpr int PW = FS_FUSED_BUCKETS / FS_FUSED_THREADS / 2;  // words per thread
+        static_assert(PW >= 1 && PW * 2 * FS_FUSED_THREADS == FS_FUSED_BUCKETS, "bucket table: whole words per thread");
+        unsigned wv[PW];
+        int sum = 0;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { loc[k] = cursor[t * PER + k]; sum += loc[k]; }
+        for (int k = 0; k < PW; ++k) { wv[k] = cw[t * PW + k]; sum += (int)(wv[k] & 0xffffu) + (int)(wv[k] >> 16); }
         int inc = sum;
         for (int off = 1; off < 64; off <<= 1) {
             int o = __shfl_up(inc, off, 64);
@@ -198,14 +209,21 @@ __device__ __forceinline__ void fs_fused_build_grid(const FsFusedConsts &c, cons
         int run = inc - sum;
         for (int w = 0; w < wave; ++w) run += wave_tot[w];  // <= 16 waves
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { cursor[t * PER + k] = run; run += loc[k]; }
+        for (int k = 0; k < PW; ++k) {
+            const unsigned lo = (unsigned)run;
+            run += (int)(wv[k] & 0xffffu);
+            const unsigned hi = (unsigned)run;
+            run += (int)(wv[k] >> 16);
+            cw[t * PW + k] = lo | (hi << 16);
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < FS_FUSED_PPT; ++k) {
         const int i = t + k * FS_FUSED_THREADS;
         if (i < c.n) {
-            int slot = atomicAdd(&cursor[bucket[k]], 1);
+            const unsigned sh = (unsigned)(bucket[k] & 1) << 4;
+            const int slot = (int)((atomicAdd(&cw[bucket[k] >> 1], 1u << sh) >> sh) & 0xffffu);
             items[slot] = (unsigned short)i;
             XSx[slot] = xp[k].x; XSy[slot] = xp[k].y; XSz[slot] = xp[k].z;
         }
@@ -380,7 +398,7 @@ __device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int
     qn = 0;
 }
 
-__device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, fs_lci cursor,
+__device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, fs_lcus cursor,
                                                        fs_lcus items, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
                                                        const FsNearWords near,
                                                        fs_lus queue /* [FINDQ][blockDim] + threadIdx */, fs_lcf XSx) {
@@ -402,12 +420,12 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
             for (int seg = 0; seg < 2; ++seg) {
                 int beg, end;
                 if (seg == 0) {
-                    beg = (b0 == 0) ? 0 : cursor[b0 - 1];
-                    end = cursor[wrap > 0 ? FS_FUSED_BUCKETS - 1 : b0 + 2];
+                    beg = (b0 == 0) ? 0 : (int)cursor[b0 - 1];
+                    end = (int)cursor[wrap > 0 ? FS_FUSED_BUCKETS - 1 : b0 + 2];
                 } else {
                     if (wrap <= 0) break;
                     beg = 0;
-                    end = cursor[wrap - 1];
+                    end = (int)cursor[wrap - 1];
                 }
                 FS_CNT_WAVE(0, 1)          // wave-level run visits
                 FS_CNT_LANE(2, end - beg)  // lane-level candidates
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     float *X0x = (float *)(smem + FS_FUSED_OFF_X0);
     float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
     float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
-    int *cursor = (int *)(smem + FS_FUSED_OFF_CUR);
+    unsigned short *cursor = (unsigned short *)(smem + FS_FUSED_OFF_CUR);
     unsigned short *items = (unsigned short *)(smem + FS_FUSED_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FS_FUSED_OFF_SCAN);
 
@@ -620,7 +638,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
             // ---- predict from (X0, vel) into X; build the spatial hash
-            for (int q = t; q < FS_FUSED_BUCKETS; q += FS_FUSED_THREADS) cursor[q] = 0;
+            for (int q = t; q < FS_FUSED_BUCKETS / 2; q += FS_FUSED_THREADS) ((unsigned *)cursor)[q] = 0u;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
             for (int k = 0; k < FS_FUSED_PPT; ++k) {
@@ -647,7 +665,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
                 const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
                 g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lci)cursor, (fs_lcus)items, g_phase,
+                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
                                                                        g_rest, g_nlist, near,
                                                                        (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
             }
