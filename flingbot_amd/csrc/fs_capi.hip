@@ -7,6 +7,9 @@
 
 #include "../../include/flingsim.h"
 #include "fs_context.h"
+#ifndef FS_STENCIL_FILTER
+#define FS_STENCIL_FILTER 1
+#endif
 
 static thread_local std::string g_err;
 void fs_set_error(const std::string &msg) { g_err = msg; }
@@ -373,7 +376,7 @@ static int phase_find_mode(const int *phase, int n, int restnear_ok) {
         if (phase[i] != phase[0]) return 0;
     if (!(phase[0] & FS_PHASE_SELF_COLLIDE)) return 3;
     if (!(phase[0] & FS_PHASE_SELF_COLLIDE_FILTER)) return 2;
-    return restnear_ok ? 1 : 0;
+    return (restnear_ok == 2 && FS_STENCIL_FILTER) ? 4 : (restnear_ok ? 1 : 0);
 }
 
 static int push_env_desc(fs_ctx *ctx, int env) {

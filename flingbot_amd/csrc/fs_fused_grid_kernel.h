@@ -173,6 +173,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
         if (!mixed) {
             if (!(ph0 & FS_PHASE_SELF_COLLIDE)) find_mode = 3;
             else if (!(ph0 & FS_PHASE_SELF_COLLIDE_FILTER)) find_mode = 2;
+            else if (E.restnear_ok == 2 && FS_STENCIL_FILTER) find_mode = 4;
             else if (E.restnear_ok) find_mode = 1;
         }
     }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
             __syncthreads();
             fs_fused_build_grid(c, xp, cursor, items, wave_tot, X0x, X0y, X0z);
             FS_TS(1)
-            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode};
+            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode, E.gp_dimx, E.gp_magic};
 #pragma unroll 1
             for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
                 const int i = items[qs];

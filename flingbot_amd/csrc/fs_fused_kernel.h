@@ -23,6 +23,9 @@
 #define FS_FUSED_PPT (4096 / FS_FUSED_THREADS)
 #define FS_FUSED_MAX_PARTICLES (FS_FUSED_THREADS * FS_FUSED_PPT)
 #define FS_FUSED_MAX_DEG 64
+#ifndef FS_STENCIL_FILTER
+#define FS_STENCIL_FILTER 1  // 0 (developer A/B): grid cloths keep the packed-id rest-near test (find mode 1 instead of 4)
+#endif
 #ifndef FS_FUSED_BUCKET_BITS
 #define FS_FUSED_BUCKET_BITS 13
 #endif
@@ -236,7 +239,10 @@ struct FsFindConsts {  // by value: a reference would force the caller's constan
     int n, ncap;
     float rad2, inv_rad;
     int mode;  // 0: test phases and rest positions per pair (global loads); 1: uniform phase with SelfCollideFilter ->
-               // membership test against the particle's packed rest-near ids; 2: uniform phase, no filter
+               // membership test against the particle's packed rest-near ids; 2: uniform phase, no filter; 3: no pairs;
+               // 4: like 1 on a canonical grid cloth whose rest-near sets are the 8 grid neighbours: two index differences
+    int dimx;        // mode 4: grid width and ceil(2^32 / width) (row = umulhi(i, magic), verified by the host)
+    unsigned magic;
 };
 struct FsNearWords {  // rest-near ids of one particle, by value (registers)
     uint32_t w[8];
@@ -318,6 +324,10 @@ __device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, in
         }
         const FsVec4 rj = fs_ld4(rest, j);
         if (!fs_pair_allowed(phi, phase[j], ri, rj, c.rad2)) return;
+    } else if (c.mode == 4) {  // grid cloth, one phase: "closer than the radius in the rest pose" = one of the 8 grid neighbours
+        const int rj = (int)__umulhi((unsigned)j, c.magic), ri_ = (int)__umulhi((unsigned)i, c.magic);
+        const int cj = j - rj * c.dimx, ci = i - ri_ * c.dimx;
+        if ((unsigned)(rj - ri_ + 1) <= 2u && (unsigned)(cj - ci + 1) <= 2u) return;  // (j != i: the caller skipped it)
     } else if (c.mode == 1) {  // one phase for the whole cloth: the filter is a set-membership test on packed ids
         const uint32_t jj = (uint32_t)j | ((uint32_t)j << 16);
         uint32_t hit = 0u;
@@ -596,6 +606,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
         if (!mixed) {
             if (!(ph0 & FS_PHASE_SELF_COLLIDE)) find_mode = 3;  // same group, no self-collision flag: no pairs at all
             else if (!(ph0 & FS_PHASE_SELF_COLLIDE_FILTER)) find_mode = 2;
+            else if (E.restnear_ok == 2 && FS_STENCIL_FILTER) find_mode = 4;
             else if (E.restnear_ok) find_mode = 1;
         }
     }
@@ -653,7 +664,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             __syncthreads();
             fs_fused_build_grid(c, xp, cursor, items, wave_tot, X0x, X0y, X0z);
             FS_TS(1)
-            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode};
+            const FsFindConsts fc = {n, c.ncap, c.rad2, c.inv_rad, find_mode, E.gp_dimx, E.gp_magic};
             // Particles are searched in BUCKET order (lane <-> slot of the sorted copy): the lanes of one cell walk the
             // same 27 buckets with the same trip counts and read the same LDS words (broadcast, no bank conflicts);
             // in id order every lane of a wave walked different buckets and the scan was LDS-conflict bound.

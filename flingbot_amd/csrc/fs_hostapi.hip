@@ -69,6 +69,7 @@ extern "C" int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, i
             packed[22] = (float)p.numPlanes; packed[23] = p.planes[0][0]; packed[24] = p.planes[0][1];
             packed[25] = p.planes[0][2]; packed[26] = p.planes[0][3]; packed[27] = (float)p.maxNeighbors;
             packed[28] = (float)p.maxContacts; packed[29] = (float)p.relaxationMode;
+            packed[30] = (float)s.restnear_ok;  // (white box: 2 = the rest-near sets are the 8 grid neighbours)
             memcpy(out, packed, sizeof(packed));
             return FS_OK;
         }

@@ -354,6 +354,9 @@ void build_restnear(FsHostScene &s) {
         q = e;
     }
     std::vector<int> found;
+    // a canonical grid cloth (index = row * dimx + column, gp_magic valid): does every particle's set equal its 8 grid
+    // neighbours?  Then the kernels test two index differences instead of sixteen packed ids (restnear_ok = 2).
+    bool stencil = s.gp_L_ok && s.gp_dimx > 0 && (long long)s.gp_dimx * s.gp_dimz == n;
     for (size_t c = 0; c < run_begin.size(); ++c) {
         const int first = order[run_begin[c]];
         int nb[27], t = 0;
@@ -381,13 +384,24 @@ void build_restnear(FsHostScene &s) {
                 }
             }
             if (found.size() > 16) return;  // restnear_ok stays 0
+            if (stencil) {  // is the set exactly the particle's in-grid 8-neighbourhood?
+                const int dimx = s.gp_dimx, dimz = s.gp_dimz, ix = i % dimx, iz = i / dimx;
+                size_t want = 0;
+                for (int dz = -1; dz <= 1 && stencil; ++dz)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if ((dx == 0 && dz == 0) || ix + dx < 0 || ix + dx >= dimx || iz + dz < 0 || iz + dz >= dimz) continue;
+                        ++want;
+                        if (std::find(found.begin(), found.end(), (iz + dz) * dimx + ix + dx) == found.end()) { stencil = false; break; }
+                    }
+                if (want != found.size()) stencil = false;
+            }
             for (size_t q = 0; q < found.size(); ++q) {
                 uint32_t &w = s.restnear_w[size_t(q / 2) * n + i];
                 w = (w & ~(0xffffu << (16 * (q % 2)))) | (uint32_t(found[q]) << (16 * (q % 2)));
             }
         }
     }
-    s.restnear_ok = 1;
+    s.restnear_ok = stencil ? 2 : 1;
 }
 
 void build_vertex_triangles(FsHostScene &s) {

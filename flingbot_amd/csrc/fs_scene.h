@@ -69,7 +69,9 @@ struct FsHostScene {
     float g64_k[FS_G64_SLOTS] = {0};
     // rest-pose neighbours for the SelfCollideFilter test (NvFlex.h:166,564-565): ids of the particles closer than the
     // interaction radius in the rest pose, 16 slots of 16 bits packed two per word, [8][n], 0xffff = empty.
-    // restnear_ok = 0 when some particle has more than 16 of them or n > 65535 (the kernels then test rest positions).
+    // restnear_ok = 0 when some particle has more than 16 of them or n > 65535 (the kernels then test rest positions);
+    // 2 when the cloth is a canonical grid and every particle's set is exactly its in-grid 8-neighbourhood (always the case
+    // for the reference's cloths: pitch 0.00625, radius 0.01125) -- the kernels then test index differences.
     int restnear_ok = 0;
     std::vector<uint32_t> restnear_w;
     // vertex -> incident triangles (ascending triangle id), for the vertex-normal gather

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
     const FsParams &p = E.p;
     const float r = p.radius + p.particleCollisionMargin;
     const int cap = p.maxNeighbors < FS_MAX_NEIGHBORS ? p.maxNeighbors : FS_MAX_NEIGHBORS;
-    const FsFindConsts c = {n, cap, r * r, 1.0f / r, E.find_mode};
+    const FsFindConsts c = {n, cap, r * r, 1.0f / r, E.find_mode, E.gp_dimx, E.gp_magic};
     const fs_gcv4 xs = (fs_gcv4)E.xb;
     const fs_gci fill = (fs_gci)E.cell_fill, phase = (fs_gci)E.phase;
     const fs_gi nlist = (fs_gi)E.nlist;

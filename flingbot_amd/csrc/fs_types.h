@@ -108,6 +108,7 @@ struct FsEnvDev {
     int find_mode;  // host-maintained summary of the phases (fs_set_scene / fs_set_phases), used by the streaming search:
                     // 0 mixed phases: test every pair; 1 one phase with SelfCollide|SelfCollideFilter and restnear_ok: rest-near
                     // membership test; 2 one phase, SelfCollide without filter: every pair in range; 3 one phase, no
-                    // SelfCollide: no pairs
+                    // SelfCollide: no pairs; 4 like 1 on a grid cloth whose rest-near sets are the 8 grid neighbours
+                    // (restnear_ok == 2): index differences instead of packed ids
     FsParams p;
 };

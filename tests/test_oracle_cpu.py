@@ -892,14 +892,38 @@ def test_host_scene_derived_tables_match_brute_force():
                 used += 1
         assert used > 100
 
+    def stencil_flag(h, dims=None):
+        """params[30] = 2 <=> the host says "every rest-near set is exactly the particle's in-grid 8-neighbourhood" (the
+        kernels then test two index differences instead of the packed ids): checked here against all pairs."""
+        flag = int(h["params"][30])
+        if dims is None:
+            return flag
+        n, (dx, dz) = h["n"], dims
+        pos = h["positions"].reshape(-1, 4)[:, :3].astype(np.float32)
+        par = h["params"]
+        r = np.float32(par[6]) + np.float32(par[10])
+        d = pos[:, None, :] - pos[None, :, :]
+        near = ((d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]) < r * r
+        np.fill_diagonal(near, False)
+        ix, iz = np.arange(n) % dx, np.arange(n) // dx
+        eight = (np.abs(ix[:, None] - ix[None, :]) <= 1) & (np.abs(iz[:, None] - iz[None, :]) <= 1)
+        np.fill_diagonal(eight, False)
+        assert (flag == 2) == bool(np.array_equal(near, eight)), dims
+        return flag
+
     from conftest import cloth_params
-    check(fsim.host_scene(cloth_params(37, 23)), "grid 37 x 23")
-    check(fsim.host_scene(cloth_params(24, 30, stiff=(0.8, 1.0, 0.6))), "grid 24 x 30, per-type stiffness")
+    h = fsim.host_scene(cloth_params(37, 23))
+    check(h, "grid 37 x 23")
+    assert stencil_flag(h, (37, 23)) == 2
+    h = fsim.host_scene(cloth_params(24, 30, stiff=(0.8, 1.0, 0.6)))
+    check(h, "grid 24 x 30, per-type stiffness")
+    assert stencil_flag(h, (24, 30)) == 2
     g = np.load(os.path.join(GOLD, "task_golden.npz"))
-    if True:
-        sp = cloth_params(0, 0)
-        check(fsim.host_scene(sp, g["obj_vertices"].reshape(-1), g["obj_stretch"].reshape(-1), g["obj_bend"].reshape(-1),
-                              g["obj_shear"].reshape(-1), g["obj_faces"].reshape(-1)), "obj mesh", expect_mesh_neighbours=False)
+    sp = cloth_params(0, 0)
+    h = fsim.host_scene(sp, g["obj_vertices"].reshape(-1), g["obj_stretch"].reshape(-1), g["obj_bend"].reshape(-1),
+                        g["obj_shear"].reshape(-1), g["obj_faces"].reshape(-1))
+    check(h, "obj mesh", expect_mesh_neighbours=False)
+    assert stencil_flag(h) != 2  # an irregular mesh keeps the packed-id test
 
 
 def test_sphere_mesh_pinned_to_reference_mesh():
