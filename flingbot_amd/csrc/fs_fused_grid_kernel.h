@@ -270,14 +270,22 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #pragma unroll 1
             for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
                 const int i = items[qs];
+                const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
+                if (find_mode == 4) {  // grid cloth: no packed rest-near ids to carry through the search
+                    FsNearWords none;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) none.w[q] = 0xffffffffu;
+                    g_ncount[i] = fs_fused_find_neighbors<true>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase, g_rest, g_nlist,
+                                                                none, (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
+                    continue;
+                }
                 FsNearWords near;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
-                const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};
                 g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
-                                                                       g_rest, g_nlist, near,
-                                                                       (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
+                                             : fs_fused_find_neighbors<false>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
+                                                                              g_rest, g_nlist, near,
+                                                                              (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
             }
             FS_TS(2)
             __syncthreads();  // every wave is done with XS, the hash and the queues (which covered the planes)

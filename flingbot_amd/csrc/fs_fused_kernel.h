@@ -313,10 +313,16 @@ __device__ __forceinline__ void fs_fused_global_insert(int n, int i, int j, int 
 
 // Second half of the search for one candidate j that passed the distance test: phase / rest-pose filter, then sorted,
 // duplicate-free insertion (a particle can be met twice: its bucket may lie in two of the visited runs when rows alias).
+// STENCIL: the caller knows c.mode == 4 (the packed ids in `near` are then never read and cost no registers).
+template <bool STENCIL = false>
 __device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, int j, FsNbList &L, int &phi, FsVec4 &ri,
                                                 bool &have_meta, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
                                                 const FsNearWords &near) {
-    if (c.mode == 0) {  // general: phases and rest positions from global memory, per pair
+    if (STENCIL) {
+        const int rj = (int)__umulhi((unsigned)j, c.magic), ri_ = (int)__umulhi((unsigned)i, c.magic);
+        const int cj = j - rj * c.dimx, ci = i - ri_ * c.dimx;
+        if ((unsigned)(rj - ri_ + 1) <= 2u && (unsigned)(cj - ci + 1) <= 2u) return;
+    } else if (c.mode == 0) {  // general: phases and rest positions from global memory, per pair
         if (!have_meta) {
             phi = phase[i];
             ri = fs_ld4(rest, i);
@@ -383,6 +389,7 @@ typedef __attribute__((address_space(3))) const fs_f4 *fs_lcf4;
 typedef __attribute__((address_space(3))) const unsigned short *fs_lcus;
 typedef __attribute__((address_space(3))) unsigned short *fs_lus;
 
+template <bool STENCIL = false>
 __device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int &qn, FsNbList &L, int &phi, FsVec4 &ri,
                                                bool &have_meta, fs_lcus items, fs_lus queue, fs_gci phase,
                                                const FsVec4 *rest, fs_gi nlist, const FsNearWords &near) {
@@ -403,11 +410,12 @@ __device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int
         m &= m - 1u;
         if (j == i) continue;
         FS_CNT_LANE(3, 1)  // lane-level survivors
-        fs_fused_accept(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
+        fs_fused_accept<STENCIL>(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
     }
     qn = 0;
 }
 
+template <bool STENCIL = false>
 __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i, const FsVec4 xi, fs_lcus cursor,
                                                        fs_lcus items, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
                                                        const FsNearWords near,
@@ -451,7 +459,7 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
                     m &= ((1u << (hi - lo)) - 1u) << lo;
                     if (m) {
                         if (qn == FS_FUSED_FINDQ)  // queue full (dense crumple): work it off first
-                            fs_fused_drain(c, i, qn, L, phi, ri, have_meta, items, queue, phase, rest, nlist, near);
+                            fs_fused_drain<STENCIL>(c, i, qn, L, phi, ri, have_meta, items, queue, phase, rest, nlist, near);
                         queue[qn * FS_FUSED_THREADS] = (unsigned short)(((unsigned)q << 2) | m);
                         ++qn;
                     }
@@ -462,7 +470,7 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
     const unsigned long long tf1 = __builtin_amdgcn_s_memtime();
     FS_DBG_COUNT(6, tf1 - tf0)
 #endif
-    fs_fused_drain(c, i, qn, L, phi, ri, have_meta, items, queue, phase, rest, nlist, near);
+    fs_fused_drain<STENCIL>(c, i, qn, L, phi, ri, have_meta, items, queue, phase, rest, nlist, near);
 #ifdef FS_TIMING
     FS_DBG_COUNT(7, __builtin_amdgcn_s_memtime() - tf1)
 #endif
@@ -671,14 +679,22 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll 1
             for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
                 const int i = items[qs];
+                const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
+                if (find_mode == 4) {  // grid cloth: no packed rest-near ids to carry through the search
+                    FsNearWords none;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) none.w[q] = 0xffffffffu;
+                    g_ncount[i] = fs_fused_find_neighbors<true>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase, g_rest, g_nlist,
+                                                                none, (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
+                    continue;
+                }
                 FsNearWords near;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
-                const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
                 g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
-                                                                       g_rest, g_nlist, near,
-                                                                       (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
+                                             : fs_fused_find_neighbors<false>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
+                                                                              g_rest, g_nlist, near,
+                                                                              (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
             }
             FS_TS(2)
             __syncthreads();  // every wave is done with XS and the hash
