@@ -86,6 +86,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     }
     size_t launch_particles = 0;
     for (int id : ids) launch_particles += (size_t)ctx->envs[id].host.n;
+    bool find_stencil = true;  // every episode a grid cloth whose SelfCollideFilter test is the 8-neighbour stencil (find mode 4)
+    for (int id : ids) find_stencil = find_stencil && ctx->envs[id].dev.find_mode == 4;
     gridl_posk = gridl_posk && launch_particles <= (size_t)4 * 1024 * 64;  // one round of 4 waves per SIMD at most (see fs_k_iterate_gridl)
     hipStream_t st = ctx->stream;
     ctx->last_form = gridl_form ? FS_FORM_STREAM_GRIDL
@@ -178,7 +180,10 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
                 case K_PREDICT: hipLaunchKernelGGL(fs_k_predict, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
                 case K_SCAN: hipLaunchKernelGGL(fs_k_grid_scan, bgrid, dim3(1024), 0, c.st, tab, cids); break;
                 case K_SCATTER: hipLaunchKernelGGL(fs_k_grid_scatter, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
-                case K_FIND: hipLaunchKernelGGL(fs_k_find_neighbors, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
+                case K_FIND:
+                    if (find_stencil) hipLaunchKernelGGL(fs_k_find_neighbors<true>, c.grid, block, 0, c.st, tab, cids, c.gx, c.count);
+                    else hipLaunchKernelGGL(fs_k_find_neighbors<false>, c.grid, block, 0, c.st, tab, cids, c.gx, c.count);
+                    break;
                 case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_shapes, cids, sub, flip, c.gx, c.count); break;
                 default: hipLaunchKernelGGL(fs_k_finalize, c.grid, block, 0, c.st, tab, cids, flip, c.gx, c.count); break;
             }

@@ -274,6 +274,9 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
 // the whole cloth is one phase), sorted duplicate-free insertion with the smallest ids (FS_NB_STAGED = 8) staged in registers.
 // A bucket spans [end[b-1], end[b]) of the sorted arrays (cell_fill holds the ends after the scatter).
 #define FS_STREAM_FINDQ 32
+// STENCIL: every episode of the launch is a grid cloth in find mode 4 (the host checks the launch list): the packed rest-near
+// ids are never loaded and the kernel fits 5 waves per SIMD instead of 4.
+template <bool STENCIL>
 __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
     }
     FsNearWords near;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) near.w[q] = c.mode == 1 ? E.restnear_w[(size_t)q * n + i] : 0xffffffffu;
+    for (int q = 0; q < 8; ++q) near.w[q] = (!STENCIL && c.mode == 1) ? E.restnear_w[(size_t)q * n + i] : 0xffffffffu;
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
     int phi = 0, qn = 0;
     FsNbList L = fs_nb_empty();
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
             m &= m - 1u;
             const int j = __float_as_int(xs[at < n ? at : n - 1].w);
             if (j == i) continue;
-            fs_fused_accept(c, i, j, L, phi, ri, have_meta, phase, E.rest, nlist, near);
+            fs_fused_accept<STENCIL>(c, i, j, L, phi, ri, have_meta, phase, E.rest, nlist, near);
         }
         qn = 0;
     };
