@@ -272,29 +272,37 @@ __device__ unsigned long long fs_dbg_cnt[8];
 
 // The neighbour list of the particle being searched, while it is built: the FOUR smallest accepted ids live in
 // registers (ascending, FS_NB_EMPTY padded), only what does not fit there goes to the global list (from slot FS_NB_STAGED
-// on, every element larger than the staged ones; 8 staged ids measured 0.5 % faster on the bench than 4 or 6).  A crumpling sheet has < 1 real contact per particle on average, so the
+// on, every element larger than the staged ones).  How many are staged is the search's choice (the template parameter ST):
+// the fused kernels stage 4 (measured in round 3, after the grid cloths' searches stopped carrying the packed rest-near ids:
+// 4 -> 2.471, 6 -> 2.476, 8 -> 2.513 ms per launch of the bench), the streaming search 8.  A crumpling sheet has < 1 real contact per particle on average, so the
 // dependent global read-modify-write chains of an in-memory insertion sort are gone from the common path; the staged
 // ids are stored once at the end.
 #define FS_NB_EMPTY 0x7fffffff
-#ifndef FS_NB_STAGED
-#define FS_NB_STAGED 8
+#ifndef FS_NB_STAGED_FUSED
+#define FS_NB_STAGED_FUSED 4
 #endif
-struct FsNbList {
-    int a[FS_NB_STAGED];  // ascending; FS_NB_EMPTY = free (statically indexed only: stays in registers)
-    int gcnt;             // elements in the global part (slots FS_NB_STAGED .. FS_NB_STAGED + gcnt - 1)
+#ifndef FS_NB_STAGED_STREAM
+#define FS_NB_STAGED_STREAM 8
+#endif
+template <int ST>
+struct FsNbListT {
+    int a[ST];  // ascending; FS_NB_EMPTY = free (statically indexed only: stays in registers)
+    int gcnt;   // elements in the global part (slots ST .. ST + gcnt - 1)
 };
-__device__ __forceinline__ FsNbList fs_nb_empty() {
-    FsNbList L;
+template <int ST>
+__device__ __forceinline__ FsNbListT<ST> fs_nb_empty() {
+    FsNbListT<ST> L;
 #pragma unroll
-    for (int q = 0; q < FS_NB_STAGED; ++q) L.a[q] = FS_NB_EMPTY;
+    for (int q = 0; q < ST; ++q) L.a[q] = FS_NB_EMPTY;
     L.gcnt = 0;
     return L;
 }
 
 // sorted insertion into the global part: ascending ids, at most `gcap` kept; an id already present is not inserted again
+template <int ST>
 __device__ __forceinline__ void fs_fused_global_insert(int n, int i, int j, int gcap, int &gcnt, fs_gi nlist) {
     if (gcap <= 0) return;
-    fs_gi list = nlist + (size_t)FS_NB_STAGED * n + i;
+    fs_gi list = nlist + (size_t)ST * n + i;
     int s = gcnt, prev = -1;
     while (s > 0) {
         prev = list[(size_t)(s - 1) * n];
@@ -314,8 +322,8 @@ __device__ __forceinline__ void fs_fused_global_insert(int n, int i, int j, int 
 // Second half of the search for one candidate j that passed the distance test: phase / rest-pose filter, then sorted,
 // duplicate-free insertion (a particle can be met twice: its bucket may lie in two of the visited runs when rows alias).
 // STENCIL: the caller knows c.mode == 4 (the packed ids in `near` are then never read and cost no registers).
-template <bool STENCIL = false>
-__device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, int j, FsNbList &L, int &phi, FsVec4 &ri,
+template <bool STENCIL = false, int ST = FS_NB_STAGED_STREAM>
+__device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, int j, FsNbListT<ST> &L, int &phi, FsVec4 &ri,
                                                 bool &have_meta, fs_gci phase, const FsVec4 *rest, fs_gi nlist,
                                                 const FsNearWords &near) {
     if (STENCIL) {
@@ -346,29 +354,30 @@ __device__ __forceinline__ void fs_fused_accept(const FsFindConsts &c, int i, in
     }
     bool dup = false;
 #pragma unroll
-    for (int q = 0; q < FS_NB_STAGED; ++q) dup |= (j == L.a[q]);
+    for (int q = 0; q < ST; ++q) dup |= (j == L.a[q]);
     if (dup) return;
-    const int gcap = c.ncap - FS_NB_STAGED;
-    if (j > L.a[FS_NB_STAGED - 1]) {  // staged part full and j beyond it (the last slot is FS_NB_EMPTY otherwise)
-        fs_fused_global_insert(c.n, i, j, gcap, L.gcnt, nlist);
+    const int gcap = c.ncap - ST;
+    if (j > L.a[ST - 1]) {  // staged part full and j beyond it (the last slot is FS_NB_EMPTY otherwise)
+        fs_fused_global_insert<ST>(c.n, i, j, gcap, L.gcnt, nlist);
         return;
     }
     int t = j;
 #pragma unroll
-    for (int q = 0; q < FS_NB_STAGED; ++q) {
+    for (int q = 0; q < ST; ++q) {
         const int lo = min(L.a[q], t);
         t = max(L.a[q], t);
         L.a[q] = lo;
     }
-    if (t != FS_NB_EMPTY) fs_fused_global_insert(c.n, i, t, gcap, L.gcnt, nlist);  // displaced: larger than all staged
+    if (t != FS_NB_EMPTY) fs_fused_global_insert<ST>(c.n, i, t, gcap, L.gcnt, nlist);  // displaced: larger than all staged
 }
 
 // stores the staged ids; returns the list length
-__device__ __forceinline__ int fs_fused_nb_finish(const FsFindConsts &c, int i, const FsNbList &L, fs_gi nlist) {
+template <int ST>
+__device__ __forceinline__ int fs_fused_nb_finish(const FsFindConsts &c, int i, const FsNbListT<ST> &L, fs_gi nlist) {
     int st = 0;
     const size_t n = (size_t)c.n;
 #pragma unroll
-    for (int q = 0; q < FS_NB_STAGED; ++q) {
+    for (int q = 0; q < ST; ++q) {
         if (L.a[q] != FS_NB_EMPTY) { nlist[(size_t)q * n + i] = L.a[q]; ++st; }  // ascending: the used slots are a prefix
     }
     const int total = st + L.gcnt;
@@ -390,7 +399,7 @@ typedef __attribute__((address_space(3))) const unsigned short *fs_lcus;
 typedef __attribute__((address_space(3))) unsigned short *fs_lus;
 
 template <bool STENCIL = false>
-__device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int &qn, FsNbList &L, int &phi, FsVec4 &ri,
+__device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int &qn, FsNbListT<FS_NB_STAGED_FUSED> &L, int &phi, FsVec4 &ri,
                                                bool &have_meta, fs_lcus items, fs_lus queue, fs_gci phase,
                                                const FsVec4 *rest, fs_gi nlist, const FsNearWords &near) {
     // one survivor per lane and trip: the next packed entry is fetched in the trip that finds the current one used up,
@@ -410,7 +419,7 @@ __device__ __forceinline__ void fs_fused_drain(const FsFindConsts &c, int i, int
         m &= m - 1u;
         if (j == i) continue;
         FS_CNT_LANE(3, 1)  // lane-level survivors
-        fs_fused_accept<STENCIL>(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
+        fs_fused_accept<STENCIL, FS_NB_STAGED_FUSED>(c, i, j, L, phi, ri, have_meta, phase, rest, nlist, near);
     }
     qn = 0;
 }
@@ -423,7 +432,7 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
     fs_lcf XSy = XSx + FS_FUSED_MAX_PARTICLES, XSz = XSy + FS_FUSED_MAX_PARTICLES;
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
     int phi = 0, qn = 0;
-    FsNbList L = fs_nb_empty();
+    FsNbListT<FS_NB_STAGED_FUSED> L = fs_nb_empty<FS_NB_STAGED_FUSED>();
     FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
     bool have_meta = false;
 #ifdef FS_TIMING

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
 // order (thread <-> slot of the sorted copy in xb); phase A scans the 9 runs (3 adjacent buckets each) four candidates per
 // trip and parks a packed entry (slot | 4-bit hit mask) per trip with hits in a per-thread LDS queue; phase B walks the
 // queue one survivor per trip: id, self test, phase / rest-pose filter (set membership on the packed rest-near ids when
-// the whole cloth is one phase), sorted duplicate-free insertion with the smallest ids (FS_NB_STAGED = 8) staged in registers.
+// the whole cloth is one phase), sorted duplicate-free insertion with the smallest ids (FS_NB_STAGED_STREAM = 8) staged in registers.
 // A bucket spans [end[b-1], end[b]) of the sorted arrays (cell_fill holds the ends after the scatter).
 #define FS_STREAM_FINDQ 32
 // STENCIL: every episode of the launch is a grid cloth in find mode 4 (the host checks the launch list): the packed rest-near
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
     for (int q = 0; q < 8; ++q) near.w[q] = (!STENCIL && c.mode == 1) ? E.restnear_w[(size_t)q * n + i] : 0xffffffffu;
     const int cx = (int)floorf(xi.x * c.inv_rad), cy = (int)floorf(xi.y * c.inv_rad), cz = (int)floorf(xi.z * c.inv_rad);
     int phi = 0, qn = 0;
-    FsNbList L = fs_nb_empty();
+    FsNbListT<FS_NB_STAGED_STREAM> L = fs_nb_empty<FS_NB_STAGED_STREAM>();
     FsVec4 ri = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
     bool have_meta = false;
     uint32_t *queue = &queue_s[0][threadIdx.x];
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
             m &= m - 1u;
             const int j = __float_as_int(xs[at < n ? at : n - 1].w);
             if (j == i) continue;
-            fs_fused_accept<STENCIL>(c, i, j, L, phi, ri, have_meta, phase, E.rest, nlist, near);
+            fs_fused_accept<STENCIL, FS_NB_STAGED_STREAM>(c, i, j, L, phi, ri, have_meta, phase, E.rest, nlist, near);
         }
         qn = 0;
     };
