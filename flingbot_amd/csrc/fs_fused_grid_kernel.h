@@ -318,11 +318,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                 if (ccls[k] > 0) atomicAdd(&chist[ccls[k]], 1);
             }
             __syncthreads();
-            if (t == 0) {
-                int run = 0;
-                for (int q = 96; q >= 1; --q) { const int hq = chist[q]; chist[q] = run; run += hq; }
-                chist[0] = run;
-            }
+            fs_fused_count_offsets(chist, t);
             __syncthreads();
             unsigned long long slotpack = ~0ull;
 #pragma unroll

@@ -486,6 +486,24 @@ __device__ __noinline__ int fs_fused_find_neighbors(const FsFindConsts c, int i,
     return fs_fused_nb_finish(c, i, L, nlist);
 }
 
+
+// Exclusive offsets of the contact-count histogram in DESCENDING count order: chist[q] <- number of particles with more than q
+// candidates (q = 1..127), chist[0] <- number of particles with any.  One wavefront, two bins per lane, a suffix scan by
+// shuffles (it was a 96-trip loop of one thread behind a workgroup barrier, every substep).  chist[0] must be 0 on entry.
+__device__ __forceinline__ void fs_fused_count_offsets(int *chist, int t) {
+    if (t >= 64) return;
+    const int h0 = chist[2 * t], h1 = chist[2 * t + 1];
+    const int pair = h0 + h1;
+    int inc = pair;  // inclusive suffix sum over the lanes
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(inc, off, 64);
+        if (t + off < 64) inc += o;
+    }
+    const int above = inc - pair;  // particles in bins > 2 t + 1
+    chist[2 * t + 1] = above;
+    chist[2 * t] = above + h1;     // (lane 0: bin 0 holds no particles, so this is the total)
+}
+
 // planes + kinematic spheres for one particle
 __device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedConsts &c, const FsParams &p,
                                                         const FsShapesDev &sh, int sub, float xi0, float xi1, float xi2,
@@ -740,11 +758,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 if (ccls[k] > 0) atomicAdd(&chist[ccls[k]], 1);
             }
             __syncthreads();
-            if (t == 0) {  // exclusive offsets in descending count order; chist[0] <- total
-                int run = 0;
-                for (int q = 96; q >= 1; --q) { const int hq = chist[q]; chist[q] = run; run += hq; }
-                chist[0] = run;
-            }
+            fs_fused_count_offsets(chist, t);  // exclusive offsets in descending count order; chist[0] <- total
             __syncthreads();
             // 16-bit set slot of each of the thread's particles (four per word), 0xffff = not in the set
             unsigned long long slotpack[(FS_FUSED_PPT + 3) / 4];
