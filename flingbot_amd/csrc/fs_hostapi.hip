@@ -69,8 +69,13 @@ extern "C" int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, i
             packed[22] = (float)p.numPlanes; packed[23] = p.planes[0][0]; packed[24] = p.planes[0][1];
             packed[25] = p.planes[0][2]; packed[26] = p.planes[0][3]; packed[27] = (float)p.maxNeighbors;
             packed[28] = (float)p.maxContacts; packed[29] = (float)p.relaxationMode;
-            packed[30] = (float)s.restnear_ok;  // (white box: 2 = the rest-near sets are the 8 grid neighbours)
             memcpy(out, packed, sizeof(packed));
+            return FS_OK;
+        }
+        case FS_SCENE_FLAGS: {
+            if (n_elems < 4) { fs_set_error("buffer too small"); return FS_ERR_ARG; }
+            const int flags[4] = {s.restnear_ok, s.g64_ok, s.gp_L_ok, s.gp_halvable};
+            memcpy(out, flags, sizeof(flags));
             return FS_OK;
         }
         case FS_SCENE_RESTNEAR: src = s.restnear_w.data(); count = s.restnear_ok ? s.restnear_w.size() : 0; break;

@@ -669,6 +669,10 @@ def host_scene(scene_params, vertices=(), stretch_edges=(), bend_edges=(), shear
             if lib.fs_host_scene_copy(h, code, a.ctypes.data_as(C.c_void_p), a.size) < 0:
                 raise FlingSimError(lib.fs_last_error().decode())
             out[name] = a[:size]
+        flags = np.zeros(4, np.int32)  # FS_SCENE_FLAGS: what the host decided about the derived tables
+        if lib.fs_host_scene_copy(h, 15, flags.ctypes.data_as(C.c_void_p), flags.size) < 0:
+            raise FlingSimError(lib.fs_last_error().decode())
+        out["flags"] = dict(restnear_ok=int(flags[0]), g64_ok=int(flags[1]), gp_L_ok=int(flags[2]), gp_halvable=int(flags[3]))
         for name, (code, dt) in SCENE_ARRAYS.items():
             a = np.zeros(max(sizes[name], 1), dt)
             rc = lib.fs_host_scene_copy(h, code, a.ctypes.data_as(C.c_void_p), a.size)

@@ -351,6 +351,8 @@ typedef struct fs_host_scene fs_host_scene;
                                        than the collision radius in the rest pose (SelfCollideFilter, NvFlex.h:166) */
 #define FS_SCENE_STREAM_CODES 13    /* uint32[n][4]: one byte per spring slot of the particle, 255 = none */
 #define FS_SCENE_STREAM_DICT 14     /* float[entries][4]: bits(j - i), rest length, stiffness, 0 */
+#define FS_SCENE_FLAGS 15           /* int[4]: restnear_ok (0 none, 1 packed ids, 2 = the sets are the 8 grid neighbours), g64_ok,
+                                       gp_L_ok, gp_halvable */
 fs_host_scene *fs_host_scene_build(const float *scene_params, int n_params, const float *verts, int n_vert_floats,
                                    const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints,
                                    const int *shear, int n_shear_ints, const int *faces, int n_face_ints);

@@ -893,9 +893,9 @@ def test_host_scene_derived_tables_match_brute_force():
         assert used > 100
 
     def stencil_flag(h, dims=None):
-        """params[30] = 2 <=> the host says "every rest-near set is exactly the particle's in-grid 8-neighbourhood" (the
-        kernels then test two index differences instead of the packed ids): checked here against all pairs."""
-        flag = int(h["params"][30])
+        """flags['restnear_ok'] = 2 <=> the host says "every rest-near set is exactly the particle's in-grid 8-neighbourhood"
+        (the kernels then test two index differences instead of the packed ids): checked here against all pairs."""
+        flag = h["flags"]["restnear_ok"]
         if dims is None:
             return flag
         n, (dx, dz) = h["n"], dims
