@@ -103,6 +103,7 @@ fs_ctx::~fs_ctx() {
     if (d_shapes) (void)hipFree(d_shapes);
     if (d_ids) (void)hipFree(d_ids);
     if (d_slot_envs) (void)hipFree(d_slot_envs);
+    if (d_slot_sweeps) (void)hipFree(d_slot_sweeps);
     if (h_ids) (void)hipHostFree(h_ids);
     if (h_stage) (void)hipHostFree(h_stage);
     if (render_scratch) (void)hipFree(render_scratch);
@@ -188,6 +189,8 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
               fs_hip_ok(hipMalloc((void **)&ctx->d_shapes, sizeof(FsShapesDev) * n_envs), "hipMalloc(shapes)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_ids, sizeof(int) * n_envs), "hipMalloc(ids)") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_slot_envs, sizeof(FsEnvDev) * n_envs), "hipMalloc(slot table)") &&
+              fs_hip_ok(hipMalloc((void **)&ctx->d_slot_sweeps, sizeof(FsSlotSweeps) * n_envs), "hipMalloc(slot sweeps)") &&
+              fs_hip_ok(hipMemset(ctx->d_slot_sweeps, 0, sizeof(FsSlotSweeps) * n_envs), "hipMemset") &&
               fs_hip_ok(hipMalloc((void **)&ctx->d_coverage, sizeof(double) * n_envs), "hipMalloc(cov)") &&
               fs_hip_ok(hipHostMalloc((void **)&ctx->h_ids, sizeof(int) * n_envs, hipHostMallocDefault), "hipHostMalloc") &&
               fs_hip_ok(hipMemset(ctx->d_envs, 0, sizeof(FsEnvDev) * n_envs), "hipMemset") &&
@@ -386,6 +389,7 @@ static int push_env_desc(fs_ctx *ctx, int env) {
     return FS_OK;
 }
 static int push_shapes(fs_ctx *ctx, int env) {
+    ctx->desc_epoch++;  // the launch table carries the spheres' per-substep sweeps (fs_k_slot_table): stale now
     HIP_TRY(hipMemcpyAsync(ctx->d_shapes + env, &ctx->envs[env].shapes, sizeof(FsShapesDev), hipMemcpyHostToDevice,
                            ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -270,6 +270,21 @@ __device__ __forceinline__ void fs_shape_contacts(FsAcc &a, float xi0, float xi1
     }
 }
 
+// the same with the spheres' sweeps of this substep taken from the launch slot's table (FsSlotSweeps, built once per launch
+// sequence by fs_k_slot_table with fs_shape_sweep's expressions: identical numbers, scalar loads instead of ~28 vector
+// instructions per sphere, particle and iteration)
+__device__ __forceinline__ void fs_swept_shape_contacts(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
+                                                        float ri2, const FsParams &p, const FsSlotSweeps &sw, int sub) {
+    for (int q = 0; q < p.numPlanes; ++q)
+        fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
+                         p.collisionDistance, p.staticFriction, p.dynamicFriction);
+    for (int q = 0; q < sw.count; ++q) {
+        const FsVec4 c = sw.c[sub][q], s = sw.s[sub][q];
+        fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.x, c.y, c.z, c.w, s.x, s.y, s.z, p.collisionDistance,
+                          p.staticFriction, p.dynamicFriction);
+    }
+}
+
 // applyDeltas with local relaxation
 __device__ __forceinline__ void fs_apply(const FsAcc &a, float relax, float &x0, float &x1, float &x2) {
     if (a.cnt > 0) {

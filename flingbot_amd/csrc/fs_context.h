@@ -124,6 +124,7 @@ struct fs_ctx {
     FsEnvDev *d_envs = nullptr;       // [n_envs]
     FsShapesDev *d_shapes = nullptr;  // [n_envs]
     FsEnvDev *d_slot_envs = nullptr;  // [n_envs] launch table of the streaming kernels (fs_k_slot_table)
+    FsSlotSweeps *d_slot_sweeps = nullptr;  // [n_envs] the slots' sphere sweeps per substep, built with the table
     int *d_ids = nullptr;             // [n_envs] launch list
     int *h_ids = nullptr;             // pinned
     std::vector<int> uploaded_ids;    // what d_ids holds (upload_ids skips an identical list)

@@ -59,6 +59,10 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             return FS_ERR_STATE;
         }
     }
+    if (substeps > FS_SWEEP_MAX_SUBSTEPS) {  // (the reference runs 4: softgym_cloth.h:154)
+        fs_set_error("the streaming back-end tabulates the kinematic spheres' sweeps for at most 8 substeps per frame");
+        return FS_ERR_STATE;
+    }
     // XCD-affine 1-D launch (fs_stream_tile): gx workgroups per episode slot, slots rounded up to a multiple of 8
     const int gx = (max_n + FS_TILE - 1) / FS_TILE, ne = (int)ids.size();
     const dim3 grid((unsigned)(((ne + 7) / 8) * 8) * (unsigned)gx);
@@ -98,7 +102,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     // list -- fs_advance, fs_wait_until_stable: slots retire on the device -- rebuilds it every call)
     const bool table_ok = !d_ids_in && ctx->table_epoch == ctx->desc_epoch && ctx->table_ids == ids;
     if (!table_ok) {
-        hipLaunchKernelGGL(fs_k_slot_table, dim3((unsigned)ne), dim3(64), 0, st, ctx->d_envs, d_ids, ctx->d_slot_envs);
+        hipLaunchKernelGGL(fs_k_slot_table, dim3((unsigned)ne), dim3(64), 0, st, ctx->d_envs, d_ids, ctx->d_slot_envs,
+                           ctx->d_shapes, ctx->d_slot_sweeps);
         ctx->table_epoch = d_ids_in ? ~0ull : ctx->desc_epoch;
         if (!d_ids_in) ctx->table_ids = ids;
     }
@@ -184,7 +189,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
                     if (find_stencil) hipLaunchKernelGGL(fs_k_find_neighbors<true>, c.grid, block, 0, c.st, tab, cids, c.gx, c.count);
                     else hipLaunchKernelGGL(fs_k_find_neighbors<false>, c.grid, block, 0, c.st, tab, cids, c.gx, c.count);
                     break;
-                case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_shapes, cids, sub, flip, c.gx, c.count); break;
+                case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, flip, c.gx, c.count); break;
                 default: hipLaunchKernelGGL(fs_k_finalize, c.grid, block, 0, c.st, tab, cids, flip, c.gx, c.count); break;
             }
         }

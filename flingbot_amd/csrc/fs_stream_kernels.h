@@ -37,13 +37,29 @@ __device__ __forceinline__ bool fs_stream_tile(int gx, int ne, int &bx, int &by)
 // Once per fs_step_stream call this kernel copies the descriptor of every listed episode into the slot-indexed table the
 // other kernels then receive as `envs` (slot_env = the episode id, -1 for a slot a device-side loop has retired), so each
 // of them starts with ONE scalar load.  One workgroup per slot.
-__global__ __launch_bounds__(64) void fs_k_slot_table(const FsEnvDev *envs, const int *ids, FsEnvDev *table) {
+// It also works out the slot's sphere sweeps for every substep of the frame (FsSlotSweeps), with fs_shape_sweep's own
+// expressions: what every particle of the episode used to recompute in each of the 120 iterations of a frame.
+__global__ __launch_bounds__(64) void fs_k_slot_table(const FsEnvDev *envs, const int *ids, FsEnvDev *table,
+                                                      const FsShapesDev *shapes, FsSlotSweeps *sweeps) {
     static_assert(sizeof(FsEnvDev) % 4 == 0, "copied as dwords");
     const int slot = blockIdx.x, e = ids[slot];
     uint32_t *dst = (uint32_t *)(table + slot);
     if (e >= 0) {
         const uint32_t *src = (const uint32_t *)(envs + e);
         for (unsigned k = threadIdx.x; k < sizeof(FsEnvDev) / 4; k += 64) dst[k] = src[k];
+        const FsShapesDev &sh = shapes[e];
+        FsSlotSweeps &W = sweeps[slot];
+        const int S = envs[e].p.numSubsteps, count = sh.count < FS_MAX_SHAPES ? sh.count : FS_MAX_SHAPES;
+        const bool fits = S >= 1 && S <= FS_SWEEP_MAX_SUBSTEPS;
+        if (threadIdx.x == 0) { W.count = count; W.substeps = fits ? S : 0; }
+        if (fits)
+            for (int k = threadIdx.x; k < S * count; k += 64) {
+                const int sub = k / count, q = k - sub * count;
+                float c0, c1, c2, s0, s1, s2;
+                fs_shape_sweep(sh, q, sub, (float)S, c0, c1, c2, s0, s1, s2);
+                W.c[sub][q] = FsVec4{c0, c1, c2, sh.pos[q].w};
+                W.s[sub][q] = FsVec4{s0, s1, s2, 0.0f};
+            }
     }
     __syncthreads();
     if (threadIdx.x == 0) table[slot].slot_env = e;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
 // in LDS (fs_scene.h build_stream_codes) instead of the three ELL arrays: 16 bytes of adjacency per particle and
 // iteration instead of 144, which is what keeps the adjacency of a launch in the L2s.
 template <int CHUNK, bool EAGER, bool CODED>
-__device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip,
+__device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsSlotSweeps &shape_set, int i, int sub, int flip,
                                                     const FsVec4 *sdict) {
     const FsParams &p = E.p;
     const FsVec4 *__restrict__ src = flip ? E.xb : E.xa;
@@ -488,7 +504,7 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
-    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     dst[i] = xi;
 }
@@ -503,7 +519,7 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
 // below that the barrier of the dictionary staging costs more than the saved round trip (measured: slower than the
 // latency form for 1..32 episodes, also with the lengths taken from the ELL arrays instead of the dictionary).
 #define FS_GRID_SLOTS 12
-__device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, const FsShapesDev &shape_set, int i_raw, bool valid,
+__device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, const FsSlotSweeps &shape_set, int i_raw, bool valid,
                                                          int sub, int flip, FsVec4 *sdict) {
     const FsParams &p = E.p;
     const FsVec4 *__restrict__ src = flip ? E.xb : E.xa;
@@ -574,12 +590,12 @@ __device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, cons
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
-    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     dst[i] = xi;
 }
 
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                              int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[256];
     int bx, by;
@@ -589,7 +605,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *env
     if (e < 0) return;  // retired slot
     if (bx * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
     const int i = bx * FS_TILE + threadIdx.x;
-    fs_iterate_particle_grid(E, shapes[e], i, i < E.n, sub, flip, sdict);
+    fs_iterate_particle_grid(E, shapes[by], i, i < E.n, sub, flip, sdict);
 }
 
 // GRID-L form of the iteration (grid cloths with the canonical spring list, FsEnvDev::gp_L_ok): like the GRID form the
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *env
 // neighbour positions, twelve rest lengths, substep-start position, candidate count and the first candidate ids -- leave
 // in one round trip.  Per-particle accumulation order = canonical order = spring-id order (build_grid_pattern).
 template <bool POSK>
-__device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, const FsShapesDev &shape_set, int i, int sub, int flip) {
+__device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, const FsSlotSweeps &shape_set, int i, int sub, int flip) {
     const FsParams &p = E.p;
     // global address space + 32-bit indices: global_load with a scalar base instead of flat loads behind 64-bit VALU adds
     const FsVec4 *src = flip ? E.xb : E.xa;
@@ -664,7 +680,7 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
-    fs_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     fs_st4o(dst, ui, xi);
 }
@@ -675,7 +691,7 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
 // beyond 4 buys nothing: 64x64 cloths x 1 / 8 / 32 / 64 episodes 0.913 / 1.054 / 1.133 / 1.484 -> 0.880 / 1.026 / 1.099 / 1.454 ms
 // per step; larger launches measured slower with it and keep the general form.
 template <bool POSK>
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                               int sub, int flip, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
@@ -684,7 +700,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
     if (e < 0) return;  // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
     if (i >= E.n) return;
-    fs_iterate_particle_gridl<POSK>(E, shapes[e], i, sub, flip);
+    fs_iterate_particle_gridl<POSK>(E, shapes[by], i, sub, flip);
 }
 
 // (A CONTACT-SORTED form was built and measured in round 2 as well: springs in id order, then accumulator, particle and first
@@ -713,7 +729,7 @@ __device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict)
 
 // throughput form (big launches): six springs in flight, later loads issued when needed (fewer live registers)
 template <bool CODED>
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                         int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
     int bx, by;
@@ -724,11 +740,11 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, co
     const int i = bx * FS_TILE + threadIdx.x;
     if (bx * FS_TILE >= E.n) return;  // whole workgroup beyond this episode's particles
     fs_stage_sdict<CODED>(E, sdict);
-    if (i < E.n) fs_iterate_particle<FS_STREAM_CHUNK, false, CODED>(E, shapes[e], i, sub, flip, sdict);
+    if (i < E.n) fs_iterate_particle<FS_STREAM_CHUNK, false, CODED>(E, shapes[by], i, sub, flip, sdict);
 }
 // latency form (small launches)
 template <bool CODED>
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsShapesDev *shapes, const int *ids,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                               int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
     int bx, by;
@@ -739,7 +755,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *en
     const int i = bx * FS_TILE + threadIdx.x;
     if (bx * FS_TILE >= E.n) return;
     fs_stage_sdict<CODED>(E, sdict);
-    if (i < E.n) fs_iterate_particle<12, true, CODED>(E, shapes[e], i, sub, flip, sdict);
+    if (i < E.n) fs_iterate_particle<12, true, CODED>(E, shapes[by], i, sub, flip, sdict);
 }
 
 // ---- finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping (:110)

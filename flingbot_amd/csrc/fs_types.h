@@ -49,6 +49,20 @@ struct FsShapesDev {
     FsVec4 prev[FS_MAX_SHAPES];  // xyz = previous centre (NvFlex.h:981-982)
 };
 
+// The kinematic spheres of one LAUNCH SLOT as the streaming iterations need them: centre at the end of every substep and
+// displacement during it (fs_shape_sweep: linear sweep from the previous to the current transform over the frame).  The
+// sweep is the same for every particle and every one of the 30 iterations of a substep, and uniform float arithmetic runs
+// on the vector unit here (no scalar float ALU), so fs_k_slot_table works it out once per launch sequence and the iterate
+// kernels read it through scalar loads.
+#define FS_SWEEP_MAX_SUBSTEPS 8
+struct FsSlotSweeps {
+    int count;      // spheres
+    int substeps;   // numSubsteps the table was built for (0: none -- the kernels then sweep per particle as before)
+    int pad[2];
+    FsVec4 c[FS_SWEEP_MAX_SUBSTEPS][FS_MAX_SHAPES];  // xyz centre at the end of the substep, w radius
+    FsVec4 s[FS_SWEEP_MAX_SUBSTEPS][FS_MAX_SHAPES];  // xyz displacement during the substep
+};
+
 // Device-side descriptor of one episode.  Particle fields are separate arrays (SoA); each field is 16 B per particle
 // so one lane moves one dwordx4.
 struct FsEnvDev {
