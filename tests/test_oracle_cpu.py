@@ -954,3 +954,37 @@ def test_sphere_mesh_pinned_to_reference_mesh():
             assert np.array_equal(n[:, :3], gn), (name, np.abs(n[:, :3] - gn).max())
     # FlingBot's pickers are drawn upside down: vertex 0 is the south pole (quaternion x = 1 is half a turn about x)
     assert gold[0]["quat"] == [1.0, 0.0, 0.0, 0.0] and gold[0]["normals"][:3] == [0.0, -1.0, 0.0]
+
+
+def test_prebuilt_scenes_host_side():
+    """The host half of fs_set_scene built ahead (sim.PrebuiltScene / tasks.ScenePrebuilder: no GPU, any thread): the worker
+    thread hands out one scene per task in order, a scene is consumed once, and what it holds is what fs_host_scene_build
+    returns for the task's arguments (same counts and arrays as flingbot_amd.sim.host_scene)."""
+    from flingbot_amd import sim as fsim, tasks as ftasks
+
+    rng = np.random.RandomState(4)
+    tasks = []
+    for k in range(5):
+        dx, dz = int(rng.randint(8, 20)), int(rng.randint(8, 20))
+        tasks.append(dict(mesh_verts=np.zeros(0, np.float32), mesh_stretch_edges=np.zeros(0, np.int32),
+                          mesh_bend_edges=np.zeros(0, np.int32), mesh_shear_edges=np.zeros(0, np.int32),
+                          mesh_faces=np.zeros(0, np.int32), cloth_size=(dx, dz), cloth_stiff=(0.9, 1.0, 0.8), cloth_mass=0.5,
+                          flip_mesh=0))
+    pre = ftasks.ScenePrebuilder(tasks, ahead=2)
+    lib = fsim.load_library()
+    try:
+        for i in (0, 1, 2, 4):  # (3 is never asked for: close() frees it)
+            scene = pre.get(i)
+            cnt = [C.c_int(0) for _ in range(4)]
+            assert lib.fs_host_scene_counts(scene.take(), *[C.byref(c) for c in cnt]) == 0
+            ref = fsim.host_scene(*ftasks.task_scene_arguments(tasks[i]))
+            assert [c.value for c in cnt] == [ref["n"], ref["m"], ref["t"], ref["max_deg"]]
+            edges = np.zeros(2 * ref["m"], np.int32)
+            assert lib.fs_host_scene_copy(scene.take(), 3, edges.ctypes.data_as(C.c_void_p), edges.size) == 0
+            assert np.array_equal(edges, ref["springs"])
+            scene.free()
+            with pytest.raises(fsim.FlingSimError):
+                scene.take()
+    finally:
+        pre.close()
+    assert not pre.futures
