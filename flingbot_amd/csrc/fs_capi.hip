@@ -53,10 +53,19 @@ void *fs_pool_take(fs_ctx *ctx, size_t bytes, size_t *got_bytes) {
     if (got_bytes) *got_bytes = want;
     return p;
 }
+// Idle slabs beyond FS_POOL_IDLE_LIMIT go back to the driver, oldest first (sizes nobody asks for any more would otherwise
+// pile up over a long run of differently sized tasks; hipFree waits for the device, so whatever still reads them has finished).
+static const size_t FS_POOL_IDLE_LIMIT = size_t(4) << 30;
 void fs_pool_give(fs_ctx *ctx, void *ptr, size_t bytes) {
     if (!ptr) return;
     ctx->pool.push_back(FsPoolBuf{ptr, bytes});
     ctx->pool_bytes += bytes;
+    while (ctx->pool_bytes > FS_POOL_IDLE_LIMIT && ctx->pool.size() > 1) {
+        const FsPoolBuf b = ctx->pool.front();
+        ctx->pool.erase(ctx->pool.begin());
+        ctx->pool_bytes -= b.bytes;
+        (void)hipFree(b.ptr);
+    }
 }
 
 // every stream the context launches on: its own and the concurrent launch chains' (fs_step_stream).  The chains join the
