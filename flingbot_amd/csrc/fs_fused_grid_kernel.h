@@ -46,6 +46,19 @@
 #define FG_OFF_COLL (FG_OFF_ROWL + 1024)       // float[4][64]: rest length of the x-direction slots 0, 1, 4, 5 per column
 #define FG_OFF_RCNT (FG_OFF_COLL + 1024)       // float[128]: relaxationFactor / count, the IEEE quotient fs_apply computes
 #define FG_LDS_BYTES (FG_OFF_RCNT + 512)
+// The overflow queue: a particle with contact candidates that found no room in the contact set (which takes the 1024 longest
+// lists; what is left over has one candidate, in a crowded episode two) used to evaluate them inside the main loop, where
+// every one of a wavefront's four particle slots has a few such lanes and so pays full contact evaluations for them.  They
+// queue in the LDS the hash tables leave idle during the iterations instead -- the main loop parks {spring sums, particle |
+// first candidate << 12 | spring count << 24 | (candidates - 1) << 28} there -- and the lanes of waves 1..15 finish them 64
+// to a wavefront in pass 2, in the shadow of wave 0, which holds the longest lists of the set and is what pass 2 waits for
+// anyway.  Same operations per particle in the same order (springs, its contacts in list order, shapes, applyDeltas).
+#ifndef FG_SINGLES
+#define FG_SINGLES 1
+#endif
+#define FG_SINGLES_CAP ((FS_FUSED_CUR_BYTES + FS_FUSED_MAX_PARTICLES * 2) / 16)  // 1536 entries of 16 B
+#define FG_SINGLES_LANES (FS_FUSED_THREADS - 64)                                  // waves 1..15, two rounds at most
+static_assert(FG_SINGLES_CAP <= 2 * FG_SINGLES_LANES, "pass 2 serves the singles queue in two rounds");
 #ifndef FG_PREFETCH_CAND
 #define FG_PREFETCH_CAND 2                     // contact candidates of a particle fetched ahead (inline path; the heavy
                                                // particles are in the contact set and finished by pass 2)
@@ -134,7 +147,12 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
     int *wave_tot = (int *)(smem + FG_OFF_SCAN);
     float *rowL = (float *)(smem + FG_OFF_ROWL);
 
-#ifdef FS_TIMING  // developer build: per-section shader-clock totals of block 0's waves, printed at the end (FS_TS)
+#ifdef FS_BLOCK_CLOCKS  // developer build: how long every workgroup runs (scripts/block_clocks.py)
+    const unsigned long long tc_start = __builtin_amdgcn_s_memtime(), tr_start = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef FS_TIMING  // developer build: per-section shader-clock totals of block 0's waves, printed at the end (FS_TS).
+                  // Block 0 of the bench is a light episode: it is done before the printing of others disturbs anything,
+                  // but its numbers are not those of the episodes a launch waits for (scripts/block_clocks.py).
     unsigned long long ts_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -307,6 +325,8 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
             FsVec4 *cacc = (FsVec4 *)(smem + FG_OFF_CACC);
             int *chist = (int *)(smem + FG_OFF_CHIST);
             if (t < 128) chist[t] = 0;
+            int *nsingles = (int *)(smem + FG_OFF_SCAN);  // (the hash build's scratch: idle)
+            if (t == 0) *nsingles = 0;
             __syncthreads();
             int ccls[FS_FUSED_PPT];
 #pragma unroll
@@ -329,10 +349,19 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                         cset[pos] = (unsigned short)(t + k * FS_FUSED_THREADS);
                         slotpack = (slotpack & ~(0xffffull << (16 * k))) | ((unsigned long long)pos << (16 * k));
                     }
+#if FG_SINGLES
+                    else if (ccls[k] <= 16) {  // slot value CAP + place in the overflow queue
+                        const int sp = atomicAdd(nsingles, 1);
+                        if (sp < FG_SINGLES_CAP)
+                            slotpack = (slotpack & ~(0xffffull << (16 * k))) | ((unsigned long long)(FS_FUSED_CSET_CAP + sp) << (16 * k));
+                    }
+#endif
                 }
             }
             __syncthreads();
             const int csize = chist[0] < FS_FUSED_CSET_CAP ? chist[0] : FS_FUSED_CSET_CAP;
+            const int n_singles = *nsingles < FG_SINGLES_CAP ? *nsingles : FG_SINGLES_CAP;
+            FsVec4 *squeue = (FsVec4 *)(smem + FG_OFF_CUR);
             const int i2 = t < csize ? (int)cset[t] : -1;
             int cnt2 = 0, cj2[FS_FUSED_PREFETCH_CAND];
 #pragma unroll
@@ -518,8 +547,11 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                         for (int q = 0; q < FG_PREFETCH_CAND; ++q) cj[q] = h == 0 ? cjP[q] : cjQ[q];
                         float nx = xi0s, ny = xi1s, nz = xi2s;
                         const unsigned myslot = (unsigned)(slotpack >> (16 * (2 * pr + h))) & 0xffffu;
-                        if (wis > 0.0f && myslot != 0xffffu && have) {
+                        if (wis > 0.0f && myslot < (unsigned)FS_FUSED_CSET_CAP && have) {
                             cacc[myslot] = FsVec4{a.d0, a.d1, a.d2, __int_as_float(a.cnt)};  // pass 2 finishes this particle
+                        } else if (wis > 0.0f && myslot != 0xffffu && have) {  // queued: pass 2 finishes it as well
+                            squeue[myslot - FS_FUSED_CSET_CAP] =
+                                FsVec4{a.d0, a.d1, a.d2, __int_as_float(i | (cj[0] << 12) | (a.cnt << 24) | ((cnt - 1) << 28))};
                         } else if (wis > 0.0f) {
                             const float ri0 = xi0s - X0x[i], ri1 = xi1s - X0y[i], ri2 = xi2s - X0z[i];
 #pragma unroll 1
@@ -589,6 +621,32 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fg_apply(a, c.relax, rcnt, n2x, n2y, n2z);
                 }
+#if FG_SINGLES
+                // ---- the overflow queue: entry q of waves 1..15, new position back into the entry until the publish below
+#pragma unroll 1
+                for (int q = t - 64; q >= 0 && q < n_singles; q += FG_SINGLES_LANES) {
+                    const FsVec4 pa = squeue[q];
+                    const unsigned word = (unsigned)__float_as_int(pa.w);
+                    const int i = (int)(word & 0xfffu), more = (int)(word >> 28);
+                    int j = (int)((word >> 12) & 0xfffu);
+                    int jn = more > 0 ? g_nlist[un + (unsigned)i] : 0;  // (the second candidate travels while the first is evaluated)
+                    FsAcc a = {pa.x, pa.y, pa.z, (int)((word >> 24) & 15u)};
+                    float xi0 = Xx[i], xi1 = Xy[i], xi2 = Xz[i];
+                    const float wi = Xw[i];
+                    const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
+#pragma unroll 1
+                    for (int sq = 0; sq <= more; ++sq) {
+                        const FsVec4 xj = FsVec4{Xx[j], Xy[j], Xz[j], Xw[j]};
+                        fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j], xj.z - X0z[j], c.restd,
+                                            c.restd2, c.mu_p);
+                        j = jn;
+                        if (sq + 2 <= more) jn = g_nlist[(unsigned)(sq + 2) * un + (unsigned)i];
+                    }
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fg_apply(a, c.relax, rcnt, xi0, xi1, xi2);
+                    squeue[q] = FsVec4{xi0, xi1, xi2, pa.w};
+                }
+#endif
                 FS_TS(8)
                 __syncthreads();  // every read of the old iterate is done
                 FS_TS(9)
@@ -599,6 +657,14 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                     if (i < n && !in_set) { Xx[i] = rx[FS_FUSED_PPT - 1 - q]; Xy[i] = ry[FS_FUSED_PPT - 1 - q]; Xz[i] = rz[FS_FUSED_PPT - 1 - q]; }
                 }
                 if (i2 >= 0) { Xx[i2] = n2x; Xy[i2] = n2y; Xz[i2] = n2z; }
+#if FG_SINGLES
+#pragma unroll 1
+                for (int q = t - 64; q >= 0 && q < n_singles; q += FG_SINGLES_LANES) {
+                    const FsVec4 pn = squeue[q];
+                    const int i = __float_as_int(pn.w) & 0xfff;
+                    Xx[i] = pn.x; Xy[i] = pn.y; Xz[i] = pn.z;
+                }
+#endif
                 __syncthreads();
                 FS_TS(10)
             }
@@ -614,6 +680,17 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
         }
     }
     for (int i = t; i < n; i += FS_FUSED_THREADS) fs_st4(g_pos, i, FsVec4{X0x[i], X0y[i], X0z[i], Xw[i]});
+#ifdef FS_BLOCK_CLOCKS
+    // Entry-to-exit shader clocks and the constant 100 MHz clock at entry / exit, left in row 95 of the episode's neighbour
+    // table (no list of the bench reaches it; fs_get_last_neighbors of this build passes the row through).  Not printf:
+    // workgroups that wait for the host to print slow down the ones still running by a factor of up to 7.
+    if (t == 0) {
+        const unsigned long long tc_total = __builtin_amdgcn_s_memtime() - tc_start, tr_end = __builtin_amdgcn_s_memrealtime();
+        const fs_gi out = g_nlist + 95u * un;
+        out[0] = (int)(unsigned)tc_total; out[1] = (int)(unsigned)(tc_total >> 32);
+        out[2] = (int)(unsigned)tr_start; out[3] = (int)(unsigned)tr_end;
+    }
+#endif
 #ifdef FS_TIMING
     FS_TS(11)
     if (blockIdx.x == 0 && (t & 63) == 0)
