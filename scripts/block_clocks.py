@@ -16,12 +16,12 @@ for e in range(E):
 done = 0
 for f in frames:
     ctx.step(f - 1 - done); ctx.step(1); ctx.sync(); done = f
-    clocks, start, end, cmean, cmax = [], [], [], [], []
+    clocks, start, end, cmean, cmax, cany = [], [], [], [], [], []
     for e in range(E):
         cnt, lists = ctx.get_last_neighbors(e)
         row = lists[:4, 95].astype(np.int64) & 0xffffffff
         clocks.append(int(row[0] | (row[1] << 32))); start.append(int(row[2])); end.append(int(row[3]))
-        cmean.append(cnt.mean()); cmax.append(cnt.max())
+        cmean.append(cnt.mean()); cmax.append(cnt.max()); cany.append(int((cnt > 0).sum()))
     clocks = np.array(clocks); start = np.array(start); end = np.array(end)
     us = ((end - start) & 0xffffffff) / 100.0
     order = np.argsort(-us)
@@ -31,5 +31,8 @@ for f in frames:
         us.max(), np.percentile(us, 90), np.median(us), np.percentile(us, 10), us.min(), us.mean(), us.mean() / us.max(),
         clocks[order[0]] / us[order[0]] / 1e3, clocks[order[-1]] / us[order[-1]] / 1e3))
     print("   longest:", ", ".join("%d: %.0f us (contacts mean %.2f max %d)" % (e, us[e], cmean[e], cmax[e]) for e in order[:8]))
+    cany = np.array(cany)
+    print("   particles with contacts per episode: max %d p90 %d median %d; episodes whose overflow (beyond the 1024 set slots) exceeds the queue's 1536: %d" % (
+        cany.max(), np.percentile(cany, 90), np.median(cany), int((cany > 2560).sum())))
     print("   correlation of the duration with the mean contact count %.3f, with the longest list %.3f" % (
         np.corrcoef(us, cmean)[0, 1], np.corrcoef(us, cmax)[0, 1]))
