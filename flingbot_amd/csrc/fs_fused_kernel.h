@@ -63,6 +63,17 @@
 #ifndef FS_FUSED_PREFETCH_CAND
 #define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
 #endif
+// The overflow queue (fs_k_fused_step; the grid-64 kernel has its own copy, see fs_fused_grid_kernel.h for the reasoning): a
+// particle with up to 8 contact candidates that found no room in the contact set parks {spring sums, particle | first
+// candidate << 12 | spring count << 24 | (candidates - 1) << 29} in the LDS the hash tables leave idle during the iterations,
+// and the lanes of every wave but the first finish it in pass 2 instead of the main loop evaluating it inline.
+#ifndef FS_FUSED_QUEUE
+#define FS_FUSED_QUEUE 1
+#endif
+#define FS_FUSED_QUEUE_LANES (FS_FUSED_THREADS - 64)
+#define FS_FUSED_QUEUE_ROOM ((FS_FUSED_CUR_BYTES + FS_FUSED_MAX_PARTICLES * 2) / 16)
+#define FS_FUSED_QUEUE_CAP (FS_FUSED_QUEUE_ROOM < 2 * FS_FUSED_QUEUE_LANES ? FS_FUSED_QUEUE_ROOM : 2 * FS_FUSED_QUEUE_LANES)
+static_assert(FS_FUSED_MAX_PARTICLES <= 4096, "queue words carry 12-bit particle ids");
 
 #define FS_GLOBAL __attribute__((address_space(1)))
 typedef FS_GLOBAL const int *fs_gci;
@@ -747,6 +758,8 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             FsVec4 *cacc = (FsVec4 *)(smem + FS_FUSED_OFF_CACC);
             int *chist = (int *)(smem + FS_FUSED_OFF_CHIST);
             if (t < 128) chist[t] = 0;
+            int *nqueued = (int *)(smem + FS_FUSED_OFF_SCAN);  // (the hash build's scratch: idle)
+            if (t == 0) *nqueued = 0;
             __syncthreads();
             int ccls[FS_FUSED_PPT];
 #pragma unroll
@@ -773,10 +786,20 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                         slotpack[k >> 2] = (slotpack[k >> 2] & ~(0xffffull << (16 * (k & 3)))) |
                                            ((unsigned long long)pos << (16 * (k & 3)));
                     }
+#if FS_FUSED_QUEUE
+                    else if (ccls[k] <= 8) {  // slot value CAP + place in the overflow queue
+                        const int sp = atomicAdd(nqueued, 1);
+                        if (sp < FS_FUSED_QUEUE_CAP)
+                            slotpack[k >> 2] = (slotpack[k >> 2] & ~(0xffffull << (16 * (k & 3)))) |
+                                               ((unsigned long long)(FS_FUSED_CSET_CAP + sp) << (16 * (k & 3)));
+                    }
+#endif
                 }
             }
             __syncthreads();
             const int csize = chist[0] < FS_FUSED_CSET_CAP ? chist[0] : FS_FUSED_CSET_CAP;
+            const int n_queued = *nqueued < FS_FUSED_QUEUE_CAP ? *nqueued : FS_FUSED_QUEUE_CAP;
+            FsVec4 *squeue = (FsVec4 *)(smem + FS_FUSED_OFF_CUR);
             // the set particle this thread finishes in pass 2, with its candidate count and list head (constant over
             // the substep's iterations)
             const int i2 = t < csize ? (int)cset[t] : -1;
@@ -854,8 +877,11 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
                     }
                     const unsigned myslot = (unsigned)(FS_SLOTWORD(slotpack, k) >> (16 * (k & 3))) & 0xffffu;
-                    if (xi.w > 0.0f && myslot != 0xffffu && i_raw < n) {
+                    if (xi.w > 0.0f && myslot < (unsigned)FS_FUSED_CSET_CAP && i_raw < n) {
                         cacc[myslot] = FsVec4{a.d0, a.d1, a.d2, __int_as_float(a.cnt)};  // pass 2 finishes this particle
+                    } else if (xi.w > 0.0f && myslot != 0xffffu && i_raw < n) {  // queued: pass 2 finishes it as well
+                        squeue[myslot - FS_FUSED_CSET_CAP] =
+                            FsVec4{a.d0, a.d1, a.d2, __int_as_float(i | (cj[0] << 12) | (a.cnt << 24) | ((cnt - 1) << 29))};
                     } else if (xi.w > 0.0f) {
                         const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
                         // A particle handled here has few candidates (the set takes the heavy ones first): the first
@@ -932,6 +958,34 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fs_apply(a, c.relax, n2x, n2y, n2z);
                 }
+#if FS_FUSED_QUEUE
+                // ---- the overflow queue: entry q of the waves behind the first (which holds the set's longest lists), the new
+                //      position back into the entry until the publish below
+#pragma unroll 1
+                for (int q = t - 64; q >= 0 && q < n_queued; q += FS_FUSED_QUEUE_LANES) {
+                    const FsVec4 pa = squeue[q];
+                    const unsigned word = (unsigned)__float_as_int(pa.w);
+                    const int i = (int)(word & 0xfffu), more = (int)(word >> 29);
+                    int j = (int)((word >> 12) & 0xfffu);
+                    int jn = more > 0 ? g_nlist[un + (unsigned)i] : 0;  // (the second candidate travels while the first is evaluated)
+                    FsAcc a = {pa.x, pa.y, pa.z, (int)((word >> 24) & 31u)};
+                    const FsVec4 xi = X[i];
+                    float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z;
+                    const float wi = xi.w;
+                    const float ri0 = xi0 - X0x[i], ri1 = xi1 - X0y[i], ri2 = xi2 - X0z[i];
+#pragma unroll 1
+                    for (int sq = 0; sq <= more; ++sq) {
+                        const FsVec4 xj = X[j];
+                        fs_particle_contact(a, xi0, xi1, xi2, wi, ri0, ri1, ri2, xj, xj.x - X0x[j], xj.y - X0y[j], xj.z - X0z[j], c.restd,
+                                            c.restd2, c.mu_p);
+                        j = jn;
+                        if (sq + 2 <= more) jn = g_nlist[(unsigned)(sq + 2) * un + (unsigned)i];
+                    }
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_apply(a, c.relax, xi0, xi1, xi2);
+                    squeue[q] = FsVec4{xi0, xi1, xi2, pa.w};
+                }
+#endif
                 FS_TS(8)
                 __syncthreads();  // every read of the old iterate is done
                 FS_TS(9)
@@ -942,6 +996,14 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     if (i < n && !in_set) { FsVec4 &d = X[i]; d.x = rx[FS_FUSED_PPT - 1 - q]; d.y = ry[FS_FUSED_PPT - 1 - q]; d.z = rz[FS_FUSED_PPT - 1 - q]; }
                 }
                 if (i2 >= 0) { FsVec4 &d = X[i2]; d.x = n2x; d.y = n2y; d.z = n2z; }
+#if FS_FUSED_QUEUE
+#pragma unroll 1
+                for (int q = t - 64; q >= 0 && q < n_queued; q += FS_FUSED_QUEUE_LANES) {
+                    const FsVec4 pn = squeue[q];
+                    FsVec4 &d = X[__float_as_int(pn.w) & 0xfff];
+                    d.x = pn.x; d.y = pn.y; d.z = pn.z;
+                }
+#endif
                 __syncthreads();
                 FS_TS(10)
             }
