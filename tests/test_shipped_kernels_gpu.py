@@ -97,6 +97,42 @@ def test_fused_kernel_bench_batch_bit_exact(gpu_required, n_envs, solver, form):
     assert contacts > 50, "the sampled episode must have particle contacts"
 
 
+def _folded_sheet(sim, shift):
+    """A 64x64 cloth folded in half on the ground: rows 32..63 lie 10.5 / 11 mm above rows 31..0, so ~3 500 particles have
+    exactly one contact candidate (shift 0: the particle below) or two (shift half a pitch in x: the two below)."""
+    sim.set_scene(cloth_params(64, 64, pos=(0.0, -0.005, 0.0)))
+    g = sim.get_positions().reshape(64, 64, 4).copy()
+    for iz in range(32, 64):
+        g[iz, :, 2] = g[63 - iz, :, 2]
+        g[iz, :, 1] = g[63 - iz, :, 1] + (0.0105 if shift else 0.011)
+        g[iz, :, 0] += shift
+    sim.set_positions(g.reshape(-1))
+    sim.set_velocities(np.zeros(3 * 4096, np.float32))
+
+
+@pytest.mark.parametrize("shift", [0.0, 0.003125])
+@pytest.mark.parametrize("solver,form", [("FS_SOLVER_FUSED", "FS_FORM_FUSED_GRID64"), ("FS_SOLVER_FUSED_CODED", "FS_FORM_FUSED_12")])
+def test_fused_kernels_overflow_queue_beyond_capacity(gpu_required, solver, form, shift):
+    """The fused kernels finish particle contacts in three places: the contact set (the 1024 longest lists), the overflow queue
+    (1536 entries, finished in pass 2) and, beyond both, inline in the main loop.  A folded sheet gives ~3 500 particles one
+    candidate each (or ~2 900 two each): more than set + queue hold, so all three run, the queue also with second candidates."""
+    from flingbot_amd import sim as fsim
+
+    ctx = fsim.FlingSim(n_envs=2, solver=getattr(fsim, solver))
+    for e in range(2):
+        _folded_sheet(ctx.env(e), shift)
+    ctx.step(8)
+    assert ctx.last_kernel_form() == getattr(fsim, form), ctx.last_kernel_form()
+    orc = _oracle_runs([lambda o: _folded_sheet(o, shift)], 8)[0]
+    co, _ = orc.get_last_neighbors()
+    assert (co > 0).sum() > 1024 + 1536 and co.max() == (2 if shift else 1), ((co > 0).sum(), co.max())
+    for e in range(2):
+        _assert_bits(ctx, e, orc, f"folded sheet, shift {shift}, episode {e}")
+    ch, _ = ctx.get_last_neighbors(0)
+    assert np.array_equal(ch, co)
+    ctx.close()
+
+
 def test_grid64_kernel_general_paths_bit_exact(gpu_required):
     """fs_k_fused_grid64 beyond the free sheet: (a) a two-picker fling of a 64x64 cloth -- picked particles have inverse
     mass 0, so the waves around them leave the equal-mass spring form for the general one (ELL adjacency) while the rest
