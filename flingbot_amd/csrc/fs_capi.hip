@@ -275,6 +275,30 @@ static FsEnv *get_env(fs_ctx *ctx, int env, bool need_scene = true) {
     return e;
 }
 
+int fs_lane_guard(fs_ctx *ctx, int env) {
+    if (!ctx || !ctx->on_svc || ctx->tickets_busy == 0) return FS_OK;
+    for (const FsAdvTicket &t : ctx->tickets) {
+        if (!t.busy) continue;
+        for (int e : t.listed) {
+            if (e != env) continue;
+            // An entry that continues a wait / step loop (start = -1) which the host already knows to be over is dead: the
+            // check kernel retires it before anything of the episode is read (fs_k_wait_check), so the episode is free.
+            bool dead = false;
+            for (size_t q = 0; q < t.w_env.size(); ++q)
+                if (t.w_env[q] == env && t.w_start[q] < 0 && env < (int)ctx->wait_over.size() && ctx->wait_over[env]) dead = true;
+            if (dead) continue;
+            fs_set_error("service lane: episode " + std::to_string(env) + " is part of an fs_advance chunk in flight (fs_advance_end first)");
+            return FS_ERR_STATE;
+        }
+    }
+    return FS_OK;
+}
+#define LANE_GUARD(ctx, env)                                   \
+    do {                                                       \
+        const int guard_rc = fs_lane_guard((ctx), (env));      \
+        if (guard_rc != FS_OK) return guard_rc;                \
+    } while (0)
+
 static uint64_t fnv(uint64_t h, const void *data, size_t bytes) {
     const unsigned char *p = (const unsigned char *)data;
     for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
@@ -410,6 +434,7 @@ static int push_shapes(fs_ctx *ctx, int env) {
 static int set_scene_impl(fs_ctx *ctx, int env, FsHostScene &&scene) {
     FsEnv *e = get_env(ctx, env, false);
     if (!e) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     fs_sync_lane(ctx);  // nothing may still run on the episode's old slab (fs_sync_lane: what that means on either lane)
     if (e->slab) { fs_pool_give(ctx, e->slab, e->slab_bytes); e->slab = nullptr; e->slab_bytes = 0; }
     e->picker_ready = false;
@@ -660,6 +685,7 @@ extern "C" int fs_get_positions(fs_ctx *ctx, int env, float *out, int n_floats) 
 extern "C" int fs_set_positions(fs_ctx *ctx, int env, const float *in, int n_floats) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !in) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     CHECK_LEN(n_floats, 4 * e->host.n);
     HIP_TRY(hipSetDevice(ctx->device));
     return h2d(ctx, e->dev.pos, in, size_t(16) * e->host.n);
@@ -680,6 +706,7 @@ extern "C" int fs_get_velocities(fs_ctx *ctx, int env, float *out, int n_floats)
 extern "C" int fs_set_velocities(fs_ctx *ctx, int env, const float *in, int n_floats) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !in) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     const int n = e->host.n;
     CHECK_LEN(n_floats, 3 * n);
     HIP_TRY(hipSetDevice(ctx->device));
@@ -698,6 +725,7 @@ extern "C" int fs_get_phases(fs_ctx *ctx, int env, int *out, int n_ints) {
 extern "C" int fs_set_phases(fs_ctx *ctx, int env, const int *in, int n_ints) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !in) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     CHECK_LEN(n_ints, e->host.n);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = h2d(ctx, e->dev.phase, in, size_t(4) * e->host.n);
@@ -770,6 +798,7 @@ extern "C" int fs_get_params(fs_ctx *ctx, int env, float *o, int n_floats) {
 extern "C" int fs_set_params(fs_ctx *ctx, int env, const float *o, int n_floats) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !o) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     CHECK_LEN(n_floats, 32);
     HIP_TRY(hipSetDevice(ctx->device));
     FsParams &p = e->dev.p;
@@ -800,6 +829,7 @@ extern "C" int fs_get_scene_bounds(fs_ctx *ctx, int env, float *lower3, float *u
 extern "C" int fs_add_sphere(fs_ctx *ctx, int env, float radius, const float *pos3, const float *quat4) {
     FsEnv *e = get_env(ctx, env, false);
     if (!e || !pos3 || !quat4) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     if (e->shapes.count >= FS_MAX_SHAPES) { fs_set_error("too many shapes"); return FS_ERR_STATE; }
     HIP_TRY(hipSetDevice(ctx->device));
     int q = e->shapes.count++;
@@ -811,6 +841,7 @@ extern "C" int fs_add_sphere(fs_ctx *ctx, int env, float radius, const float *po
 extern "C" int fs_clear_shapes(fs_ctx *ctx, int env) {
     FsEnv *e = get_env(ctx, env, false);
     if (!e) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     HIP_TRY(hipSetDevice(ctx->device));
     e->shapes.count = 0;
     return push_shapes(ctx, env);
@@ -830,6 +861,7 @@ extern "C" int fs_get_shape_states(fs_ctx *ctx, int env, float *out, int n_float
 extern "C" int fs_set_shape_states(fs_ctx *ctx, int env, const float *in, int n_floats) {
     FsEnv *e = get_env(ctx, env, false);
     if (!e) return FS_ERR_ARG;
+    LANE_GUARD(ctx, env);
     if (e->shapes.count == 0) return FS_OK;  // loops over the internal count (pyflex.cpp:839)
     if (!in) return FS_ERR_ARG;
     CHECK_LEN(n_floats, 14 * e->shapes.count);

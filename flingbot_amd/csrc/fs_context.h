@@ -89,6 +89,7 @@ struct FsAdvTicket {
     size_t h_tab_bytes = 0;
     FsWaitDev *h_wait = nullptr;  // pinned [n_envs]: the wait states after the call's last launch
     int n = 0;
+    std::vector<int> listed;  // the call's episodes (fs_lane_guard)
     std::vector<int> w_arg, w_env, w_kind, w_limit, w_start;  // the call's waiters: index in the caller's arrays, episode, ...
     std::vector<char> w_skip;                                  // loop budget already used up when the call was made
     size_t n_seq = 0;
@@ -149,6 +150,8 @@ struct fs_ctx {
     size_t pool_bytes = 0;
     FsWaitDev *d_wait = nullptr;      // [n_envs]
     FsAdvTicket tickets[FS_ADV_TICKETS];
+    std::vector<char> wait_over;  // [n_envs] host's knowledge: the episode's wait / step loop has ended (fs_advance_end said so)
+                                  // and no new loop was started since -- its entries in chunks queued ahead retire unstepped
     int tickets_busy = 0;
     double *d_coverage = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;  // fs_timer_start / fs_timer_stop
@@ -166,6 +169,9 @@ void *fs_stage(fs_ctx *ctx, size_t bytes);
 void fs_sync_all_streams(fs_ctx *ctx);  // both lanes' streams and the launch chains' streams
 void fs_sync_lane(fs_ctx *ctx);         // service lane: its stream; main lane: the main stream and the chains'
 void *fs_svc_scratch(fs_ctx *ctx, size_t bytes);
+// The service lane's contract, checked: FS_ERR_STATE when a call on the service lane is about to rewrite an episode that is
+// part of an fs_advance chunk still in flight (nothing waits for the chunk there, so the write would race with its launches).
+int fs_lane_guard(fs_ctx *ctx, int env);
 void *fs_pool_take(fs_ctx *ctx, size_t bytes, size_t *got_bytes);
 void fs_pool_give(fs_ctx *ctx, void *ptr, size_t bytes);
 void *fs_loop_scratch(fs_ctx *ctx, size_t bytes);

@@ -315,11 +315,13 @@ extern "C" int fs_set_particles(fs_ctx *ctx, int n, const int *envs, const int *
     int *d_ids = nullptr;
     int rc = upload_list(ctx, n, envs, &d_ids);
     if (rc != FS_OK) return rc;
-    for (int k = 0; k < n; ++k)
+    for (int k = 0; k < n; ++k) {
         if (particle_ids[k] < 0 || particle_ids[k] >= ctx->envs[envs[k]].host.n) {
             fs_set_error("fs_set_particles: particle id out of range");
             return FS_ERR_ARG;
         }
+        if (const int guard_rc = fs_lane_guard(ctx, envs[k])) return guard_rc;
+    }
     char *d_buf = (char *)fs_svc_scratch(ctx, (sizeof(int) + 4 * sizeof(float)) * n);  // pids[n] | pos4[4n]
     if (!d_buf) return FS_ERR_HIP;
     int *d_pids = (int *)d_buf;

@@ -129,6 +129,7 @@ static FsEnv *picker_env(fs_ctx *ctx, int env) {
 extern "C" int fs_picker_reset(fs_ctx *ctx, int env, double picker_threshold, double particle_radius) {
     FsEnv *e = picker_env(ctx, env);
     if (!e) return FS_ERR_ARG;
+    if (const int guard_rc = fs_lane_guard(ctx, env)) return guard_rc;
     HIP_TRY(hipSetDevice(ctx->device));
     if (!e->d_picked) HIP_TRY(hipMalloc((void **)&e->d_picked, sizeof(int) * FS_MAX_SHAPES));
     if (!e->d_saved_w) {
@@ -537,9 +538,14 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
         status_out[a] = -1; progress_out[a] = start[a]; steps_out[a] = 0;
         T.w_arg.push_back(a); T.w_env.push_back(envs[a]); T.w_kind.push_back(kind[a]); T.w_limit.push_back(limit[a]);
         T.w_start.push_back(start[a]);
+        if (ctx->wait_over.size() != (size_t)ctx->n_envs) ctx->wait_over.assign((size_t)ctx->n_envs, 0);
+        if (start[a] >= 0) ctx->wait_over[envs[a]] = 0;  // a new loop
     }
     const int nw = (int)T.w_arg.size();
     T.n = n; T.n_seq = n_seq;
+    T.listed.clear();  // the episodes this call's launches may touch: its movers and the waiters that take part
+    for (int q = 0; q < nm; ++q) T.listed.push_back(envs[movers[q]]);
+    T.listed.insert(T.listed.end(), T.w_env.begin(), T.w_env.end());
     // host mirrors of the shape states follow the planned trajectories
     for (int q = 0; q < nm; ++q) {
         FsEnv &e = ctx->envs[envs[movers[q]]];
@@ -673,7 +679,9 @@ static int advance_end(fs_ctx *ctx, int ticket, int *progress_out, int *status_o
         const FsWaitDev w = T.h_wait[T.w_env[q]];
         if (progress_out) progress_out[a] = w.steps;
         if (steps_out) steps_out[a] = T.w_start[q] >= 0 ? w.steps - T.w_start[q] : -1;
-        if (status_out) status_out[a] = w.stable ? 1 : ((w.over || w.steps >= T.w_limit[q]) ? (T.w_kind[q] == 2 ? 1 : 2) : 0);
+        const int st = w.stable ? 1 : ((w.over || w.steps >= T.w_limit[q]) ? (T.w_kind[q] == 2 ? 1 : 2) : 0);
+        if (status_out) status_out[a] = st;
+        if (st != 0) ctx->wait_over[T.w_env[q]] = 1;  // (over on the device, or its next check finds the steps used up)
     }
     ctx->adv_wall_ms += T.wall_begin_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return FS_OK;

@@ -199,7 +199,10 @@ int fs_advance_in_flight(const fs_ctx *ctx);
 /* The service lane: between fs_service_lane(ctx, 1) and fs_service_lane(ctx, 0) every entry point of the library works on
    a second, high-priority stream, so that reductions, observations and resets for episodes that are NOT part of a chunk
    in flight neither queue up behind the chunk nor wait for it.  Contract: on the lane the caller touches only such
-   episodes (or ones whose wait loop in the chunk has already ended).  Leaving the lane orders the main stream behind it. */
+   episodes (or ones whose wait loop in the chunk has already ended).  Leaving the lane orders the main stream behind it.
+   The calls that REWRITE an episode (fs_set_scene*, fs_set_positions / velocities / phases / params / shape_states /
+   particles, fs_add_sphere, fs_clear_shapes, fs_picker_reset) check the contract: FS_ERR_STATE for an episode that an open
+   ticket still steps or moves (an entry that continues a wait loop fs_advance_end has already reported over does not count). */
 int fs_service_lane(fs_ctx *ctx, int on);
 /* fs_advance's stopwatch since fs_create: out5 = calls, launch sequences, wall ms inside the calls, device ms between a
    call's first and last launch, wall ms the calls spent before their first launch (planning, tables, upload) */

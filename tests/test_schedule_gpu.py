@@ -295,3 +295,34 @@ def test_advance_argument_errors(gpu_required):
     ref.step_list([1], 9)
     for e in range(2):
         assert np.array_equal(ctx.get_positions(e).view(np.uint32), ref.get_positions(e).view(np.uint32)), e
+
+
+def test_service_lane_refuses_to_rewrite_an_episode_in_flight(gpu_required):
+    """The service lane's contract -- only episodes that are NOT part of a chunk in flight -- is checked where it would
+    corrupt state silently: a setter / scene load / picker reset for a listed episode raises there, the same call for another
+    episode works, and after fs_advance_end (or on the main lane, which waits for the chunk) the episode can be written."""
+    from flingbot_amd import sim as fsim
+
+    g = load_fling_golden()
+    ctx = _make(g, 2)
+    z, gr = np.zeros((1, 2, 3)), np.zeros((1, 2), int)
+    ticket, prog, status, steps = ctx.advance_begin([0], [2], z, gr, [0.0], [6], [-1], [0], [0], cap_min=6, cap=6)
+    pos1 = ctx.get_positions(1).copy()
+    ctx.service_lane(True)
+    try:
+        for call in (lambda: ctx.set_positions(0, pos1), lambda: ctx.set_velocities(0, np.zeros(pos1.size // 4 * 3, np.float32)),
+                     lambda: ctx.env(0).set_scene(g["scene_params"]), lambda: ctx.picker_reset(0, 0.005, 0.00625)):
+            with pytest.raises(fsim.FlingSimError, match="in flight"):
+                call()
+        ctx.set_positions(1, pos1)  # the episode next to it is free
+    finally:
+        ctx.service_lane(False)
+    prog, status, steps = ctx.advance_end(ticket, prog, status, steps)
+    assert prog.tolist() == [6] and status.tolist() == [1]
+    ref = _make(g, 2)
+    ref.step_list([0], 6)
+    assert np.array_equal(ctx.get_positions(0).view(np.uint32), ref.get_positions(0).view(np.uint32))  # the refused calls changed nothing
+    ctx.service_lane(True)
+    ctx.set_positions(0, pos1)  # nothing in flight any more
+    ctx.service_lane(False)
+    assert np.array_equal(ctx.get_positions(0), pos1)
