@@ -56,9 +56,9 @@
 #ifndef FG_SINGLES
 #define FG_SINGLES 1
 #endif
-#define FG_SINGLES_CAP ((FS_FUSED_CUR_BYTES + FS_FUSED_MAX_PARTICLES * 2) / 16)  // 1536 entries of 16 B
 #define FG_SINGLES_LANES (FS_FUSED_THREADS - 64)                                  // waves 1..15, two rounds at most
-static_assert(FG_SINGLES_CAP <= 2 * FG_SINGLES_LANES, "pass 2 serves the singles queue in two rounds");
+#define FG_SINGLES_ROOM ((FS_FUSED_CUR_BYTES + FS_FUSED_MAX_PARTICLES * 2) / 16)  // 1536 entries of 16 B
+#define FG_SINGLES_CAP (FG_SINGLES_ROOM < 2 * FG_SINGLES_LANES ? FG_SINGLES_ROOM : 2 * FG_SINGLES_LANES)
 #ifndef FG_PREFETCH_CAND
 #define FG_PREFETCH_CAND 2                     // contact candidates of a particle fetched ahead (inline path; the heavy
                                                // particles are in the contact set and finished by pass 2)
