@@ -931,8 +931,8 @@ extern "C" int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lis
     if (rc != FS_OK) return rc;
     for (int i = 0; i < n; ++i)
         for (int s = 0; s < FS_MAX_NEIGHBORS; ++s)
-#ifdef FS_BLOCK_CLOCKS  // developer build: the fused grid kernel leaves its clocks in row 95 (scripts/block_clocks.py)
-            lists[size_t(i) * FS_MAX_NEIGHBORS + s] = (s < counts[i] || s == 95) ? slotmajor[size_t(s) * n + i] : -1;
+#ifdef FS_BLOCK_CLOCKS  // developer build: the instrumented kernels leave their clocks in rows 94 / 95 (scripts/block_clocks.py, stream_clocks.py)
+            lists[size_t(i) * FS_MAX_NEIGHBORS + s] = (s < counts[i] || s >= 94) ? slotmajor[size_t(s) * n + i] : -1;
 #else
             lists[size_t(i) * FS_MAX_NEIGHBORS + s] = s < counts[i] ? slotmajor[size_t(s) * n + i] : -1;
 #endif

@@ -699,8 +699,19 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
     const int e = E.slot_env;
     if (e < 0) return;  // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
-    if (i >= E.n) return;
-    fs_iterate_particle_gridl<POSK>(E, shapes[by], i, sub, flip);
+#ifdef FS_BLOCK_CLOCKS  // developer build: the constant 100 MHz clock at this workgroup's entry and exit, in rows 94 / 95 (by
+                        // `flip`) of the neighbour table (scripts/stream_clocks.py); wave 0 of the workgroup only
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (i < E.n) fs_iterate_particle_gridl<POSK>(E, shapes[by], i, sub, flip);
+#ifdef FS_BLOCK_CLOCKS
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+        E.nlist[(size_t)(94 + flip) * E.n + i] = (int)(unsigned)tr0;
+        E.nlist[(size_t)(94 + flip) * E.n + i + 1] = (int)(unsigned)tr1;
+    }
+#endif
 }
 
 // (A CONTACT-SORTED form was built and measured in round 2 as well: springs in id order, then accumulator, particle and first
