@@ -471,14 +471,16 @@ def run_rank(args):
         torch.distributed.destroy_process_group()
 
 
-def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=192, stream_slots=96):
+def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream_slots=192):
     """Secondary, after the timed region (rank 0, N = 1): BASELINE.json configs[4] at the reference's own sizes -- the
     run_sim.py evaluation loop on generated 'hard' tasks with cloth sides 64..103 (environment/tasks.py:105-275), 720 x 720
     render -> 400 x 400 observation with adaptive scaling, 12 rotations x 8 scales, seeded random-init fling policy
     (flingbot.pth is not in this image), up to `actions` actions per episode.  The loop is flingbot_amd.evaluate.run_tasks:
     like the reference's (utils.step_env's ray.wait, SimEnv pulling its next task) every slot steps on its own and refills
     itself, and the device is kept busy while the host serves requests (schedule.run_programs_pipelined).  Two figures: `episodes` tasks on as many slots (the configuration of the earlier rounds' figure), and
-    `continuous`: stream_tasks tasks through stream_slots slots (throughput of a long evaluation run).  Reports flings/s and
+    `continuous`: stream_tasks tasks through stream_slots slots (throughput of a long evaluation run; 192 slots since the end of
+    round 3 -- about a third of the slots is in a host-side stage at any time, and the streaming kernels only fill the chip from
+    ~130 active episodes on: 96 slots give 28 flings/s, 192 give 32, 256 give 32.6).  Reports flings/s and
     simulated episode-steps/s of the whole loop (perception + action selection + primitives + resets)."""
     try:
         import random
