@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -55,7 +56,16 @@ void *fs_pool_take(fs_ctx *ctx, size_t bytes, size_t *got_bytes) {
 }
 // Idle slabs beyond FS_POOL_IDLE_LIMIT go back to the driver, oldest first (sizes nobody asks for any more would otherwise
 // pile up over a long run of differently sized tasks; hipFree waits for the device, so whatever still reads them has finished).
-static const size_t FS_POOL_IDLE_LIMIT = size_t(4) << 30;
+static const size_t FS_POOL_IDLE_LIMIT = [] {
+    const char *v = getenv("FLINGSIM_POOL_IDLE_MB");  // (tests shrink it to see the trimming)
+    const long long mb = v ? atoll(v) : 0;
+    return mb > 0 ? size_t(mb) << 20 : size_t(4) << 30;
+}();
+extern "C" int fs_pool_stats(const fs_ctx *ctx, long long *out3) {
+    if (!ctx || !out3) return FS_ERR_ARG;
+    out3[0] = (long long)ctx->pool_bytes; out3[1] = (long long)ctx->pool.size(); out3[2] = (long long)FS_POOL_IDLE_LIMIT;
+    return FS_OK;
+}
 void fs_pool_give(fs_ctx *ctx, void *ptr, size_t bytes) {
     if (!ptr) return;
     ctx->pool.push_back(FsPoolBuf{ptr, bytes});

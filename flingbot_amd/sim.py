@@ -99,6 +99,7 @@ def load_library(build_if_missing=True):
         "fs_picker_set_radius": (ci, [vp, ci, C.c_double]),
         "fs_last_movep_steps": (C.c_longlong, [vp]),
         "fs_advance_timing": (ci, [vp, C.POINTER(C.c_double)]),
+        "fs_pool_stats": (ci, [vp, C.POINTER(C.c_longlong)]),
         "fs_advance_begin": (ci, [vp, ci, ip, ip, C.POINTER(C.c_double), ip, C.POINTER(C.c_double), ip, ip, ip, ip, C.c_double,
                                   C.POINTER(C.c_double), ci, ci, ip, ip, ip]),
         "fs_advance_end": (ci, [vp, ci, ip, ip, ip]),
@@ -350,6 +351,12 @@ class FlingSim:
         out = np.zeros(5, np.float64)
         self._ck(self.lib.fs_advance_timing(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
         return dict(calls=int(out[0]), sequences=int(out[1]), wall_ms=float(out[2]), gpu_ms=float(out[3]), prep_ms=float(out[4]))
+
+    def pool_stats(self):
+        """fs_pool_stats: dict(idle_bytes, idle_buffers, idle_limit) of the context's buffer pool."""
+        out = (C.c_longlong * 3)()
+        self._ck(self.lib.fs_pool_stats(self.h, out))
+        return dict(idle_bytes=int(out[0]), idle_buffers=int(out[1]), idle_limit=int(out[2]))
 
     def cloth_stats(self, envs):
         """[n,3] float32: min height, max height, max |velocity component| per episode (device reductions)."""

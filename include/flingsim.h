@@ -207,6 +207,10 @@ int fs_service_lane(fs_ctx *ctx, int on);
 /* fs_advance's stopwatch since fs_create: out5 = calls, launch sequences, wall ms inside the calls, device ms between a
    call's first and last launch, wall ms the calls spent before their first launch (planning, tables, upload) */
 int fs_advance_timing(const fs_ctx *ctx, double *out5);
+/* The context's buffer pool (episode slabs, topology images, ticket tables: recycled by size instead of hipFree / hipMalloc,
+   which synchronise the device).  out[0] = idle bytes held, out[1] = idle buffers, out[2] = the idle limit in bytes: what
+   lies beyond it goes back to the driver, oldest first (4 GiB; FLINGSIM_POOL_IDLE_MB overrides it when the library loads). */
+int fs_pool_stats(const fs_ctx *ctx, long long *out3);
 /* picked particle index per picker (-1 = none) */
 int fs_picker_get_picked(fs_ctx *ctx, int env, int *out, int n_ints);
 /* SimEnv.movep: move picker k toward targets[3k..3k+2] by `speed` per simulation step with grasp flag grasp[k], until all

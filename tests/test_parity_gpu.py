@@ -390,3 +390,39 @@ def test_two_contexts_on_two_devices(gpu_required):
         _assert_state_equal(ctx.env(0), orc, "device %d" % ctx.device)
     for ctx in ctxs:
         ctx.close()
+
+
+def test_buffer_pool_recycles_and_trims(gpu_required):
+    """Episode slabs and topology images are recycled through the context's pool (no hipFree / hipMalloc inside a running
+    loop); idle buffers beyond the limit go back to the driver.  With the limit shrunk to 8 MiB (a child process: the variable
+    is read when the library loads) a slot that cycles through cloths of three sizes keeps at most limit + one slab idle, and
+    the last scene still steps bit for bit like the oracle."""
+    import os, subprocess, sys, textwrap
+
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, "tests")
+        from conftest import cloth_params
+        from flingbot_amd import sim as fsim
+        from oracle import OracleSim
+        ctx = fsim.FlingSim(n_envs=2, solver=0)
+        st = ctx.pool_stats()
+        assert st["idle_limit"] == 8 << 20, st
+        peak = 0
+        for rep in range(4):
+            for dims in ((32, 32), (104, 104), (64, 64), (90, 70)):
+                for e in range(2):
+                    ctx.env(e).set_scene(cloth_params(*dims, pos=(0.0, -0.3, 0.0)))
+                ctx.step(2)
+                st = ctx.pool_stats()
+                peak = max(peak, st["idle_bytes"])
+        assert st["idle_buffers"] >= 1, st                       # something is being recycled
+        assert peak <= (8 << 20) + (16 << 20), peak              # ... and the idle part stays near the limit (one 104x104 slab is ~8 MiB)
+        orc = OracleSim(); orc.set_scene(cloth_params(90, 70, pos=(0.0, -0.3, 0.0))); orc.step(2)
+        assert np.array_equal(ctx.get_positions(0).view(np.uint32), orc.get_positions().view(np.uint32))
+        print("pool ok", st, peak)
+    """)
+    env = dict(os.environ, FLINGSIM_POOL_IDLE_MB="8")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "pool ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
