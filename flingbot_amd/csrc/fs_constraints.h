@@ -32,6 +32,9 @@ __device__ __forceinline__ float fs_dot3(float ax, float ay, float az, float bx,
 // of mul / fma it gives the same bits on the CPU oracle and on the GPU, and replaces the ~30 instruction
 // correctly-rounded sqrt + divide sequences (two quarter-rate ops among them) by 12 full-rate VALU ops.
 __device__ __forceinline__ float fs_rsqrt(float x) {
+#ifdef FS_HW_RSQ  // measurement build only (EXPERIMENTS R4.1): v_rsq_f32, 1 ulp, NOT bit-reproducible on the CPU
+    return __builtin_amdgcn_rsqf(x);
+#endif
     float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
     const float xh = 0.5f * x;
     y = y * FS_FMA(-(xh * y), y, 1.5f);

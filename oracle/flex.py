@@ -32,6 +32,11 @@ def oracle_lib_path():
 # bounding builds of the same step (oracle/Makefile): plain IEEE arithmetic, and each arithmetic choice alone.  Tests use
 # them to measure how far the default oracle's spelled-out approximations move a step; they are never the parity oracle.
 VARIANTS = ("exact", "exact_rsqrt", "nofma")
+# sensitivity builds of the model-level [I] choices (flex_oracle.c "MODEL switches"): one alternative reading each, built on
+# first use (liboracle_alt_<name>.so).  They measure how far another reading of the closed solver would move a trajectory
+# (PARITY.md); they are never the parity oracle either.
+MODEL_ALTERNATIVES = ("friction_post", "neighbors_by_distance", "shape_end_pose", "sleep_velocity_only", "sleep_at_predict",
+                      "no_sleep", "apply_per_type", "damping_mult", "stiffness_iter")
 
 
 def build_oracle(force=False):
@@ -56,9 +61,13 @@ _libs = {}
 def _load(variant=None):
     if variant in _libs:
         return _libs[variant]
-    assert variant is None or variant in VARIANTS, variant
+    assert variant is None or variant in VARIANTS or (variant.startswith("alt_") and variant[4:] in MODEL_ALTERNATIVES), variant
     path = oracle_lib_path() if variant is None else os.path.join(_HERE, f"liboracle_{variant}.so")
-    if not os.path.exists(path):
+    if variant is not None and variant.startswith("alt_"):
+        srcs = [os.path.join(_HERE, f) for f in ("flex_oracle.c", "flex_oracle.h", "Makefile")]
+        if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "-B", os.path.basename(path)])
+    elif not os.path.exists(path):
         build_oracle()
     lib = C.CDLL(path)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
@@ -78,6 +87,7 @@ def _load(variant=None):
     lib.orc_add_sphere.argtypes = [vp, C.c_float, fp, fp]
     lib.orc_clear_shapes.argtypes = [vp]
     lib.orc_get_last_neighbors.argtypes = [vp, ip, ip]
+    lib.orc_max_neighbor_list.argtypes = [vp]
     _libs[variant] = lib
     return lib
 
@@ -102,7 +112,8 @@ class OracleSim:
     """One cloth episode on the CPU oracle, pyflex-shaped methods."""
 
     def __init__(self, variant=None):
-        """variant: None = THE oracle; "exact" / "exact_rsqrt" / "nofma" = the bounding builds (VARIANTS)."""
+        """variant: None = THE oracle; "exact" / "exact_rsqrt" / "nofma" = the arithmetic bounding builds (VARIANTS);
+        "alt_<name>" = one model-level alternative (MODEL_ALTERNATIVES)."""
         self.lib = _load(variant)
         self.h = self.lib.orc_create()
 
@@ -215,6 +226,10 @@ class OracleSim:
         s = _f(s)
         assert s.size >= 14 * self.get_n_shapes()
         self.lib.orc_set_shape_states(self.h, _fp(s))
+
+    def max_neighbor_list(self):
+        """Longest particle-contact candidate list any particle has had since set_scene (before truncation to 96)."""
+        return self.lib.orc_max_neighbor_list(self.h)
 
     def get_last_neighbors(self):
         counts = np.empty(self.n, np.int32)

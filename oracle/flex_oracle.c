@@ -64,13 +64,15 @@ struct orc_sim {
     float *xp, *xn, *x0, *v0;
     int *ncount, *nlist;
     int *cell_key, *cell_order;
+    int max_list;  /* longest candidate list any particle has had since set_scene (white-box: PARITY.md) */
+    float *lam;    /* ORC_ALT_FRICTION_POST only */
 };
 
 static void free_scene(orc_sim *s) {
     free(s->pos); free(s->vel); free(s->phase); free(s->rest); free(s->sidx); free(s->slen); free(s->sk);
     free(s->tris); free(s->tnrm); free(s->nrm); free(s->adj_off); free(s->adj_spr);
     free(s->xp); free(s->xn); free(s->x0); free(s->v0); free(s->ncount); free(s->nlist);
-    free(s->cell_key); free(s->cell_order);
+    free(s->cell_key); free(s->cell_order); free(s->lam);
     memset(s, 0, sizeof(*s));
 }
 
@@ -306,6 +308,16 @@ int orc_set_scene(orc_sim *s, const float *ptr, const float *verts, int n_vert_f
     s->cell_key = (int *)malloc(sizeof(int) * 4 * (n + 1));
     s->cell_order = (int *)malloc(sizeof(int) * (n + 1));
     s->ns = 0;
+#ifdef ORC_ALT_FRICTION_POST
+    s->lam = (float *)calloc((size_t)(ORC_MAX_NEIGHBORS + 8 + ORC_MAX_SHAPES) * (n + 1), sizeof(float));
+#endif
+#ifdef ORC_ALT_STIFFNESS_ITER
+    for (int e = 0; e < m; ++e) { /* Mueller 2007 section 3.3: k' = 1 - (1 - k)^(1 / iterations); tethers keep their sign */
+        float k = fabsf(s->sk[e]);
+        float kk = (float)(1.0 - pow(1.0 - (double)(k > 1.0f ? 1.0f : k), 1.0 / (double)p->numIterations));
+        s->sk[e] = s->sk[e] < 0.0f ? -kk : kk;
+    }
+#endif
     return 0;
 }
 
@@ -333,6 +345,38 @@ static int cell_lower_bound(const orc_sim *s, const int *keys, int cx, int cy, i
     }
     return lo;
 }
+
+/*
+ * MODEL switches -- sensitivity builds (oracle/Makefile liboracle_alt_<name>.so; tests/parity_table.py -> PARITY.md).
+ * The solver step restates closed-source code, so every [I] below is a READING of NvFlex.h + Macklin 2014.  Each switch
+ * replaces exactly ONE such reading by its most plausible alternative; the default build (no switch) is THE oracle the HIP
+ * kernels are compared with bit for bit, the alternatives only measure how far a different reading would move a trajectory
+ * (= the error bar this repo can state on "within 1e-4 of PyFleX" without PyFleX).  Never used as a parity oracle.
+ *   -DORC_ALT_FRICTION_POST          contacts inside the iterations are frictionless; friction is applied once per substep
+ *                                    after the position solve, with the normal correction each contact accumulated over
+ *                                    the iterations as the Coulomb bound (default: per contact inside every iteration,
+ *                                    bound = that iteration's penetration depth, Macklin 2014 section 6.1)
+ *   -DORC_ALT_NEIGHBORS_BY_DISTANCE  a candidate list longer than maxNeighborsPerParticle keeps the 96 NEAREST
+ *                                    (default: the 96 smallest ids)
+ *   -DORC_ALT_SHAPE_END_POSE         kinematic spheres stand at their end-of-frame pose in every substep and carry the
+ *                                    frame's mean velocity (default: linear sweep prev -> current over the substeps)
+ *   -DORC_ALT_SLEEP_VELOCITY_ONLY    a particle below sleepThreshold gets zero velocity but keeps its new position
+ *   -DORC_ALT_SLEEP_AT_PREDICT       "considered fixed" is applied at predict (x* = x when the gravity-integrated speed is
+ *                                    below the threshold), nothing at finalize
+ *   -DORC_ALT_NO_SLEEP               sleepThreshold ignored (how much the rule matters at all)
+ *                                    (default: at finalize, position kept AND velocity zeroed)
+ *   -DORC_ALT_APPLY_PER_TYPE         one applyDeltas after each constraint type -- springs, then particle contacts, then
+ *                                    shapes, each seeing the previous type's result (default: one per iteration over all)
+ *   -DORC_ALT_DAMPING_MULT           v = (v + h g) (1 - h damping)   (default: v += h (g - damping v))
+ *   -DORC_ALT_STIFFNESS_ITER         spring stiffness made iteration-count independent, k' = 1 - (1 - k)^(1/iterations)
+ *                                    (Mueller 2007 section 3.3)   (default: k used as is in every iteration)
+ * The static-friction branch has no alternative worth a build: with mu_s <= mu_k (0 <= 0.75 for shapes, 1 = 1 between
+ * particles) "full stick below mu_s * depth" and "clamp to mu_k * depth" give the same scale for every input
+ * (tests/test_oracle_cpu.py::test_static_friction_branch_is_redundant).
+ */
+#if defined(ORC_ALT_SLEEP_VELOCITY_ONLY) + defined(ORC_ALT_SLEEP_AT_PREDICT) + defined(ORC_ALT_NO_SLEEP) > 1
+#error "one sleep alternative at a time"
+#endif
 
 /*
  * Particle-contact candidates, built once per substep on the predicted positions
@@ -386,6 +430,23 @@ static void find_neighbors(orc_sim *s) {
                     if (cnt < total_cap) tmp[cnt++] = j;
                 }
             }
+        if (cnt > s->max_list) s->max_list = cnt; /* before truncation */
+#ifdef ORC_ALT_NEIGHBORS_BY_DISTANCE
+        if (cnt > s->p.maxNeighbors) { /* keep the nearest: selection by (distance^2, id), then back to ascending id */
+            for (int a = 0; a < s->p.maxNeighbors; ++a) {
+                int best = a;
+                float bd = 0.0f;
+                for (int b = a; b < cnt; ++b) {
+                    const float *xj = s->xp + 4 * tmp[b];
+                    float ddx = xi[0] - xj[0], ddy = xi[1] - xj[1], ddz = xi[2] - xj[2];
+                    float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                    if (b == a || d2 < bd || (d2 == bd && tmp[b] < tmp[best])) { best = b; bd = d2; }
+                }
+                int t_ = tmp[a]; tmp[a] = tmp[best]; tmp[best] = t_;
+            }
+            cnt = s->p.maxNeighbors;
+        }
+#endif
         qsort(tmp, cnt, sizeof(int), cmp_int);
         if (cnt > s->p.maxNeighbors) cnt = s->p.maxNeighbors;
         s->ncount[i] = cnt;
@@ -448,6 +509,221 @@ static inline float friction_scale(float tl, float inv_tl, float pen, float mu_s
     return (tl > lim) ? ORC_OVER_LEN(lim, tl, inv_tl) : 1.0f;
 }
 
+/* which constraint types one Jacobi pass accumulates (the default iteration = one pass over all of them) */
+#define ORC_T_SPRINGS 1
+#define ORC_T_PARTICLES 2
+#define ORC_T_SHAPES 4
+#define ORC_T_ALL 7
+
+#ifdef ORC_ALT_FRICTION_POST
+#define ORC_LAM_STRIDE (ORC_MAX_NEIGHBORS + 8 + ORC_MAX_SHAPES) /* per particle: neighbour slots, planes, spheres */
+#define ORC_MU(x) 0.0f /* contacts inside the iterations are frictionless */
+#else
+#define ORC_MU(x) (x)
+#endif
+
+/* One Jacobi pass with local relaxation (NvFlex.h:86-90,152-153) over the constraint types in `types`: xp -> xn. */
+static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0, float (*sc)[3], float (*sd)[3], int types) {
+    const orc_params *p = &s->p;
+    const int n = s->n;
+    const float restd = p->solidRestDistance, restd2 = restd * restd;
+    const float cd = p->collisionDistance;
+    const float mu_pp = ORC_MU(p->particleFriction);
+    for (int i = 0; i < n; ++i) {
+        const float wi = xp[4 * i + 3];
+        const float xi0 = xp[4 * i], xi1 = xp[4 * i + 1], xi2 = xp[4 * i + 2];
+        if (!(wi > 0.0f)) { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; xn[4 * i + 3] = wi; continue; }
+        float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+        int cnt = 0;
+#ifdef ORC_ALT_FRICTION_POST
+        float cn_now[ORC_LAM_STRIDE];
+        memset(cn_now, 0, sizeof(cn_now));
+#endif
+        /* 4a. distance constraints (NvFlex.h:656-667), ascending spring id */
+        if (types & ORC_T_SPRINGS)
+        for (int a = s->adj_off[i]; a < s->adj_off[i + 1]; ++a) {
+            int e = s->adj_spr[a];
+            int j = (s->sidx[2 * e] == i) ? s->sidx[2 * e + 1] : s->sidx[2 * e];
+            const float wj = xp[4 * j + 3];
+            float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
+            float l2 = dot3(ex, ey, ez, ex, ey, ez);
+            float inv_len = orc_rsqrt(l2);
+            float len = ORC_LEN(l2, inv_len);
+            if (!(len > 0.0f)) continue;
+            float C = len - s->slen[e];
+            float k = s->sk[e];
+            if (k < 0.0f) { if (!(C > 0.0f)) continue; k = -k; } /* tether: unilateral */
+            float ratio = wi / (wi + wj);
+            float sc_ = (k * ratio) * ORC_OVER_LEN(C, len, inv_len);
+            d0 = ORC_FMA(-ex, sc_, d0); d1 = ORC_FMA(-ey, sc_, d1); d2 = ORC_FMA(-ez, sc_, d2);
+            cnt++;
+        }
+        /* 4b. particle-particle contacts (NvFlex.h:101 solidRestDistance, :107 particleFriction, :108 inelastic) */
+        const float ri0 = xi0 - x0[4 * i], ri1 = xi1 - x0[4 * i + 1], ri2 = xi2 - x0[4 * i + 2];
+        if (types & ORC_T_PARTICLES)
+        for (int a = 0; a < s->ncount[i]; ++a) {
+            int j = s->nlist[(size_t)ORC_MAX_NEIGHBORS * i + a];
+            const float wj = xp[4 * j + 3];
+            float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
+            float l2 = dot3(ex, ey, ez, ex, ey, ez);
+            if (!(l2 < restd2)) continue;
+            float inv = orc_rsqrt(l2);
+            float dist = ORC_LEN(l2, inv);
+            float nx, ny, nz;
+            if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
+            else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+            float pen = restd - dist;
+            float ratio = wi / (wi + wj);
+            float cn = pen * ratio;
+            float c0 = nx * cn, c1 = ny * cn, c2 = nz * cn;
+            if (mu_pp > 0.0f) {
+                float rx = ri0 - (xp[4 * j] - x0[4 * j]);
+                float ry = ri1 - (xp[4 * j + 1] - x0[4 * j + 1]);
+                float rz = ri2 - (xp[4 * j + 2] - x0[4 * j + 2]);
+                float rn = dot3(rx, ry, rz, nx, ny, nz);
+                float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
+                float tl2 = dot3(tx, ty, tz, tx, ty, tz);
+                if (tl2 > 0.0f) {
+                    float inv_tl = orc_rsqrt(tl2);
+                    float tl = ORC_LEN(tl2, inv_tl);
+                    float fs = friction_scale(tl, inv_tl, pen, mu_pp, mu_pp) * ratio;
+                    c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
+                }
+            }
+            d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
+            cnt++;
+#ifdef ORC_ALT_FRICTION_POST
+            cn_now[a] = cn;
+#endif
+        }
+        /* 4c. planes (NvFlex.h:145 collisionDistance, :149 plane form, :105-106 friction) */
+        if (types & ORC_T_SHAPES)
+        for (int q = 0; q < p->numPlanes; ++q) {
+            const float *pl = p->planes[q];
+            float sdist = dot3(pl[0], pl[1], pl[2], xi0, xi1, xi2) + pl[3];
+            if (!(sdist < cd)) continue;
+            float pen = cd - sdist;
+            float c0 = pl[0] * pen, c1 = pl[1] * pen, c2 = pl[2] * pen;
+#ifndef ORC_ALT_FRICTION_POST
+            float rn = dot3(ri0, ri1, ri2, pl[0], pl[1], pl[2]);
+            float tx = ORC_FMA(-pl[0], rn, ri0), ty = ORC_FMA(-pl[1], rn, ri1), tz = ORC_FMA(-pl[2], rn, ri2);
+            float tl2 = dot3(tx, ty, tz, tx, ty, tz);
+            if (tl2 > 0.0f) {
+                float inv_tl = orc_rsqrt(tl2);
+                float tl = ORC_LEN(tl2, inv_tl);
+                float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
+                c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
+            }
+#else
+            cn_now[ORC_MAX_NEIGHBORS + q] = pen;
+#endif
+            d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
+            cnt++;
+        }
+        /* 4d. kinematic spheres (NvFlex.h:941-987), all channels set so every particle collides (NvFlex.h:163,965) */
+        if (types & ORC_T_SHAPES)
+        for (int q = 0; q < s->ns; ++q) {
+            float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
+            float l2 = dot3(ex, ey, ez, ex, ey, ez);
+            float lim = s->sh_radius[q] + cd;
+            if (!(l2 < lim * lim)) continue;
+            float inv = orc_rsqrt(l2);
+            float dist = ORC_LEN(l2, inv);
+            float nx, ny, nz;
+            if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
+            else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+            float pen = lim - dist;
+            float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
+#ifndef ORC_ALT_FRICTION_POST
+            float rx = ri0 - sd[q][0], ry = ri1 - sd[q][1], rz = ri2 - sd[q][2];
+            float rn = dot3(rx, ry, rz, nx, ny, nz);
+            float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
+            float tl2 = dot3(tx, ty, tz, tx, ty, tz);
+            if (tl2 > 0.0f) {
+                float inv_tl = orc_rsqrt(tl2);
+                float tl = ORC_LEN(tl2, inv_tl);
+                float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
+                c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
+            }
+#else
+            cn_now[ORC_MAX_NEIGHBORS + 8 + q] = pen;
+#endif
+            d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
+            cnt++;
+        }
+        /* 4e. applyDeltas, eNvFlexRelaxationLocal: delta / constraint count * relaxationFactor */
+        if (cnt > 0) {
+            float sc_ = p->relaxationFactor / (float)cnt;
+            xn[4 * i] = ORC_FMA(d0, sc_, xi0); xn[4 * i + 1] = ORC_FMA(d1, sc_, xi1); xn[4 * i + 2] = ORC_FMA(d2, sc_, xi2);
+#ifdef ORC_ALT_FRICTION_POST
+            float *lam = s->lam + (size_t)ORC_LAM_STRIDE * i; /* normal correction each contact really applied so far */
+            for (int c = 0; c < ORC_LAM_STRIDE; ++c) lam[c] += cn_now[c] * sc_;
+#endif
+        } else { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; }
+        xn[4 * i + 3] = wi;
+    }
+}
+
+#ifdef ORC_ALT_FRICTION_POST
+/* Friction after the position solve: one Jacobi pass in which every contact that pushed during the iterations removes
+   tangential relative displacement (since the substep start) up to mu x the normal correction it accumulated. */
+static void friction_pass(orc_sim *s, const float *xp, float *xn, const float *x0, float (*sc)[3], float (*sd)[3]) {
+    const orc_params *p = &s->p;
+    const int n = s->n;
+    for (int i = 0; i < n; ++i) {
+        const float wi = xp[4 * i + 3];
+        const float xi0 = xp[4 * i], xi1 = xp[4 * i + 1], xi2 = xp[4 * i + 2];
+        xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; xn[4 * i + 3] = wi;
+        if (!(wi > 0.0f)) continue;
+        const float *lam = s->lam + (size_t)ORC_LAM_STRIDE * i;
+        const float ri0 = xi0 - x0[4 * i], ri1 = xi1 - x0[4 * i + 1], ri2 = xi2 - x0[4 * i + 2];
+        float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+        int cnt = 0;
+        for (int c = 0; c < ORC_LAM_STRIDE; ++c) {
+            if (!(lam[c] > 0.0f)) continue;
+            float nx, ny, nz, rx, ry, rz, mu_s, mu_k, ratio = 1.0f;
+            if (c < ORC_MAX_NEIGHBORS) {
+                int j = s->nlist[(size_t)ORC_MAX_NEIGHBORS * i + c];
+                float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
+                float l2 = dot3(ex, ey, ez, ex, ey, ez);
+                if (l2 > 0.0f) { float inv = orc_rsqrt(l2); nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+                rx = ri0 - (xp[4 * j] - x0[4 * j]); ry = ri1 - (xp[4 * j + 1] - x0[4 * j + 1]); rz = ri2 - (xp[4 * j + 2] - x0[4 * j + 2]);
+                mu_s = mu_k = p->particleFriction;
+                ratio = wi / (wi + xp[4 * j + 3]);
+            } else if (c < ORC_MAX_NEIGHBORS + 8) {
+                const float *pl = p->planes[c - ORC_MAX_NEIGHBORS];
+                nx = pl[0]; ny = pl[1]; nz = pl[2];
+                rx = ri0; ry = ri1; rz = ri2;
+                mu_s = p->staticFriction; mu_k = p->dynamicFriction;
+            } else {
+                int q = c - ORC_MAX_NEIGHBORS - 8;
+                float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
+                float l2 = dot3(ex, ey, ez, ex, ey, ez);
+                if (l2 > 0.0f) { float inv = orc_rsqrt(l2); nx = ex * inv; ny = ey * inv; nz = ez * inv; }
+                else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+                rx = ri0 - sd[q][0]; ry = ri1 - sd[q][1]; rz = ri2 - sd[q][2];
+                mu_s = p->staticFriction; mu_k = p->dynamicFriction;
+            }
+            if (!(mu_k > 0.0f)) continue;
+            float rn = dot3(rx, ry, rz, nx, ny, nz);
+            float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
+            float tl2 = dot3(tx, ty, tz, tx, ty, tz);
+            if (!(tl2 > 0.0f)) continue;
+            float inv_tl = orc_rsqrt(tl2);
+            float tl = ORC_LEN(tl2, inv_tl);
+            float fs = friction_scale(tl, inv_tl, lam[c], mu_s, mu_k) * ratio;
+            d0 = ORC_FMA(-tx, fs, d0); d1 = ORC_FMA(-ty, fs, d1); d2 = ORC_FMA(-tz, fs, d2);
+            cnt++;
+        }
+        if (cnt > 0) {
+            float sc_ = p->relaxationFactor / (float)cnt;
+            xn[4 * i] = ORC_FMA(d0, sc_, xi0); xn[4 * i + 1] = ORC_FMA(d1, sc_, xi1); xn[4 * i + 2] = ORC_FMA(d2, sc_, xi2);
+        }
+    }
+}
+#endif
+
 static void substep(orc_sim *s, int sub, float h, float inv_h) {
     const orc_params *p = &s->p;
     const int n = s->n;
@@ -461,11 +737,25 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
         x0[4 * i + 3] = w;
         xp[4 * i + 3] = w;
         if (w > 0.0f) {
+#ifdef ORC_ALT_SLEEP_AT_PREDICT
+            float vv[3];
+#endif
             for (int k = 0; k < 3; ++k) {
                 float v = s->vel[3 * i + k];
+#ifdef ORC_ALT_DAMPING_MULT
+                v = (v + h * p->gravity[k]) * (1.0f - h * p->damping);
+#else
                 v = v + h * (p->gravity[k] - p->damping * v);
+#endif
                 xp[4 * i + k] = x0[4 * i + k] + h * v;
+#ifdef ORC_ALT_SLEEP_AT_PREDICT
+                vv[k] = v;
+#endif
             }
+#ifdef ORC_ALT_SLEEP_AT_PREDICT
+            if (vv[0] * vv[0] + vv[1] * vv[1] + vv[2] * vv[2] < p->sleepThreshold * p->sleepThreshold)
+                for (int k = 0; k < 3; ++k) xp[4 * i + k] = x0[4 * i + k];
+#endif
         } else {
             for (int k = 0; k < 3; ++k) xp[4 * i + k] = x0[4 * i + k];
         }
@@ -480,129 +770,40 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
         float a1 = (float)(sub + 1) / S, a0 = (float)sub / S;
         for (int k = 0; k < 3; ++k) {
             float dlt = s->sh_pos[q][k] - s->sh_prev[q][k];
+#ifdef ORC_ALT_SHAPE_END_POSE
+            (void)a1; (void)a0;
+            sc[q][k] = s->sh_pos[q][k];
+            sd[q][k] = dlt / S;
+#else
             float c1 = s->sh_prev[q][k] + dlt * a1;
             float c0 = s->sh_prev[q][k] + dlt * a0;
             sc[q][k] = c1;
             sd[q][k] = c1 - c0;
+#endif
         }
     }
 
-    const float restd = p->solidRestDistance, restd2 = restd * restd;
-    const float cd = p->collisionDistance;
-    /* 4. Jacobi iterations with local relaxation (NvFlex.h:86-90,152-153) */
+#ifdef ORC_ALT_FRICTION_POST
+    memset(s->lam, 0, sizeof(float) * (size_t)ORC_LAM_STRIDE * n);
+#endif
+    /* 4. Jacobi iterations with local relaxation (NvFlex.h:86-90,152-153); one applyDeltas per iteration over all
+          constraint types [I: the single applyDeltas timer, NvFlex.h:215] */
     for (int it = 0; it < p->numIterations; ++it) {
-        for (int i = 0; i < n; ++i) {
-            const float wi = xp[4 * i + 3];
-            const float xi0 = xp[4 * i], xi1 = xp[4 * i + 1], xi2 = xp[4 * i + 2];
-            if (!(wi > 0.0f)) { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; xn[4 * i + 3] = wi; continue; }
-            float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
-            int cnt = 0;
-            /* 4a. distance constraints (NvFlex.h:656-667), ascending spring id */
-            for (int a = s->adj_off[i]; a < s->adj_off[i + 1]; ++a) {
-                int e = s->adj_spr[a];
-                int j = (s->sidx[2 * e] == i) ? s->sidx[2 * e + 1] : s->sidx[2 * e];
-                const float wj = xp[4 * j + 3];
-                float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
-                float l2 = dot3(ex, ey, ez, ex, ey, ez);
-                float inv_len = orc_rsqrt(l2);
-                float len = ORC_LEN(l2, inv_len);
-                if (!(len > 0.0f)) continue;
-                float C = len - s->slen[e];
-                float k = s->sk[e];
-                if (k < 0.0f) { if (!(C > 0.0f)) continue; k = -k; } /* tether: unilateral */
-                float ratio = wi / (wi + wj);
-                float sc_ = (k * ratio) * ORC_OVER_LEN(C, len, inv_len);
-                d0 = ORC_FMA(-ex, sc_, d0); d1 = ORC_FMA(-ey, sc_, d1); d2 = ORC_FMA(-ez, sc_, d2);
-                cnt++;
-            }
-            /* 4b. particle-particle contacts (NvFlex.h:101 solidRestDistance, :107 particleFriction, :108 inelastic) */
-            const float ri0 = xi0 - x0[4 * i], ri1 = xi1 - x0[4 * i + 1], ri2 = xi2 - x0[4 * i + 2];
-            for (int a = 0; a < s->ncount[i]; ++a) {
-                int j = s->nlist[(size_t)ORC_MAX_NEIGHBORS * i + a];
-                const float wj = xp[4 * j + 3];
-                float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
-                float l2 = dot3(ex, ey, ez, ex, ey, ez);
-                if (!(l2 < restd2)) continue;
-                float inv = orc_rsqrt(l2);
-                float dist = ORC_LEN(l2, inv);
-                float nx, ny, nz;
-                if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
-                else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
-                float pen = restd - dist;
-                float ratio = wi / (wi + wj);
-                float cn = pen * ratio;
-                float c0 = nx * cn, c1 = ny * cn, c2 = nz * cn;
-                if (p->particleFriction > 0.0f) {
-                    float rx = ri0 - (xp[4 * j] - x0[4 * j]);
-                    float ry = ri1 - (xp[4 * j + 1] - x0[4 * j + 1]);
-                    float rz = ri2 - (xp[4 * j + 2] - x0[4 * j + 2]);
-                    float rn = dot3(rx, ry, rz, nx, ny, nz);
-                    float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
-                    float tl2 = dot3(tx, ty, tz, tx, ty, tz);
-                    if (tl2 > 0.0f) {
-                        float inv_tl = orc_rsqrt(tl2);
-                        float tl = ORC_LEN(tl2, inv_tl);
-                        float fs = friction_scale(tl, inv_tl, pen, p->particleFriction, p->particleFriction) * ratio;
-                        c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
-                    }
-                }
-                d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
-                cnt++;
-            }
-            /* 4c. planes (NvFlex.h:145 collisionDistance, :149 plane form, :105-106 friction) */
-            for (int q = 0; q < p->numPlanes; ++q) {
-                const float *pl = p->planes[q];
-                float sdist = dot3(pl[0], pl[1], pl[2], xi0, xi1, xi2) + pl[3];
-                if (!(sdist < cd)) continue;
-                float pen = cd - sdist;
-                float c0 = pl[0] * pen, c1 = pl[1] * pen, c2 = pl[2] * pen;
-                float rn = dot3(ri0, ri1, ri2, pl[0], pl[1], pl[2]);
-                float tx = ORC_FMA(-pl[0], rn, ri0), ty = ORC_FMA(-pl[1], rn, ri1), tz = ORC_FMA(-pl[2], rn, ri2);
-                float tl2 = dot3(tx, ty, tz, tx, ty, tz);
-                if (tl2 > 0.0f) {
-                    float inv_tl = orc_rsqrt(tl2);
-                    float tl = ORC_LEN(tl2, inv_tl);
-                    float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
-                    c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
-                }
-                d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
-                cnt++;
-            }
-            /* 4d. kinematic spheres (NvFlex.h:941-987), all channels set so every particle collides (NvFlex.h:163,965) */
-            for (int q = 0; q < s->ns; ++q) {
-                float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
-                float l2 = dot3(ex, ey, ez, ex, ey, ez);
-                float lim = s->sh_radius[q] + cd;
-                if (!(l2 < lim * lim)) continue;
-                float inv = orc_rsqrt(l2);
-                float dist = ORC_LEN(l2, inv);
-                float nx, ny, nz;
-                if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
-                else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
-                float pen = lim - dist;
-                float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
-                float rx = ri0 - sd[q][0], ry = ri1 - sd[q][1], rz = ri2 - sd[q][2];
-                float rn = dot3(rx, ry, rz, nx, ny, nz);
-                float tx = ORC_FMA(-nx, rn, rx), ty = ORC_FMA(-ny, rn, ry), tz = ORC_FMA(-nz, rn, rz);
-                float tl2 = dot3(tx, ty, tz, tx, ty, tz);
-                if (tl2 > 0.0f) {
-                    float inv_tl = orc_rsqrt(tl2);
-                    float tl = ORC_LEN(tl2, inv_tl);
-                    float fs = friction_scale(tl, inv_tl, pen, p->staticFriction, p->dynamicFriction);
-                    c0 = ORC_FMA(-tx, fs, c0); c1 = ORC_FMA(-ty, fs, c1); c2 = ORC_FMA(-tz, fs, c2);
-                }
-                d0 = d0 + c0; d1 = d1 + c1; d2 = d2 + c2;
-                cnt++;
-            }
-            /* 4e. applyDeltas, eNvFlexRelaxationLocal: delta / constraint count * relaxationFactor */
-            if (cnt > 0) {
-                float sc_ = p->relaxationFactor / (float)cnt;
-                xn[4 * i] = ORC_FMA(d0, sc_, xi0); xn[4 * i + 1] = ORC_FMA(d1, sc_, xi1); xn[4 * i + 2] = ORC_FMA(d2, sc_, xi2);
-            } else { xn[4 * i] = xi0; xn[4 * i + 1] = xi1; xn[4 * i + 2] = xi2; }
-            xn[4 * i + 3] = wi;
+#ifdef ORC_ALT_APPLY_PER_TYPE
+        static const int order[3] = {ORC_T_SPRINGS, ORC_T_PARTICLES, ORC_T_SHAPES};
+        for (int ty = 0; ty < 3; ++ty) {
+            jacobi_pass(s, xp, xn, x0, sc, sd, order[ty]);
+            float *t = xp; xp = xn; xn = t;
         }
+#else
+        jacobi_pass(s, xp, xn, x0, sc, sd, ORC_T_ALL);
         float *t = xp; xp = xn; xn = t;
+#endif
     }
+#ifdef ORC_ALT_FRICTION_POST
+    friction_pass(s, xp, xn, x0, sc, sd);
+    { float *t = xp; xp = xn; xn = t; }
+#endif
     s->xp = xp; s->xn = xn;
 
     /* 5. finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping
@@ -626,11 +827,18 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
             for (int k = 0; k < 3; ++k) v[k] = v[k] * sc_;
             v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
         }
+#if defined(ORC_ALT_NO_SLEEP) || defined(ORC_ALT_SLEEP_AT_PREDICT)
+        (void)thr2;
+        for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
+#elif defined(ORC_ALT_SLEEP_VELOCITY_ONLY)
+        for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = (v2 < thr2) ? 0.0f : v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
+#else
         if (v2 < thr2) { /* asleep: "considered fixed" -> keeps its position, zero velocity [I] */
             for (int k = 0; k < 3; ++k) s->vel[3 * i + k] = 0.0f;
         } else {
             for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
         }
+#endif
     }
 }
 
@@ -712,6 +920,8 @@ int orc_set_shape_states(orc_sim *s, const float *in) {
     }
     return 0;
 }
+
+int orc_max_neighbor_list(const orc_sim *s) { return s->max_list; }
 
 int orc_get_last_neighbors(const orc_sim *s, int *counts, int *lists) {
     memcpy(counts, s->ncount, sizeof(int) * s->n);

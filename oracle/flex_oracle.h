@@ -61,6 +61,9 @@ int orc_set_shape_states(orc_sim *s, const float *in14s);
 
 /* neighbour (particle-contact candidate) lists of the LAST substep run, for white-box tests:
    out_counts[n], out_lists[n*96] */
+/* longest candidate list (before truncation to 96 it is capped there) any particle has had since set_scene */
+int orc_max_neighbor_list(const orc_sim *s);
+
 int orc_get_last_neighbors(const orc_sim *s, int *out_counts, int *out_lists);
 
 #ifdef __cplusplus
