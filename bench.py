@@ -141,7 +141,7 @@ def traffic_from_profile(episodes):
 def limiter_from_profile():
     """What the committed PMC counters say actually limits the fused kernel (it keeps the iterations in LDS, so the
     contract's algorithmic-bytes `roofline` is an equivalent streamed bandwidth, not HBM traffic)."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
         try:
             with open(path) as fh:
@@ -149,8 +149,10 @@ def limiter_from_profile():
             c = rec["counters"]
             valu = c["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] / c["SQ_WAVE_CYCLES"]["avg_per_launch"]
             return {"bound": "valu-issue", "source": f"profiles/{tag}_pmc.json", "episodes": rec.get("episodes", 256),
-                    "valu_active_per_wave_cycle": valu, "ceiling_per_wave_cycle": 1.0 / rec.get("waves_per_simd", 4),
-                    "frac": valu * rec.get("waves_per_simd", 4),
+                    "valu_active_per_wave_cycle": valu, "waves_per_simd": rec.get("waves_per_simd", 4),
+                    "note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES: with 4 resident waves per SIMD a VALU that never idles gives "
+                            "~0.25 per wave-cycle; the counter pair is an indicator, not a calibrated ceiling -- the bounded "
+                            "figure is `valu_roofline` (lane-operations per second against the issue peak)",
                     "valu_instructions_per_launch": c["SQ_INSTS_VALU"]["avg_per_launch"],
                     "hbm_bytes_per_launch": rec["hbm_bytes_per_launch"]["total_corrected"],
                     "hbm_gbs": rec["hbm_bytes_per_launch"]["total_corrected"] / (rec["average_us"] * 1e-6) / 1e9,
@@ -184,7 +186,7 @@ def stream_limiter_from_profile():
     """What the committed profiles say about the 64-episodes-per-GPU launch shape (streaming back-end, two launch
     chains): per-kernel share and duration of one frame's 129 dependent launches."""
     import csv
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{tag}_stream64_kernel_stats.csv")
         try:
             rows = list(csv.reader(open(path)))[1:]
@@ -229,10 +231,49 @@ def perception_leg(device):
                 net(obs)
             torch.cuda.synchronize(device)
         ms = (time.perf_counter() - t0) / 50 * 1e3
-        return {"value_net_ms_per_observation": ms, "value_net_useful_tflops_f32": 96 * 306.7e6 / (ms * 1e-3) / 1e12,
-                "value_net_path": "fs_value_net_forward" if net._hip is not None else "pytorch"}
+        out = {"value_net_ms_per_observation": ms, "value_net_useful_tflops_f32": 96 * 306.7e6 / (ms * 1e-3) / 1e12,
+               "value_net_fraction_of_f32_mfma_peak": 96 * 306.7e6 / (ms * 1e-3) / 1e12 / 157.3,
+               "value_net_path": "fs_value_net_forward" if net._hip is not None else "pytorch"}
+        out.update(render_leg(device.index or 0))
+        return out
     except Exception as exc:  # the headline number must not depend on this leg
         return {"error": str(exc)[:200]}
+
+
+RENDER_BYTES = 720 * 720 * (4 + 4) + N_PART * 32 + 7938 * 12      # RGBA8 + depth out, positions + normals + triangles in
+
+
+def render_leg(device_index, frames=30):
+    """BASELINE.json configs[1] (64 x 64 cloth + depth render, one GPU): one crumpled bench episode with the two pickers
+    parked where SimEnv leaves them; `pyflex.render()` as the reference calls it (720 x 720 RGBA + depth downloaded to the
+    host, pyflex.cpp:924-1133) and the device-resident observation (render -> 400 x 400 obs + cloth mask + bounding box,
+    nothing downloaded but 5 integers), milliseconds per call and the render's 4.4 MB of algorithmic bytes per second."""
+    from flingbot_amd import sim as fsim
+    ctx = fsim.FlingSim(n_envs=1, device=device_index)
+    setup_episode(ctx.env(0), seed=0)
+    for c in ((0.5, 0.5, -0.5), (-0.5, 0.5, -0.5)):
+        ctx.env(0).add_sphere(0.02, c, [1, 0, 0, 0])
+    ctx.step(80)
+    ctx.render(0); ctx.observe(0, 400)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        ctx.render(0)
+    t_render = (time.perf_counter() - t0) / frames
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        ctx.observe(0, 400)
+    ctx.sync()
+    t_obs = (time.perf_counter() - t0) / frames
+    ctx.close()
+    return {"render": {"baseline_config": "configs[1]", "cloth": "64x64 crumpled + 2 picker spheres", "render_dim": 720,
+                       "pyflex_render_ms": t_render * 1e3, "pyflex_render_includes": "2 x 2.07 MB download to the host (the reference's return value)",
+                       "render_observe_device_ms": t_obs * 1e3, "observe_dim": 400,
+                       "algorithmic_bytes_per_frame": RENDER_BYTES,
+                       "device_path_gbs": RENDER_BYTES / t_obs / 1e9,
+                       "device_path_frac_of_hbm_peak": RENDER_BYTES / t_obs / 1e9 / HBM_PEAK_GBS,
+                       "note": "4.4 MB per frame: a latency-bound chain of small kernels (sphere mesh, normals, two raster passes, "
+                               "shade, resize, labelling rounds), not a bandwidth problem; profiles/r04_render_kernel_stats.csv"}}
 
 
 def timed_batch(ctx, fdist, torch, steps, warmup, preroll):
@@ -346,6 +387,160 @@ class ParityCheck:
                 "episode": self.seed, "mode": self.mode, "checker": "oracle/flex_oracle.c"}
 
 
+# ---------------------------------------------------------------- crumple + scripted two-corner fling
+C2_RAISE, C2_HOLD, C2_SETTLE, C2_FLING_SETTLE = 200, 100, 150, 300
+
+
+def c2_crumple(ctx, seeds):
+    """The deterministic "hard task" crumple of SURVEY 8(d) C2 for every episode of `ctx` (tests/scenarios.py scenario_c2 is
+    the same recipe for one episode of any solver; mirror of environment/tasks.py:177-224): flattened 64 x 64 sheet,
+    center_object's step, particle seed % N pinned and raised to 0.5 + u over 200 steps, held 100, released, 150 settle
+    steps.  The pinned particle is rewritten on the device (fs_set_particles) instead of through 2 x 64 KiB per step."""
+    import scenarios as sc
+
+    E = ctx.n_envs
+    flat = sc.set_to_flatten_positions(DIM, DIM).flatten()
+    for e in range(E):
+        env = ctx.env(e)
+        env.set_scene(sc.survey_params(DIM))
+        env.step(1)
+        env.set_positions(flat)
+        pos = env.get_positions().reshape(-1, 4).copy()
+        pos[:, [0, 2]] -= np.mean(pos[:, [0, 2]], axis=0, keepdims=True)
+        env.set_positions(pos.ravel())
+    ctx.step(1)
+    ks = np.array([int(sd) % N_PART for sd in seeds], np.int32)
+    heights = np.array([float(np.random.RandomState(int(sd)).random_sample(1)[0]) + 0.5 for sd in seeds])
+    pick = np.stack([ctx.get_positions(e).reshape(-1, 4)[ks[e]].copy() for e in range(E)]).astype(np.float32)
+    w0 = pick[:, 3].copy()
+    init_h = pick[:, 1].copy()
+    pick[:, 3] = 0.0
+    envs = np.arange(E, dtype=np.int32)
+    speed = 1.0 / C2_RAISE
+    for j in range(C2_RAISE + C2_HOLD):
+        if j < C2_RAISE:
+            pick[:, 1] = ((heights - init_h.astype(np.float64)) * (j * speed) + init_h).astype(np.float32)
+        ctx.set_particles(envs, ks, pick, zero_velocity=True)
+        ctx.step(1)
+    for e in range(E):  # release: the particle gets its mass back where the solver left it (kinematic: where it was put)
+        pick[e, :3] = ctx.get_positions(e).reshape(-1, 4)[ks[e], :3]
+    pick[:, 3] = w0
+    ctx.set_particles(envs, ks, pick, zero_velocity=False)
+    ctx.step(C2_SETTLE)
+
+
+def c2_fling_script(batch, envs, corners, timed=None):
+    """The scripted fling of SURVEY 8(d) on `batch` (FlingSim, or the oracle stand-in of the checker -- both expose the
+    batched movep of SimEnv.movep): both pickers to 5 cm above the cloth corners 0 and DIM - 1, down onto them, grasp, lift
+    to y = 0.3 at 5e-3 per step, forward / back +-0.2 at 6e-3 per step (simEnv.py:262-275 speeds), down to 0.05, release,
+    300 settle steps.  Returns the simulation steps taken, summed over the episodes."""
+    n = len(envs)
+    steps = 0
+
+    def go(targets, grasp, speed):
+        nonlocal steps
+        batch.movep(envs, targets, np.full((n, 2), int(grasp)), speed=speed, limit=2000)
+        steps += int(batch.last_movep_steps)
+
+    c = np.asarray(corners, np.float64).reshape(n, 2, 3)
+    above = c.copy(); above[:, :, 1] += 0.05
+    go(above, False, 0.05)
+    on = c.copy(); on[:, :, 1] += 0.01
+    go(on, False, 5e-3)
+    up = on.copy(); up[:, :, 1] = 0.3
+    go(up, True, 5e-3)
+    fwd = up.copy(); fwd[:, :, 2] += 0.2
+    go(fwd, True, 6e-3)
+    back = up.copy(); back[:, :, 2] -= 0.2
+    go(back, True, 6e-3)
+    low = back.copy(); low[:, :, 1] = 0.05
+    go(low, True, 6e-3)
+    go(low, False, 6e-3)          # release (the pickers are on their targets: no simulation step)
+    batch.step_list(list(envs), C2_FLING_SETTLE)
+    return steps + n * C2_FLING_SETTLE
+
+
+class C2Check:
+    """The checker of a C2 entry: episode `env` from the state the timed region started in (particles, velocities, pickers),
+    the same script on the CPU oracle + the numpy restatement of the reference picker (tests/fling_helpers.OracleBatch),
+    compared bit for bit with where the GPU left the episode.  Runs in a thread after every timed region."""
+
+    def __init__(self, env, start_state, corners, gpu_end):
+        import threading
+        self.env, self.start, self.corners, self.gpu_end, self.out = env, start_state, corners, gpu_end, None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import scenarios as sc
+        from fling_helpers import OracleBatch
+        from flingbot_amd.primitives import FlingPrimitives
+
+        pos, vel = self.start
+        ob = OracleBatch(1, sc.survey_params(DIM), pos.reshape(-1, 4), pickers=False)
+        ob.sims[0].set_velocities(vel)
+        FlingPrimitives(ob, [0]).place_pickers(0)
+        steps = c2_fling_script(ob, [0], self.corners[None])
+        po, vo = ob.sims[0].get_positions(), ob.sims[0].get_velocities()
+        ph, vh = self.gpu_end
+        exact = bool(np.array_equal(ph.view(np.uint32), po.view(np.uint32)) and np.array_equal(vh.view(np.uint32), vo.view(np.uint32)))
+        rel = float(np.abs(ph - po).max() / max(1.0, float(np.abs(po).max())))
+        self.out = {"parity_checked": True, "bit_exact": exact, "max_rel_position_error": rel, "within_1e-4": rel <= 1e-4,
+                    "episode": int(self.env), "mode": f"fling + settle phases ({steps} frames) from the GPU's post-crumple state",
+                    "checker": "oracle/flex_oracle.c + oracle/picker.py"}
+
+    def start_thread(self):
+        self.thread.start()
+
+    def result(self):
+        self.thread.join()
+        return self.out
+
+
+def c2_leg(fsim, fdist, torch, local_rank, rank, world, E, check=True):
+    """One C2 / C3 entry: E episodes per GPU, crumple (untimed) then the scripted fling + settle timed with the same
+    brackets as the headline.  Returns (entry or None on ranks > 0, checker or None)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from flingbot_amd.primitives import FlingPrimitives
+
+    ctx = fsim.FlingSim(n_envs=E, device=local_rank, solver=fsim.FS_SOLVER_AUTO)
+    seeds = list(fdist.episode_range(rank, E))
+    c2_crumple(ctx, seeds)
+    prim = FlingPrimitives(ctx, range(E))
+    for e in range(E):
+        prim.place_pickers(e)
+    corners = np.stack([ctx.get_positions(e).reshape(-1, 4)[[0, DIM - 1], :3] for e in range(E)]).astype(np.float64)
+    ce = E // 2
+    start_state = (ctx.get_positions(ce), ctx.get_velocities(ce))
+    fdist.gather_rewards(ctx.coverage(), device="cuda")
+    fdist.barrier(); ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    steps = c2_fling_script(ctx, np.arange(E, dtype=np.int32), corners)
+    gpu_ms = ctx.timer_stop()
+    cov = fdist.gather_rewards(ctx.coverage(), device="cuda")
+    fdist.barrier(); ctx.sync(); torch.cuda.synchronize()
+    elapsed = fdist.max_over_ranks(time.perf_counter() - t0, device="cuda")
+    all_steps = float(fdist.gather_rewards([float(steps)], device="cuda").double().sum().item())   # over all ranks
+    form = ctx.last_kernel_form()
+    entry, chk = None, None
+    if rank == 0:
+        fused = form in (fsim.FS_FORM_FUSED_12, fsim.FS_FORM_FUSED_16, fsim.FS_FORM_FUSED_GENERIC, fsim.FS_FORM_FUSED_GRID64)
+        entry = {"name": f"C2 scripted fling, {E} x 64x64 episodes per GPU" + (f" ({E * world} over {world} GPUs)" if world > 1 else ""),
+                 "baseline_config": "SURVEY 8(d) C2 / C3: crumple recipe (tasks.py:177-224) + two-corner fling at simEnv.py:262-275 speeds",
+                 "value": all_steps / elapsed, "unit": "sim steps/s", "episodes_per_gpu": E,
+                 "episode_steps": int(all_steps), "seconds": elapsed, "gpu_ms": gpu_ms,
+                 "phases": "pickers to the corners, grasp, lift to 0.3 at 5e-3/step, +-0.2 at 6e-3/step, lower, release, "
+                           f"{C2_FLING_SETTLE} settle steps; the crumple ({C2_RAISE} + {C2_HOLD} + {C2_SETTLE} steps) is untimed set-up",
+                 "calls": "one fs_movep_batch per leg (picker kernel + solver per step, planned on the host) + one fs_step_list",
+                 "solver": ("fused (AUTO)" if fused else "stream (AUTO)"), "kernel_form": int(form),
+                 "mean_coverage": float(cov.mean().item())}
+        if check:
+            chk = C2Check(ce, start_state, corners[ce], (ctx.get_positions(ce), ctx.get_velocities(ce)))
+    ctx.close()
+    return entry, chk
+
+
 def run_rank(args):
     import torch
 
@@ -448,19 +643,39 @@ def run_rank(args):
                 entry]
         ctx2.close()
 
+    # ---- SURVEY 8(d) C2 / C3 as timed entries: crumple + scripted fling with both pickers, at the headline's batch and at 64
+    c2_checks = []
+    if not args.no_secondary and not args.no_c2:
+        for Ec in (E, 64):
+            entry, chk = c2_leg(fsim, fdist, torch, local_rank, rank, world, Ec, check=not args.no_parity)
+            if rank == 0:
+                entry["ratio_to_crumpled_sheet"] = entry["value"] / (out["configs"][0]["value"] if Ec == E else out["configs"][1]["value"])
+                out["configs"].append(entry)
+                c2_checks.append((len(out["configs"]) - 1, chk))
+        if rank == 0:
+            out["fling_phase_ratio"] = out["configs"][2]["ratio_to_crumpled_sheet"]
+
     if rank == 0:
         # every timed region of the solver is over: now the checkers run (one host core each, side by side), then the
         # CPU baseline (all cores, nothing else running), then the perception and evaluation-loop legs
         for chk in (parity_main, parity_2):
             if chk is not None:
                 chk.start()
+        for _, chk in c2_checks:
+            if chk is not None:
+                chk.start_thread()
         if parity_main is not None:
             out["parity"] = parity_main.result()
             out["parity_checked"] = bool(out["parity"]["bit_exact"])
         if parity_2 is not None:
             out["configs"][1]["parity"] = parity_2.result()
+        for idx, chk in c2_checks:
+            if chk is not None:
+                out["configs"][idx]["parity"] = chk.result()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preroll + args.warmup)
+        if getattr(args, "dropin", None) is not None:
+            out["dropin"] = args.dropin
         if world == 1 and not args.no_secondary:
             out["perception"] = perception_leg(torch.device("cuda", local_rank))
             if not args.no_eval_loop:
@@ -496,9 +711,12 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream
             for k in range(0, n_tasks, n_slots):
                 part = [ftasks.draw_task_parameters() for _ in range(min(n_slots, n_tasks - k))]
                 gen = fsim.FlingSim(n_envs=len(part), device=device_index, solver=0)
-                tasks += ftasks.generate_tasks(gen, part)
+                made = ftasks.generate_tasks(gen, part)
                 gen.close()
-                params += part
+                # the generator rejects a task whose cloth did not come down ("probably an error", tasks.py:226-229 -> None);
+                # like the reference's generation loop, such a task is simply not part of the set
+                tasks += [t for t in made if t is not None]
+                params += [p_ for p_, t in zip(part, made) if t is not None]
             t_gen = time.perf_counter() - t0
             ctx = fsim.FlingSim(n_envs=n_slots, device=device_index, solver=0)
             env = BatchedFlingEnv(ctx, episode_length=actions, device=f"cuda:{device_index}")
@@ -513,6 +731,7 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream
             sides = np.array([p["cloth_size"] for p in params])
             sched = stats["scheduler"]
             ctx.close()
+            n_tasks = len(tasks)
             return {"episodes": n_tasks, "slots": n_slots, "max_actions": actions, "cloth_sides": [int(sides.min()), int(sides.max())],
                     "transforms": len(env.transformations), "render_dim": env.render_dim, "image_dim": env.image_dim,
                     "seconds": dt, "task_generation_seconds": t_gen, "flings": flings, "flings_per_s": flings / dt,
@@ -531,7 +750,8 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream
             out["continuous"] = one(stream_tasks, stream_slots, 1)
         return out
     except Exception as exc:  # the headline number must not depend on this leg
-        return {"error": str(exc)[:300]}
+        import traceback
+        return {"error": str(exc)[:300], "where": traceback.format_exc().strip().splitlines()[-6:]}
 
 
 def main():
@@ -547,6 +767,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed batch")
     ap.add_argument("--no-secondary", action="store_true", help="headline only: no 64-episode figure, no perception leg")
     ap.add_argument("--no-eval-loop", action="store_true", help="skip the evaluation-loop leg (configs[4], ~50 s)")
+    ap.add_argument("--no-c2", action="store_true", help="skip the C2 / C3 crumple + scripted-fling entries")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the pyflex-module drop-in leg (1 and 16 processes)")
     ap.add_argument("--timeout", type=float, default=1800.0,
                     help="seconds after which self-launched ranks (--gpus N without WORLD_SIZE) are stopped: a hung rendezvous ends")
     args = ap.parse_args()
@@ -558,6 +780,14 @@ def main():
         from flingbot_amd.launch import launch_local_ranks
 
         sys.exit(launch_local_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], timeout=args.timeout))
+    if world_env is None and args.gpus == 1 and not args.no_secondary and not args.no_dropin:
+        # the drop-in leg runs FIRST, from this process while it has not touched the GPU: its workers are fresh interpreters
+        # (one pyflex.init each, like the reference's Ray workers) and must not be children of a process that holds the device
+        try:
+            import bench_dropin
+            args.dropin = bench_dropin.measure()
+        except Exception as exc:
+            args.dropin = {"error": str(exc)[:300]}
     if int(world_env or "1") != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}: launch with torch.distributed.run, or leave "
                          f"WORLD_SIZE unset and bench.py starts the ranks itself")

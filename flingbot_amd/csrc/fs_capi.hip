@@ -303,6 +303,16 @@ int fs_lane_guard(fs_ctx *ctx, int env) {
     }
     return FS_OK;
 }
+// Stepping on the service lane while a chunk is in flight is refused outright: a launch sequence rebuilds the context's ONE
+// slot table / sweep table and reuses its chain streams, fork / join events and loop scratch, which the chunk still running
+// on the main stream reads -- whichever episodes are listed.  (The services the lane exists for -- reductions, observations,
+// resets -- never step.)
+int fs_step_guard(fs_ctx *ctx, const char *who) {
+    if (!ctx || !ctx->on_svc || ctx->tickets_busy == 0) return FS_OK;
+    fs_set_error(std::string(who) + ": the simulation cannot be stepped on the service lane while an fs_advance chunk is in flight "
+                                    "(fs_advance_end / fs_service_lane(ctx, 0) first)");
+    return FS_ERR_STATE;
+}
 #define LANE_GUARD(ctx, env)                                   \
     do {                                                       \
         const int guard_rc = fs_lane_guard((ctx), (env));      \
@@ -547,6 +557,7 @@ extern "C" int fs_set_scene_prebuilt(fs_ctx *ctx, int env, fs_host_scene *scene)
 extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
     if (!ctx) { fs_set_error("null context"); return FS_ERR_ARG; }
     if (n_steps < 0) { fs_set_error("n_steps < 0"); return FS_ERR_ARG; }
+    if (const int guard_rc = fs_step_guard(ctx, "fs_step")) return guard_rc;
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<int> ids;
     if (env == -1) {
@@ -563,6 +574,7 @@ extern "C" int fs_step(fs_ctx *ctx, int env, int n_steps) {
 extern "C" int fs_step_list(fs_ctx *ctx, int n, const int *envs, int n_steps) {
     if (!ctx || !envs || n <= 0) { fs_set_error("fs_step_list: bad arguments"); return FS_ERR_ARG; }
     if (n_steps < 0) { fs_set_error("n_steps < 0"); return FS_ERR_ARG; }
+    if (const int guard_rc = fs_step_guard(ctx, "fs_step_list")) return guard_rc;
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<int> ids(envs, envs + n);
     for (int id : ids)
@@ -601,6 +613,7 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
 
 extern "C" int fs_step_timed(fs_ctx *ctx, int env, int n_steps, float *elapsed_ms) {
     if (!ctx || !elapsed_ms) { fs_set_error("null argument"); return FS_ERR_ARG; }
+    if (const int guard_rc = fs_step_guard(ctx, "fs_step_timed")) return guard_rc;
     HIP_TRY(hipSetDevice(ctx->device));
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));

@@ -27,20 +27,16 @@ __device__ __forceinline__ float fs_dot3(float ax, float ay, float az, float bx,
     return FS_FMA(az, bz, FS_FMA(ay, by, ax * bx));
 }
 
-// Reciprocal square root for every length inside the constraint sweeps: integer seed + three Newton steps
-// y <- y * fma(-(x/2 * y), y, 3/2), a fixed sequence of IEEE fp32 operations (max error ~2 ulp).  Being a pure function
-// of mul / fma it gives the same bits on the CPU oracle and on the GPU, and replaces the ~30 instruction
-// correctly-rounded sqrt + divide sequences (two quarter-rate ops among them) by 12 full-rate VALU ops.
+// Reciprocal square root for every length inside the constraint sweeps: the hardware's v_rsq_f32 (1 ulp) on
+// max(x, FLT_MIN) -- two instructions where rounds 1-3 spelled an integer seed + three Newton steps out in twelve (the
+// reciprocal root was nearly half of the arithmetic of a spring; EXPERIMENTS R4.1: -7 ... -9 % on the fused kernels).
+// The clamp keeps every result finite: a zero or denormal squared length gives 2^63 and the product l2 * rsqrt(l2) -- the
+// length -- stays 0 or tiny, so the `length > 0` tests below work as they read.  The instruction is a pure function of
+// its input bits, and the CPU oracle reproduces it from a table of this chip's 2^24 (exponent parity, mantissa) results
+// (oracle/v_rsq_f32_gfx950.npz, dumped through fs_eval_rsqrt; the GPU suite re-reads the whole table on the box it runs
+// on), so HIP and oracle still agree bit for bit.
 __device__ __forceinline__ float fs_rsqrt(float x) {
-#ifdef FS_HW_RSQ  // measurement build only (EXPERIMENTS R4.1): v_rsq_f32, 1 ulp, NOT bit-reproducible on the CPU
-    return __builtin_amdgcn_rsqf(x);
-#endif
-    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(x) >> 1));
-    const float xh = 0.5f * x;
-    y = y * FS_FMA(-(xh * y), y, 1.5f);
-    y = y * FS_FMA(-(xh * y), y, 1.5f);
-    y = y * FS_FMA(-(xh * y), y, 1.5f);
-    return y;
+    return __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 1.17549435e-38f));
 }
 
 // friction scale on a tangential displacement of length tl = tl2 * inv_tl under penetration pen

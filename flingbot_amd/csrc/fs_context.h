@@ -91,6 +91,7 @@ struct FsAdvTicket {
     int n = 0;
     std::vector<int> listed;  // the call's episodes (fs_lane_guard)
     std::vector<int> w_arg, w_env, w_kind, w_limit, w_start;  // the call's waiters: index in the caller's arrays, episode, ...
+    std::vector<int> w_gen;                                    // ... and the generation of the loop the entry belongs to (fs_ctx::wait_gen)
     std::vector<char> w_skip;                                  // loop budget already used up when the call was made
     size_t n_seq = 0;
     double wall_begin_ms = 0.0;
@@ -151,6 +152,8 @@ struct fs_ctx {
     FsWaitDev *d_wait = nullptr;      // [n_envs]
     FsAdvTicket tickets[FS_ADV_TICKETS];
     std::vector<char> wait_over;  // [n_envs] host's knowledge: the episode's wait / step loop has ended (fs_advance_end said so)
+    std::vector<int> wait_gen;    // [n_envs] counts the wait / step loops an episode has started (start >= 0): a ticket's report
+                                  // only ends the loop it was queued for, never a newer one a later ticket has started
                                   // and no new loop was started since -- its entries in chunks queued ahead retire unstepped
     int tickets_busy = 0;
     double *d_coverage = nullptr;
@@ -172,6 +175,7 @@ void *fs_svc_scratch(fs_ctx *ctx, size_t bytes);
 // The service lane's contract, checked: FS_ERR_STATE when a call on the service lane is about to rewrite an episode that is
 // part of an fs_advance chunk still in flight (nothing waits for the chunk there, so the write would race with its launches).
 int fs_lane_guard(fs_ctx *ctx, int env);
+int fs_step_guard(fs_ctx *ctx, const char *who);  // FS_ERR_STATE for a stepping call on the service lane while a chunk is in flight
 void *fs_pool_take(fs_ctx *ctx, size_t bytes, size_t *got_bytes);
 void fs_pool_give(fs_ctx *ctx, void *ptr, size_t bytes);
 void *fs_loop_scratch(fs_ctx *ctx, size_t bytes);

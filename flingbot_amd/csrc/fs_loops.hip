@@ -63,6 +63,7 @@ extern "C" int fs_wait_until_stable(fs_ctx *ctx, int n, const int *envs, int max
         fs_set_error("fs_wait_until_stable: bad arguments");
         return FS_ERR_ARG;
     }
+    if (const int guard_rc = fs_step_guard(ctx, "fs_wait_until_stable")) return guard_rc;
     std::vector<int> ids(envs, envs + n);
     for (int e : ids)
         if (e < 0 || e >= ctx->n_envs || !ctx->envs[e].has_scene) {

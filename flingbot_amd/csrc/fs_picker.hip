@@ -279,6 +279,7 @@ static int movep_batch_impl(fs_ctx *ctx, int n, const int *envs, const double *t
                             int limit, int min_steps, double eps, int *iterations_out, bool f32_targets) {
     if (ctx) ctx->last_movep_steps = 0;  // an early error return must not leave the previous call's count behind
     if (!ctx || n <= 0 || !envs || !targets || !grasp) { fs_set_error("fs_movep: bad arguments"); return FS_ERR_ARG; }
+    if (const int guard_rc = fs_step_guard(ctx, "fs_movep")) return guard_rc;
     HIP_TRY(hipSetDevice(ctx->device));
     int S = -1;
     std::vector<Plan> plans(n);
@@ -525,7 +526,22 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
     }
     const size_t mover_seq = n_seq;  // launch sequences that still have a mover
     // waiters: a loop whose steps are known to be used up is answered here; the others take part for up to `chunk` sequences
-    T.w_arg.clear(); T.w_env.clear(); T.w_kind.clear(); T.w_limit.clear(); T.w_start.clear();
+    T.w_arg.clear(); T.w_env.clear(); T.w_kind.clear(); T.w_limit.clear(); T.w_start.clear(); T.w_gen.clear();
+    if (ctx->wait_over.size() != (size_t)ctx->n_envs) ctx->wait_over.assign((size_t)ctx->n_envs, 0);
+    if (ctx->wait_gen.size() != (size_t)ctx->n_envs) ctx->wait_gen.assign((size_t)ctx->n_envs, 0);
+    // what this call changes on the host before its launches are queued -- shape mirrors, loop flags -- is put back if queueing
+    // fails, so that an error return leaves the host describing what the device really executed
+    struct Undo { int env; char over; int gen; bool shapes; FsShapesDev sh; };
+    std::vector<Undo> undo;
+    const long long movep_steps_planned = ctx->last_movep_steps;
+    auto rollback = [&]() {
+        for (const Undo &u : undo) {
+            ctx->wait_over[u.env] = u.over; ctx->wait_gen[u.env] = u.gen;
+            if (u.shapes) ctx->envs[u.env].shapes = u.sh;
+        }
+        ctx->last_movep_steps = 0;
+    };
+    (void)movep_steps_planned;
     for (int q = 0; q < nw_all; ++q) {
         const int a = waiters[q];
         if (start[a] >= 0 && limit[a] - start[a] <= 0) {  // wait_until_stable returns False, plain steps are done
@@ -538,8 +554,12 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
         status_out[a] = -1; progress_out[a] = start[a]; steps_out[a] = 0;
         T.w_arg.push_back(a); T.w_env.push_back(envs[a]); T.w_kind.push_back(kind[a]); T.w_limit.push_back(limit[a]);
         T.w_start.push_back(start[a]);
-        if (ctx->wait_over.size() != (size_t)ctx->n_envs) ctx->wait_over.assign((size_t)ctx->n_envs, 0);
-        if (start[a] >= 0) ctx->wait_over[envs[a]] = 0;  // a new loop
+        if (start[a] >= 0) {  // a new loop
+            undo.push_back(Undo{envs[a], ctx->wait_over[envs[a]], ctx->wait_gen[envs[a]], false, FsShapesDev{}});
+            ctx->wait_over[envs[a]] = 0;
+            ctx->wait_gen[envs[a]] += 1;
+        }
+        T.w_gen.push_back(ctx->wait_gen[envs[a]]);
     }
     const int nw = (int)T.w_arg.size();
     T.n = n; T.n_seq = n_seq;
@@ -551,6 +571,7 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
         FsEnv &e = ctx->envs[envs[movers[q]]];
         const auto &cm = plans[q].cmds;
         if (cm.empty()) continue;
+        undo.push_back(Undo{envs[movers[q]], ctx->wait_over[envs[movers[q]]], ctx->wait_gen[envs[movers[q]]], true, e.shapes});
         for (int k = 0; k < S; ++k) {
             const float r = e.shapes.pos[k].w;
             const float *pv = cm.size() >= 2 ? cm[cm.size() - 2].new_pos[k] : &e.shapes.pos[k].x;
@@ -561,8 +582,8 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
     if (n_seq == 0) {  // nothing to launch: an empty ticket keeps the begin / end protocol uniform
         T.busy = true; ctx->tickets_busy++;
         int rc0 = ticket_buffers(ctx, T, 16);
-        if (rc0 != FS_OK) { T.busy = false; ctx->tickets_busy--; return rc0; }
-        HIP_TRY(hipEventRecord(T.done, ctx->stream));
+        if (rc0 != FS_OK) { T.busy = false; ctx->tickets_busy--; rollback(); return rc0; }
+        if (!fs_hip_ok(hipEventRecord(T.done, ctx->stream), "fs_advance event")) { T.busy = false; ctx->tickets_busy--; rollback(); return FS_ERR_HIP; }
         return tk;
     }
     // device tables, ONE upload from the ticket's pinned image.  Per launch sequence s a row of the launch list:
@@ -576,7 +597,7 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
     const size_t o_cmds = carve(sizeof(FsPickerCmd) * n_seq * width);
     const size_t o_rows = carve(sizeof(int) * n_seq * W);
     int rc = ticket_buffers(ctx, T, off);
-    if (rc != FS_OK) return rc;
+    if (rc != FS_OK) { rollback(); return rc; }
     char *blob = (char *)T.h_tab;
     memset(blob, 0, off);
     int **h_picked = (int **)(blob + o_picked);
@@ -604,7 +625,7 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
     }
     char *dev = (char *)T.d_tab;
     T.busy = true; ctx->tickets_busy++;
-    auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); T.busy = false; ctx->tickets_busy--; return code; };
+    auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); T.busy = false; ctx->tickets_busy--; rollback(); return code; };
     if (!fs_hip_ok(hipMemcpyAsync(dev, blob, off, hipMemcpyHostToDevice, ctx->stream), "fs_advance upload")) return fail(FS_ERR_HIP);
     if (!ctx->adv_ev0) {
         if (!fs_hip_ok(hipEventCreate(&ctx->adv_ev0), "event") || !fs_hip_ok(hipEventCreate(&ctx->adv_ev1), "event")) return fail(FS_ERR_HIP);
@@ -681,7 +702,9 @@ static int advance_end(fs_ctx *ctx, int ticket, int *progress_out, int *status_o
         if (steps_out) steps_out[a] = T.w_start[q] >= 0 ? w.steps - T.w_start[q] : -1;
         const int st = w.stable ? 1 : ((w.over || w.steps >= T.w_limit[q]) ? (T.w_kind[q] == 2 ? 1 : 2) : 0);
         if (status_out) status_out[a] = st;
-        if (st != 0) ctx->wait_over[T.w_env[q]] = 1;  // (over on the device, or its next check finds the steps used up)
+        // (over on the device, or its next check finds the steps used up) -- but only the loop this entry was queued for: a
+        // later ticket may already have started the episode's NEXT loop, which this report must not end on the host
+        if (st != 0 && q < (int)T.w_gen.size() && T.w_gen[q] == ctx->wait_gen[T.w_env[q]]) ctx->wait_over[T.w_env[q]] = 1;
     }
     ctx->adv_wall_ms += T.wall_begin_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return FS_OK;

@@ -278,3 +278,26 @@ int fs_step_fused(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const i
     HIP_TRY(hipGetLastError());
     return FS_OK;
 }
+
+// white box: the solver's reciprocal square root (fs_constraints.h fs_rsqrt) evaluated on the device for n host values
+__global__ void fs_k_eval_rsqrt(const float *__restrict__ x, float *__restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fs_rsqrt(x[i]);
+}
+extern "C" int fs_eval_rsqrt(fs_ctx *ctx, const float *x, float *y, int n) {
+    if (!ctx || !x || !y || n < 0) return FS_ERR_ARG;
+    if (n == 0) return FS_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, size_t(8) * n));
+    int rc = FS_OK;
+    if (hipMemcpy(d, x, size_t(4) * n, hipMemcpyHostToDevice) != hipSuccess) rc = FS_ERR_HIP;
+    if (rc == FS_OK) {
+        fs_k_eval_rsqrt<<<(n + 255) / 256, 256>>>(d, d + n, n);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(y, d + n, size_t(4) * n, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = FS_ERR_HIP;
+    }
+    (void)hipFree(d);
+    if (rc != FS_OK) fs_set_error("fs_eval_rsqrt: HIP error");
+    return rc;
+}

@@ -102,7 +102,7 @@ class BatchedFlingEnv:
         depth = obs[:, 3].cpu().numpy() if envs else None
         for k, e in enumerate(envs):
             self.pretransform_depth[e] = depth[k]
-            self.pretransform_depth_dev[e] = obs[k, 3]
+            self.pretransform_depth_dev[e] = obs[k, 3].clone()  # (a view would keep the whole batch tensor alive per slot)
             self.adaptive_scale_factors[e] = self._adaptive_factors(bbox[k])
         return obs
 

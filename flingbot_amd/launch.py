@@ -44,19 +44,25 @@ def launch_local_ranks(n_ranks, script, argv, env=None, timeout=None, master_add
     src = os.environ if env is None else env
     chosen = master_port or src.get("MASTER_PORT")
     rc = 0
+    deadline = None if timeout is None else time.monotonic() + timeout   # for the whole launch, not per attempt
     for attempt in range(1 if chosen else max(1, attempts)):
         port = int(chosen) if chosen else free_port(master_addr)
-        rc = _launch_once(n_ranks, script, argv, src, timeout, master_addr, port)
-        # a rendezvous that lost its port dies with EADDRINUSE in rank 0 and the port is still somebody else's afterwards;
-        # any other failure is the script's own and is not repeated
+        left = None if deadline is None else max(0.0, deadline - time.monotonic())
+        rc = _launch_once(n_ranks, script, argv, src, left, master_addr, port)
+        # a rendezvous that lost its port dies with EADDRINUSE in rank 0 and somebody else is still LISTENING on the port
+        # afterwards; any other failure is the script's own and is not repeated
         if rc == 0 or rc == 124 or chosen or not _port_in_use(master_addr, port):
             break
     return rc
 
 
 def _port_in_use(host, port):
+    """True when somebody is listening on (host, port).  SO_REUSEADDR makes the probe ignore TIME_WAIT leftovers -- which our
+    own rank 0 leaves behind whenever it dies after the rendezvous, and which must not turn a failure of the script into
+    "the port was stolen, launch everything again"."""
     s = socket.socket()
     try:
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         s.bind((host, port))
         return False
     except OSError:

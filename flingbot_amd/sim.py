@@ -132,6 +132,7 @@ def load_library(build_if_missing=True):
         "fs_value_net_work_bytes": (C.c_size_t, [ci, ci]),
         "fs_value_net_pack": (ci, [ci, fp, fp, fp, fp, fp, fp, fp, fp]),
         "fs_value_net_forward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
+        "fs_eval_rsqrt": (ci, [vp, fp, fp, ci]),
         "fs_timer_start": (ci, [vp]),
         "fs_timer_stop": (ci, [vp, fp]),
         "fs_host_scene_build": (vp, [fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
@@ -570,6 +571,13 @@ class FlingSim:
                                            C.c_void_p(mask.data_ptr()) if want_mask else None, _ip(bbox),
                                            C.c_void_p(work.data_ptr())))
         return (obs, bbox, mask) if want_mask else (obs, bbox)
+
+    def eval_rsqrt(self, x):
+        """The constraint kernels' reciprocal square root on the device for a float32 array (white box: fs_eval_rsqrt)."""
+        x = np.ascontiguousarray(np.asarray(x, np.float32).ravel())
+        y = np.empty_like(x)
+        self._ck(self.lib.fs_eval_rsqrt(self.h, _fp(x), _fp(y), x.size))
+        return y
 
     def get_last_neighbors(self, env=0):
         n = self.n_particles(env)

@@ -149,6 +149,9 @@ int fs_last_kernel_form(const fs_ctx *ctx);
    number of chains of the most recent streaming launch (white box for the tests). */
 int fs_set_stream_groups(fs_ctx *ctx, int groups);
 int fs_last_stream_groups(const fs_ctx *ctx);
+/* white-box access for tests: y[i] = the reciprocal square root the constraint kernels use (csrc/fs_constraints.h fs_rsqrt),
+   evaluated on the device for n host values -- what pins the checker's restatement of it to this chip */
+int fs_eval_rsqrt(fs_ctx *ctx, const float *x, float *y, int n);
 /* device pointer of env's position array (float4[N]) for zero-copy consumers (torch) */
 void *fs_device_positions(fs_ctx *ctx, int env);
 
@@ -202,7 +205,10 @@ int fs_advance_in_flight(const fs_ctx *ctx);
    episodes (or ones whose wait loop in the chunk has already ended).  Leaving the lane orders the main stream behind it.
    The calls that REWRITE an episode (fs_set_scene*, fs_set_positions / velocities / phases / params / shape_states /
    particles, fs_add_sphere, fs_clear_shapes, fs_picker_reset) check the contract: FS_ERR_STATE for an episode that an open
-   ticket still steps or moves (an entry that continues a wait loop fs_advance_end has already reported over does not count). */
+   ticket still steps or moves (an entry that continues a wait loop fs_advance_end has already reported over does not count).
+   The calls that STEP the simulation (fs_step, fs_step_list, fs_step_timed, fs_wait_until_stable, fs_movep*, fs_advance*)
+   return FS_ERR_STATE on the lane while any ticket is open, whichever episodes they list: a launch sequence uses per-context
+   tables and streams the chunk in flight is still reading. */
 int fs_service_lane(fs_ctx *ctx, int on);
 /* fs_advance's stopwatch since fs_create: out5 = calls, launch sequences, wall ms inside the calls, device ms between a
    call's first and last launch, wall ms the calls spent before their first launch (planning, tables, upload) */

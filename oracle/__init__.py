@@ -3,4 +3,4 @@
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package.
 The product (``flingbot_amd``) never does.
 """
-from .flex import OracleSim, build_oracle, oracle_lib_path  # noqa: F401
+from .flex import OracleSim, build_oracle, oracle_lib_path, eval_rsqrt, rsqrt_table  # noqa: F401

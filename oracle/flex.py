@@ -31,7 +31,7 @@ def oracle_lib_path():
 
 # bounding builds of the same step (oracle/Makefile): plain IEEE arithmetic, and each arithmetic choice alone.  Tests use
 # them to measure how far the default oracle's spelled-out approximations move a step; they are never the parity oracle.
-VARIANTS = ("exact", "exact_rsqrt", "nofma")
+VARIANTS = ("exact", "exact_rsqrt", "nofma", "newton")
 # sensitivity builds of the model-level [I] choices (flex_oracle.c "MODEL switches"): one alternative reading each, built on
 # first use (liboracle_alt_<name>.so).  They measure how far another reading of the closed solver would move a trajectory
 # (PARITY.md); they are never the parity oracle either.
@@ -56,6 +56,26 @@ def build_oracle(force=False):
 
 
 _libs = {}
+_rsq_table = None
+
+
+def rsqrt_table():
+    """The chip's v_rsq_f32 as data: 2^24 two-bit fields (ulps from float32(1 / sqrt(float64(x))) + 2), four per byte, dumped
+    on an MI355X by tests/golden/make_rsq_table.py.  Loaded once; every oracle library points at this buffer."""
+    global _rsq_table
+    if _rsq_table is None:
+        with np.load(os.path.join(_HERE, "v_rsq_f32_gfx950.npz")) as z:
+            _rsq_table = np.ascontiguousarray(z["delta2bit"], np.uint8)
+        assert _rsq_table.size == 1 << 22
+    return _rsq_table
+
+
+def eval_rsqrt(x):
+    """The oracle's reciprocal square root (= the product's: v_rsq_f32(max(x, FLT_MIN)) of gfx950) for a float32 array."""
+    x = np.ascontiguousarray(np.asarray(x, np.float32).ravel())
+    y = np.empty_like(x)
+    assert _load().orc_eval_rsqrt(_fp(x), _fp(y), x.size) == 0
+    return y
 
 
 def _load(variant=None):
@@ -70,7 +90,10 @@ def _load(variant=None):
     elif not os.path.exists(path):
         build_oracle()
     lib = C.CDLL(path)
+    lib.orc_set_rsqrt_table.argtypes = [C.c_void_p]
+    lib.orc_set_rsqrt_table(rsqrt_table().ctypes.data)
     fp, ip, vp = C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p
+    lib.orc_eval_rsqrt.argtypes = [fp, fp, C.c_int]
     lib.orc_create.restype = vp
     lib.orc_destroy.argtypes = [vp]
     lib.orc_set_scene.argtypes = [vp, fp, fp, C.c_int, ip, C.c_int, ip, C.c_int, ip, C.c_int, ip, C.c_int]

@@ -31,6 +31,12 @@ int orc_set_scene(orc_sim *s, const float *scene_params /*[19]*/, const float *v
                   const int *stretch, int n_stretch_ints, const int *bend, int n_bend_ints, const int *shear,
                   int n_shear_ints, const int *faces, int n_face_ints);
 
+/* The reciprocal square root of the constraint sweeps is the product's: gfx950's v_rsq_f32 on max(x, FLT_MIN), carried as a
+   table of the chip's results (oracle/v_rsq_f32_gfx950.npz `delta2bit`, 4 MiB: see flex_oracle.c).  Process-global; must be
+   set before orc_step (which returns -2 without it).  orc_eval_rsqrt: y[i] = that function of x[i]. */
+void orc_set_rsqrt_table(const unsigned char *packed_2bit);
+int orc_eval_rsqrt(const float *x, float *y, int n);
+
 /* pyflex.step xN (pyflex.cpp:213-222 -> main.cpp UpdateFrame:2120) */
 int orc_step(orc_sim *s, int n_steps);
 

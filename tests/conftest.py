@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
@@ -27,9 +29,4 @@ def gpu_required():
         pytest.fail("this test is marked gpu but no HIP device is visible")
 
 
-def cloth_params(dimx, dimz, pos=(0.0, -0.1, 0.0), stiff=(0.9, 0.9, 0.9), mass=0.5, flip=0):
-    """scene_params[19] in the layout of flex_utils.py:332-342."""
-    import numpy as np
-
-    return np.array([pos[0], pos[1], pos[2], dimx, dimz, stiff[0], stiff[1], stiff[2], 2,
-                     0, 2, 0, np.pi / 2, -np.pi / 2, 0, 720, 720, mass, flip], dtype=np.float64)
+from scenarios import cloth_params  # noqa: E402,F401  (re-exported: the tests import it from here)

@@ -1,0 +1,147 @@
+"""PARITY.md's sensitivity table: how far each alternative reading of the closed solver moves a trajectory.
+
+    python tests/parity_table.py [--quick] [--jobs 8] > PARITY_table.md
+
+The solver step restates closed-source NVIDIA FleX; every inferred choice [I] of oracle/flex_oracle.c has a compile switch
+that replaces it by its most plausible alternative (liboracle_alt_<name>.so), and the two arithmetic choices have their
+bounding builds (liboracle_exact*.so).  This script runs the three canonical workloads of SURVEY.md 8(d) -- C1 (32 x 32
+flat, 200 steps), C2 (64 x 64 crumple), the scripted two-corner fling (64 x 64) -- on THE oracle and on every alternative,
+and prints the maximum position divergence relative to the scene extent (max |x|, at least 1 m: north_star's "1e-4 rel")
+at frames 1 / 10 / 100 / last, the divergence of the coverage reward at the end (the number the pipeline consumes), and the
+longest particle-contact candidate list seen.  Test infrastructure (imports oracle/).
+"""
+import argparse
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+FRAMES = (1, 10, 100)
+
+ROWS = [  # (variant, what it changes)
+    ("exact", "arithmetic: IEEE sqrt / divide instead of the spelled-out reciprocal root, unfused multiply-adds (noise floor)"),
+    ("alt_friction_post", "friction once per substep after the position solve, Coulomb bound = accumulated normal correction"),
+    ("alt_neighbors_by_distance", "candidate lists above 96 keep the nearest instead of the smallest ids"),
+    ("alt_shape_end_pose", "kinematic spheres at their end-of-frame pose in every substep"),
+    ("alt_sleep_velocity_only", "sleeping particle: velocity zeroed, position still updated"),
+    ("alt_sleep_at_predict", "sleep applied at predict (x* = x), nothing at finalize"),
+    ("alt_no_sleep", "sleepThreshold ignored"),
+    ("alt_apply_per_type", "applyDeltas after each constraint type (springs, particle contacts, shapes)"),
+    ("alt_damping_mult", "damping as v = (v + h g)(1 - h damping)"),
+    ("alt_stiffness_iter", "stiffness made iteration-count independent: k' = 1 - (1 - k)^(1/30)"),
+]
+
+
+def _run(job):
+    name, variant, quick = job
+    import scenarios as sc
+    from oracle import OracleSim
+    from oracle.coverage import covered_area
+
+    sim = OracleSim(variant)
+    rec = sc.Recorder(every=1 << 30, also=FRAMES)
+    if name == "c1":
+        sc.scenario_c1(sim, record=rec)
+    elif name == "c2":
+        if quick:
+            sc.scenario_c2(sim, seed=0, dim=32, raise_steps=60, hold_steps=20, settle_steps=40, record=rec)
+        else:
+            sc.scenario_c2(sim, seed=0, record=rec)
+    else:
+        sc.scenario_c2_fling(sim, dim=32 if quick else 64, settle_steps=60 if quick else 300, record=rec)
+    rec.close()
+    states = list(zip(rec.pos, rec.vel, rec.shapes)) if variant is None else None
+    return name, variant, rec.frames, rec.pos, covered_area(sim.get_positions()), sim.max_neighbor_list(), states
+
+
+def _scene(name, quick):
+    import scenarios as sc
+    if name == "c1":
+        return sc.survey_params(32)
+    if name == "c2":
+        return sc.survey_params(32 if quick else 64)
+    d = 32 if quick else 64
+    return sc.cloth_params(d, d, pos=(0.0, -0.2, 0.0))
+
+
+def _local(job):
+    """One plain pyflex.step() from the DEFAULT oracle's recorded states, on the default and on `variant`: the local (one-step)
+    effect of the alternative, free of the chaotic growth a trajectory comparison contains."""
+    name, variant, quick, states = job
+    from oracle import OracleSim
+
+    out = []
+    for pos, vel, shapes in states:
+        ends = []
+        for var in (None, variant):
+            o = OracleSim(var)
+            o.set_scene(_scene(name, quick))
+            for row in shapes.reshape(-1, 14):
+                o.add_sphere(0.02, row[:3], [1, 0, 0, 0])
+            if shapes.size:
+                o.set_shape_states(shapes)
+            o.set_positions(pos)
+            o.set_velocities(vel)
+            o.step()
+            ends.append(o.get_positions().reshape(-1, 4)[:, :3])
+        out.append(float(np.abs(ends[0] - ends[1]).max() / max(1.0, float(np.abs(ends[0]).max()))))
+    return name, variant, out
+
+
+def table(quick=False, jobs=8, scenarios=("c1", "c2", "fling")):
+    variants = [None] + [v for v, _ in ROWS]
+    work = [(s, v, quick) for s in scenarios for v in variants]
+    with Pool(min(jobs, len(work))) as pool:
+        res = pool.map(_run, work, chunksize=1)
+    by = {(s, v): (fr, pos, cov, ml) for s, v, fr, pos, cov, ml, _ in res}
+    states = {s: st for s, v, _, _, _, _, st in res if v is None}
+    with Pool(min(jobs, len(work))) as pool:
+        loc = {(s, v): d for s, v, d in pool.map(_local, [(s, v, quick, states[s]) for s in scenarios for v in variants[1:]],
+                                                  chunksize=1)}
+    out = {}
+    for s in scenarios:
+        fr0, pos0, cov0, ml0 = by[(s, None)]
+        for v in variants[1:]:
+            fr, pos, cov, ml = by[(s, v)]
+            assert fr == fr0, (s, v, fr, fr0)
+            div = []
+            for a, b in zip(pos0, pos):
+                a3, b3 = a.reshape(-1, 4)[:, :3], b.reshape(-1, 4)[:, :3]
+                div.append(float(np.abs(a3 - b3).max() / max(1.0, float(np.abs(a3).max()))))
+            out[(s, v)] = {"frames": fr, "divergence": div, "local": loc[(s, v)], "coverage": (cov0, cov), "max_list": (ml0, ml)}
+    return out
+
+
+def render(out, scenarios=("c1", "c2", "fling")):
+    names = {"c1": "C1 (32x32 flat)", "c2": "C2 crumple (64x64)", "fling": "scripted fling (64x64)"}
+    lines = []
+    for s in scenarios:
+        fr = out[(s, ROWS[0][0])]["frames"]
+        lines.append(f"\n**{names[s]}** -- frames {', '.join(str(f) for f in fr)} (last = end of the scenario); longest candidate "
+                     f"list of the default oracle: {out[(s, ROWS[0][0])]['max_list'][0]} (cap 96)\n")
+        lines.append("| alternative | " + " | ".join(f"trajectory @{f}" for f in fr) + " | " +
+                     " | ".join(f"one step from @{f}" for f in fr) + " | coverage at the end (default -> alternative) |")
+        lines.append("|---|" + "---|" * (2 * len(fr) + 1))
+        fmt = lambda d: f"{d:.1e}" if d else "0"  # noqa: E731
+        for v, what in ROWS:
+            r = out[(s, v)]
+            c0, c1 = r["coverage"]
+            lines.append(f"| `{v}` | " + " | ".join(fmt(d) for d in r["divergence"]) + " | " + " | ".join(fmt(d) for d in r["local"]) +
+                         f" | {c0:.4f} -> {c1:.4f} ({(c1 - c0) / max(c0, 1e-12) * 100:+.1f} %) |")
+    lines.append("\n| alternative | what it replaces |\n|---|---|")
+    for v, what in ROWS:
+        lines.append(f"| `{v}` | {what} |")
+    return "\n".join(lines)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="32 x 32 cloths, shorter phases (what the CPU test runs)")
+    ap.add_argument("--jobs", type=int, default=8)
+    a = ap.parse_args()
+    print(render(table(a.quick, a.jobs)))

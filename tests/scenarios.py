@@ -10,7 +10,12 @@ Picker._get_pos/_set_pos/step and environment/simEnv.py:739-769 movep): a kinema
 """
 import numpy as np
 
-from conftest import cloth_params  # noqa: F401
+
+def cloth_params(dimx, dimz, pos=(0.0, -0.1, 0.0), stiff=(0.9, 0.9, 0.9), mass=0.5, flip=0):
+    """scene_params[19] in the layout of flex_utils.py:332-342.  (Lives here, not in conftest.py, so that this module needs
+    numpy only: tests/golden/capture_pyflex.py imports it on a machine that has PyFleX and no pytest.)"""
+    return np.array([pos[0], pos[1], pos[2], dimx, dimz, stiff[0], stiff[1], stiff[2], 2,
+                     0, 2, 0, np.pi / 2, -np.pi / 2, 0, 720, 720, mass, flip], dtype=np.float64)
 
 
 def flat_positions(dimx, dimz, y=0.00625 * 2, inv_mass=None, spacing=0.00625):
@@ -164,3 +169,143 @@ def scenario_fling(sim, dimx=32, dimz=32, lift=0.25, fling_dist=0.15, settle_ste
         if record is not None:
             record(sim)
     return pick
+
+
+# ---------------------------------------------------------------- SURVEY.md 8(d) canonical workloads C1 / C2 / scripted fling
+# The same three recipes drive the parity tests, PARITY.md's sensitivity table (tests/parity_table.py), bench.py's C2 entry
+# and -- on a machine with real PyFleX -- tests/golden/capture_pyflex.py, so a recorded PyFleX trajectory can be replayed
+# here input for input.
+
+
+def survey_params(dim):
+    """scene_params = [0,1,0, dim,dim, .9,.9,.9, 2, 0,2,0, pi/2,-pi/2,0, 720,720, 0.5, 0]."""
+    return cloth_params(dim, dim, pos=(0.0, 1.0, 0.0))
+
+
+def set_to_flatten_positions(dimx, dimz, cloth_particle_radius=0.00625):
+    """The array flex_utils.set_to_flatten (flex_utils.py:398-415) hands to pyflex.set_positions, expression by
+    expression: linspace over dim * radius (so the pitch is dim / (dim - 1) * radius), y = radius, w = 1, then the
+    mean of x, y, z subtracted -- which puts the sheet at y = 0 (to 1e-16), inside the ground's collision distance."""
+    px = np.linspace(0, dimx * cloth_particle_radius, dimx)
+    py = np.linspace(0, dimz * cloth_particle_radius, dimz)
+    xx, yy = np.meshgrid(px, py)
+    new_pos = np.empty(shape=(dimx * dimz, 4), dtype=np.float64)
+    new_pos[:, 0] = xx.flatten()
+    new_pos[:, 1] = cloth_particle_radius
+    new_pos[:, 2] = yy.flatten()
+    new_pos[:, 3] = 1.
+    new_pos[:, :3] -= np.mean(new_pos[:, :3], axis=0)
+    return new_pos
+
+
+def canonical_flat(sim, dim):
+    """flex_utils.set_scene (set_scene + its one step, flex_utils.py:343-354) followed by set_to_flatten: where every
+    generated task starts (tasks.py:160-174)."""
+    sim.set_scene(survey_params(dim))
+    sim.step()
+    sim.set_positions(set_to_flatten_positions(dim, dim).flatten())
+
+
+def scenario_c1(sim, steps=200, record=None):
+    """C1 = BASELINE.json configs[0]: 32 x 32, flattened, 200 pyflex.step() without rendering."""
+    canonical_flat(sim, 32)
+    for _ in range(steps):
+        sim.step()
+        if record is not None:
+            record(sim)
+
+
+def scenario_c2(sim, seed=0, dim=64, raise_steps=200, hold_steps=100, settle_steps=150, record=None):
+    """C2 = the deterministic "hard task" crumple (mirror of tasks.py:177-224): flattened sheet, centre_object's step, pin
+    particle seed % N, raise it to height 0.5 + u over 200 steps exactly like the generator's loop (position rewritten and
+    velocity zeroed before every step), hold (fixed count instead of the generator's stability test, so that two solvers
+    take the same number of steps), release, settle."""
+    n = dim * dim
+    canonical_flat(sim, dim)
+    pos = sim.get_positions().reshape(-1, 4).copy()
+    pos[:, [0, 2]] -= np.mean(pos[:, [0, 2]], axis=0, keepdims=True)       # center_object (flex_utils.py:310-314)
+    sim.set_positions(pos.ravel())
+    sim.step()
+    if record is not None:
+        record(sim)
+    k = int(seed) % n
+    height = float(np.random.RandomState(seed).random_sample(1)[0]) * 1.0 + 0.5
+    cur = sim.get_positions().copy()
+    w0 = cur[4 * k + 3]
+    cur[4 * k + 3] = 0
+    sim.set_positions(cur)
+    pick = cur[4 * k: 4 * k + 3].copy()
+    init_h = pick[1]
+    speed = 1.0 / raise_steps
+
+    def pinned_step():
+        cur, vel = sim.get_positions().copy(), sim.get_velocities().copy()
+        cur[4 * k: 4 * k + 3] = pick
+        cur[4 * k + 3] = 0
+        vel[3 * k: 3 * k + 3] = 0
+        sim.set_positions(cur)
+        sim.set_velocities(vel)
+        sim.step()
+        if record is not None:
+            record(sim)
+
+    for j in range(raise_steps):
+        pick[1] = (height - init_h) * (j * speed) + init_h
+        pinned_step()
+    for _ in range(hold_steps):
+        pinned_step()
+    cur = sim.get_positions().copy()
+    cur[4 * k + 3] = w0
+    sim.set_positions(cur)
+    for _ in range(settle_steps):
+        sim.step()
+        if record is not None:
+            record(sim)
+    return k
+
+
+def scenario_c2_fling(sim, dim=64, settle_steps=300, record=None):
+    """The scripted fling of SURVEY 8(d): pickers grasp the corners 0 and dim - 1, lift to y = 0.3 at 5e-3 per step, forward /
+    back +-0.2 at 6e-3 per step (simEnv.py:262-275 speeds), lower, release, 300 settle steps."""
+    return scenario_fling(sim, dim, dim, lift=0.3, fling_dist=0.2, settle_steps=settle_steps, record=record)
+
+
+CANONICAL = {"c1": scenario_c1, "c2": scenario_c2, "fling": scenario_c2_fling}
+
+
+class Recorder:
+    """record= callback: keeps positions / velocities / shape states of frames 1, 10, 100, every `every`-th and (close()) the last."""
+
+    def __init__(self, every=10, also=(1, 10, 100)):
+        self.every, self.also, self.count = int(every), set(also), 0
+        self.frames, self.pos, self.vel, self.shapes = [], [], [], []
+        self._last = None
+
+    def _snap(self, sim):
+        sh = np.array(sim.get_shape_states(), np.float32).ravel()
+        return (np.array(sim.get_positions(), np.float32).copy(), np.array(sim.get_velocities(), np.float32).copy(), sh)
+
+    def __call__(self, sim):
+        self.count += 1
+        self._sim = sim
+        if self.count % self.every == 0 or self.count in self.also:
+            self._keep(self._snap(sim))
+
+    def _keep(self, snap):
+        if self.frames and self.frames[-1] == self.count:
+            return
+        self.frames.append(self.count)
+        self.pos.append(snap[0]); self.vel.append(snap[1]); self.shapes.append(snap[2])
+
+    def close(self):
+        if self.count and (not self.frames or self.frames[-1] != self.count):
+            self._keep(self._snap(self._sim))
+        return self
+
+    def arrays(self, prefix):
+        ns = max((s.size for s in self.shapes), default=0)
+        sh = np.zeros((len(self.frames), ns), np.float32)
+        for i, s in enumerate(self.shapes):
+            sh[i, :s.size] = s
+        return {prefix + "frames": np.array(self.frames, np.int32), prefix + "positions": np.stack(self.pos),
+                prefix + "velocities": np.stack(self.vel), prefix + "shape_states": sh}

@@ -289,6 +289,70 @@ def test_oracle_is_deterministic():
     assert np.array_equal(a.get_positions().view(np.uint32), b.get_positions().view(np.uint32))
 
 
+def test_rsqrt_table_is_within_one_ulp_and_rescales():
+    """The oracle's reciprocal square root is data measured on an MI355X (oracle/v_rsq_f32_gfx950.npz: gfx950's v_rsq_f32).
+    What can be checked without the chip: every entry is -1 / 0 / +1 ulp from float32(1 / sqrt(float64(x))), the function is
+    within 1 ulp of the exact reciprocal root over every normal exponent (AMD documents 1 ulp for the instruction), zero and
+    denormal inputs take the FLT_MIN clamp (2^63, finite), inf gives 0, and the C implementation equals a numpy
+    restatement of table + rescaling.  (tests/test_parity_gpu.py re-reads the whole table from the GPU it runs on.)"""
+    import oracle
+
+    tab = oracle.rsqrt_table()
+    fields = np.stack([(tab >> s) & 3 for s in (0, 2, 4, 6)], 1).ravel().astype(np.int64) - 2
+    assert fields.size == 1 << 24 and set(np.unique(fields)) <= {-1, 0, 1}
+    assert (fields == 0).mean() > 0.8
+    rng = np.random.RandomState(3)
+    xb = rng.randint(1 << 23, 255 << 23, size=1 << 18).astype(np.uint32)
+    x = xb.view(np.float32)
+    y = oracle.eval_rsqrt(x)
+    exact = 1.0 / np.sqrt(x.astype(np.float64))
+    assert (np.abs(y.astype(np.float64) - exact) / np.spacing(exact.astype(np.float32)).astype(np.float64)).max() <= 1.0
+    e = (xb >> 23).astype(np.int64) - 127
+    par = e & 1
+    xr = (((127 + par) << 23) | (xb & 0x7fffff)).astype(np.uint32).view(np.float32)
+    base = ((1.0 / np.sqrt(xr.astype(np.float64))).astype(np.float32).view(np.int32) + fields[(par << 23) | (xb & 0x7fffff)]).astype(np.int32)
+    pred = np.ldexp(base.view(np.float32), (-(e - par) // 2).astype(np.int32)).astype(np.float32)
+    assert np.array_equal(pred.view(np.uint32), y.view(np.uint32))
+    sp = oracle.eval_rsqrt(np.array([0.0, 1e-45, 1e-40, 1.17549435e-38, np.inf, 4.0], np.float32))
+    assert list(sp) == [2.0 ** 63] * 4 + [0.0, 0.5]
+
+
+def test_static_friction_branch_is_redundant():
+    """flex_oracle.c friction_scale: 'full stick below mu_s x depth, else clamp to mu_k x depth'.  With mu_s <= mu_k -- the
+    cloth scene has (0, 0.75) against shapes and (1, 1) between particles -- the static branch can never change a result:
+    whenever it fires the kinetic clamp would have returned 1 as well.  So 'is there a separate static branch in FleX' is
+    not a parity risk for this scene (PARITY.md)."""
+    rng = np.random.RandomState(0)
+    tl = np.concatenate([rng.rand(20000) * 0.01, [0.0]])
+    pen = np.concatenate([rng.rand(20000) * 0.01, [0.0]])
+    for mu_s, mu_k in ((0.0, 0.75), (1.0, 1.0), (0.3, 0.75)):
+        with_static = np.where(tl < mu_s * pen, 1.0, np.where(tl > mu_k * pen, mu_k * pen / np.maximum(tl, 1e-30), 1.0))
+        without = np.where(tl > mu_k * pen, mu_k * pen / np.maximum(tl, 1e-30), 1.0)
+        assert np.array_equal(with_static, without)
+
+
+def test_model_alternatives_are_live_and_bounded(capsys):
+    """oracle/flex_oracle.c "MODEL switches": every alternative reading of an inferred choice builds, runs the canonical
+    workloads, and changes what it claims to change and nothing else -- the by-distance truncation and the end-pose spheres
+    are exact no-ops where lists stay below 96 / no sphere exists, every other switch moves the trajectory.  The full table
+    (64 x 64, all frames) is PARITY.md, made by tests/parity_table.py."""
+    import parity_table as pt
+
+    out = pt.table(quick=True, jobs=4, scenarios=("c2", "fling"))
+    for s in ("c2", "fling"):
+        assert out[(s, "alt_neighbors_by_distance")]["divergence"] == [0.0] * len(out[(s, "exact")]["frames"])
+        assert out[(s, "exact")]["max_list"][0] < 96
+        assert out[(s, "exact")]["local"][0] <= 1e-6           # arithmetic choices: one step from the same state
+        for v in ("alt_friction_post", "alt_apply_per_type", "alt_stiffness_iter", "alt_damping_mult"):
+            assert max(out[(s, v)]["divergence"]) > 1e-6, (s, v)
+        for v in ("alt_sleep_velocity_only", "alt_sleep_at_predict", "alt_no_sleep"):
+            assert max(out[(s, v)]["divergence"]) > 0, (s, v)
+    assert max(out[("c2", "alt_shape_end_pose")]["divergence"]) == 0.0       # no spheres in the crumple
+    assert max(out[("fling", "alt_shape_end_pose")]["divergence"]) > 1e-6    # pickers move in the fling
+    with capsys.disabled():
+        print("\n" + pt.render(out, scenarios=("c2", "fling")))
+
+
 # ---------------------------------------------------------------- how far the oracle's spelled-out arithmetic moves a step
 def _clone_state(src, variant, params):
     """A fresh oracle of build `variant` in exactly the state of `src` (particles, velocities, phases, shapes)."""
@@ -369,7 +433,7 @@ def test_approximations_stay_within_1e_4_of_exact_math(capsys):
     for name, src, params in _approximation_cases():
         moving = int((src.get_velocities().reshape(-1, 3) != 0).any(1).sum())
         assert moving > 100, f"{name}: the recorded state must be in motion"
-        for variant in ("exact", "exact_rsqrt", "nofma"):
+        for variant in ("exact", "exact_rsqrt", "nofma", "newton"):
             a, b = _clone_state(src, None, params), _clone_state(src, variant, params)
             a.step(1)
             b.step(1)

@@ -43,6 +43,30 @@ def _assert_state_equal(hip, orc, what=""):
 SOLVERS = [1, 2, 6]
 
 
+def test_hw_rsqrt_matches_committed_table(gpu_required):
+    """The numerical contract's one hardware-defined function: the constraint kernels' reciprocal square root is gfx950's
+    v_rsq_f32 on max(x, FLT_MIN), and the oracle reproduces it from a table of the chip's results
+    (oracle/v_rsq_f32_gfx950.npz).  Before any trajectory is compared, THIS box's instruction is read back through
+    fs_eval_rsqrt for all 2^24 (exponent parity, mantissa) inputs in [1, 4), for 4 M random inputs over every normal exponent
+    (other exponents only rescale), and for zero / denormals / FLT_MIN / FLT_MAX / inf -- and must equal the oracle bit for bit."""
+    import oracle
+    from flingbot_amd import sim as fsim
+
+    ctx = fsim.FlingSim(n_envs=1)
+    x = (np.arange(1 << 24, dtype=np.uint32) + np.uint32(127 << 23)).view(np.float32)
+    for k in range(0, 1 << 24, 1 << 22):
+        hw, orc = ctx.eval_rsqrt(x[k:k + (1 << 22)]), oracle.eval_rsqrt(x[k:k + (1 << 22)])
+        assert np.array_equal(hw.view(np.uint32), orc.view(np.uint32)), f"v_rsq_f32 differs from the committed table in [{x[k]}, ...)"
+    rng = np.random.RandomState(0)
+    xr = rng.randint(1 << 23, 255 << 23, size=1 << 22).astype(np.uint32).view(np.float32)
+    assert np.array_equal(ctx.eval_rsqrt(xr).view(np.uint32), oracle.eval_rsqrt(xr).view(np.uint32)), "exponent rescaling"
+    sp = np.array([0.0, 1e-45, 1e-40, 1.17549421e-38, 1.17549435e-38, 1.17549449e-38, 3.4028235e38, np.inf], np.float32)
+    hw = ctx.eval_rsqrt(sp)
+    assert np.array_equal(hw.view(np.uint32), oracle.eval_rsqrt(sp).view(np.uint32)), list(zip(sp, hw))
+    assert np.isfinite(hw).all() and hw[0] == hw[4] == np.float32(2.0 ** 63)
+    ctx.close()
+
+
 @pytest.mark.parametrize("dims", [(32, 32), (64, 64), (5, 3), (1, 1), (2, 1)])
 def test_topology_bit_exact(gpu_required, dims):
     ctx, orc = _sims(1)
@@ -74,20 +98,7 @@ def test_drop_32_bit_exact_every_step(gpu_required, solver):
         _assert_state_equal(hip, orc, f"drop step {k}")
 
 
-def set_to_flatten_positions(dimx, dimz, cloth_particle_radius=0.00625):
-    """The array flex_utils.set_to_flatten (flex_utils.py:398-415) hands to pyflex.set_positions, expression by
-    expression: linspace over dim * radius (so the pitch is dim / (dim - 1) * radius), y = radius, w = 1, then the
-    mean of x, y, z subtracted -- which puts the sheet at y = 0 (to 1e-16), inside the ground's collision distance."""
-    px = np.linspace(0, dimx * cloth_particle_radius, dimx)
-    py = np.linspace(0, dimz * cloth_particle_radius, dimz)
-    xx, yy = np.meshgrid(px, py)
-    new_pos = np.empty(shape=(dimx * dimz, 4), dtype=np.float64)
-    new_pos[:, 0] = xx.flatten()
-    new_pos[:, 1] = cloth_particle_radius
-    new_pos[:, 2] = yy.flatten()
-    new_pos[:, 3] = 1.
-    new_pos[:, :3] -= np.mean(new_pos[:, :3], axis=0)
-    return new_pos
+from scenarios import set_to_flatten_positions  # noqa: E402
 
 
 @pytest.mark.parametrize("solver", SOLVERS)

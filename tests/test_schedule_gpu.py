@@ -315,6 +315,12 @@ def test_service_lane_refuses_to_rewrite_an_episode_in_flight(gpu_required):
             with pytest.raises(fsim.FlingSimError, match="in flight"):
                 call()
         ctx.set_positions(1, pos1)  # the episode next to it is free
+        # ... but nothing may be STEPPED on the lane while a chunk is in flight, not even the free episode: a launch sequence
+        # rebuilds per-context tables the running chunk reads (include/flingsim.h, fs_service_lane)
+        for call in (lambda: ctx.step_list([1], 1), lambda: ctx.step(1), lambda: ctx.wait_until_stable([1], 3, 1e-2),
+                     lambda: ctx.movep([1], z, gr, speed=0.01, limit=10)):
+            with pytest.raises(fsim.FlingSimError, match="service lane"):
+                call()
     finally:
         ctx.service_lane(False)
     prog, status, steps = ctx.advance_end(ticket, prog, status, steps)
