@@ -253,6 +253,13 @@ PYBIND11_MODULE(pyflex, m) {
     }, py::arg("targets"), py::arg("grasp"), py::arg("speed") = 0.1, py::arg("limit") = 1000,
           py::arg("min_steps") = py::none(), py::arg("eps") = 1e-4,
           "SimEnv.movep (simEnv.py:739-769): every simulation step on the device; returns the loop iterations");
+    // the name SURVEY.md 8(f) f1 gives the same entry point: pyflex.step_n(targets, speed, grasp, max_steps)
+    m.def("step_n", [](py::array targets, double speed, py::array_t<int, py::array::c_style | py::array::forcecast> grasp,
+                       int max_steps) {
+        return py::module_::import("pyflex").attr("movep")(targets, grasp, speed, max_steps);
+    }, py::arg("targets"), py::arg("speed") = 0.1, py::arg("grasp") = py::array_t<int>(), py::arg("max_steps") = 1000,
+          "alias of movep with the argument order of SURVEY.md 8(f): both pickers towards `targets` by `speed` per simulation "
+          "step with grasp flags `grasp`, at most `max_steps` loop iterations, every step on the device");
     m.def("wait_until_stable", [](int max_steps, double tolerance) {
         int env = 0, steps = 0, stable = 0;
         if (fs_wait_until_stable(ctx(), 1, &env, max_steps, tolerance, &steps, &stable) != FS_OK) fail("pyflex.wait_until_stable");

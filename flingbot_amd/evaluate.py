@@ -180,3 +180,42 @@ def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=None, **k
     stats["all_final_coverage"] = fdist.gather_rewards(stats["final_coverage"], device=device).cpu().numpy()
     stats["rank"], stats["world"] = rank, world
     return stats
+
+
+def main(argv=None):
+    """python -m flingbot_amd.evaluate --tasks set.npz [--weights flingbot.pth] [--slots 96] [--episode-length 10]
+
+    run_sim.py's evaluation (run_sim.py:37-109 with --eval: fling policy, 12 rotations x 8 scales, obs_dim 64) on a task
+    set converted by scripts/convert_tasks_hdf5.py; prints the reference's summary statistics as one JSON line."""
+    import argparse
+    import json
+
+    from . import nets, sim as fsim, taskio
+    from .env import BatchedFlingEnv
+
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--tasks", required=True, help=".npz task set (flingbot_amd/taskio.py; scripts/convert_tasks_hdf5.py makes it)")
+    ap.add_argument("--weights", default=None, help="checkpoint with the reference's state_dict layout (flingbot.pth)")
+    ap.add_argument("--slots", type=int, default=96, help="episodes resident on the GPU at a time")
+    ap.add_argument("--episode-length", type=int, default=10)
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    tasks = taskio.TaskLoader(a.tasks, repeat=False).all_tasks()
+    dev = f"cuda:{a.device}"
+    ctx = fsim.FlingSim(n_envs=min(a.slots, len(tasks)), device=a.device, solver=0)
+    env = BatchedFlingEnv(ctx, episode_length=a.episode_length, device=dev)
+    policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+                                     obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
+                                     depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
+                                     value_expl_decay=1.0, device=dev)
+    if a.weights:
+        ckpt = torch.load(a.weights, map_location=dev)
+        policy.load_state_dict(ckpt.get("net", ckpt))          # utils.py:116-118 stores the module under 'net'
+    stats = run_tasks(policy, env, tasks)
+    ctx.close()
+    print(json.dumps({"tasks": len(tasks), **stats["mean"], "action_primitive_counts": stats["action_primitive_counts"],
+                      "simulation_steps": stats["simulation_steps"]}))
+
+
+if __name__ == "__main__":
+    main()

@@ -97,7 +97,8 @@ def fake_runner(policy, env, tasks):           # stands in for the GPU loop: cov
     init = np.array([t["seed"] * 0.01 for t in tasks])
     return {"init_coverage": init, "final_coverage": init + 0.5, "n": len(tasks)}
 
-tasks = [{"seed": g} for g in range(8)]
+W = int(os.environ["WORLD_SIZE"])
+tasks = [{"seed": g} for g in range(4 * W)]
 stats = run_episodes_sharded(None, None, tasks, episodes_per_rank=4, runner=fake_runner)
 print(json.dumps({"rank": stats["rank"], "world": stats["world"], "n": stats["n"], "mine": stats["init_coverage"].tolist(),
                   "all_init": stats["all_init_coverage"].tolist(), "all_final": stats["all_final_coverage"].tolist()}))
@@ -106,30 +107,32 @@ torch.distributed.destroy_process_group()
 """
 
 
-def test_sharded_evaluation_gathers_by_global_episode(tmp_path):
-    """evaluate.run_episodes_sharded on two gloo ranks: each rank runs only its own tasks, every rank ends with the
-    coverages of all episodes in global order."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_evaluation_gathers_by_global_episode(tmp_path, world):
+    """evaluate.run_episodes_sharded on two and on EIGHT gloo ranks (the node's shape): each rank runs only its own tasks,
+    every rank ends with the coverages of all episodes in global order."""
     import json
 
     script = tmp_path / "sharded.py"
     script.write_text(SHARDED_WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), FS_ROOT=ROOT)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
-        out, err = p.communicate(timeout=180)
+        out, err = p.communicate(timeout=300)
         assert p.returncode == 0, err[-2000:]
         outs.append(json.loads(out.strip().splitlines()[-1]))
     outs.sort(key=lambda o: o["rank"])
-    assert np.allclose(outs[0]["mine"], [0.0, 0.01, 0.02, 0.03]) and np.allclose(outs[1]["mine"], [0.04, 0.05, 0.06, 0.07])
+    for r in range(world):
+        assert np.allclose(outs[r]["mine"], (np.arange(4) + 4 * r) * 0.01)
     for o in outs:
-        assert o["world"] == 2 and o["n"] == 4
-        assert np.allclose(o["all_init"], np.arange(8) * 0.01) and np.allclose(o["all_final"], np.arange(8) * 0.01 + 0.5)
+        assert o["world"] == world and o["n"] == 4
+        assert np.allclose(o["all_init"], np.arange(4 * world) * 0.01) and np.allclose(o["all_final"], np.arange(4 * world) * 0.01 + 0.5)
 
 
 LAUNCHED_WORKER = r"""
@@ -174,6 +177,31 @@ def test_launcher_starts_ranks_that_rendezvous(tmp_path):
     port = _free_port()
     assert launch_local_ranks(2, str(script), [str(tmp_path), "--kill-rank-1"], env=dict(env, MASTER_PORT=str(port)),
                               timeout=180) == 128 + 9
+    # the node's shape: eight ranks, LOCAL_RANK = RANK = the device each one binds, a port found by the launcher
+    assert launch_local_ranks(8, str(script), [str(tmp_path)], env=env, timeout=300) == 0
+    for r in range(8):
+        assert json.load(open(tmp_path / f"rank{r}.json")) == {"rank": r, "local_rank": r, "world": 8, "sum": 36.0, "argv": []}
+
+
+def test_launcher_port_probe_ignores_time_wait_but_sees_a_listener():
+    """launch._port_in_use decides whether a failed launch is repeated on another port: a LISTENING socket counts, the
+    TIME_WAIT leftovers of our own dead rank 0 do not (a script failure must not be relaunched three times)."""
+    from flingbot_amd.launch import _port_in_use, free_port
+
+    port = free_port()
+    assert not _port_in_use("127.0.0.1", port)
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port))
+    srv.listen(1)
+    assert _port_in_use("127.0.0.1", port)
+    cli = socket.socket()
+    cli.connect(("127.0.0.1", port))
+    conn, _ = srv.accept()
+    conn.close()            # the server side closes first: its end of the connection goes to TIME_WAIT on `port`
+    cli.close()
+    srv.close()
+    assert not _port_in_use("127.0.0.1", port)
 
 
 def test_launcher_module_never_touches_the_gpu_runtime():
@@ -255,7 +283,7 @@ class StubSim:
         return View()
     def sync(self): LOG.append(("ctx_sync", None))
     def step(self, n=1):
-        self.steps += n; LOG.append(("step", n)); time.sleep(0.001 * (1 + 2 * RANK))      # rank 1 is the slow one
+        self.steps += n; LOG.append(("step", n)); time.sleep(0.001 * (1 + 2 * (RANK == 1)))      # rank 1 is the slow one
     def timer_start(self): LOG.append(("timer_start", None)); self._t = time.perf_counter()
     def timer_stop(self): LOG.append(("timer_stop", None)); return (time.perf_counter() - self._t) * 1e3
     def coverage(self): return np.arange(self.n_envs, dtype=np.float64) + 1000.0 * RANK
@@ -270,7 +298,7 @@ class StubSim:
 fsim.FlingSim = StubSim
 import bench
 args = types.SimpleNamespace(episodes=4, steps=3, warmup=1, preroll=2, solver=2, no_parity=True, no_cpu_baseline=True,
-                             no_secondary=False, no_eval_loop=True, gpus=2)
+                             no_secondary=False, no_eval_loop=True, no_c2=True, no_dropin=True, gpus=int(os.environ["WORLD_SIZE"]))
 bench.run_rank(args)
 seeds_ok = all(np.array_equal(s.first_pos[e], bench.initial_state(RANK * s.n_envs + e, 8192.0).ravel())
                for s in StubSim.instances for e in range(s.n_envs))
@@ -279,8 +307,9 @@ with open(os.path.join(os.environ["FS_OUT"], f"rank{RANK}.json"), "w") as fh:
 """
 
 
-def test_bench_run_rank_control_flow_two_ranks(tmp_path):
-    """8-GPU readiness without the hardware: `bench.run_rank` itself runs as two gloo ranks with the solver context stubbed
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
+    """8-GPU readiness without the hardware: `bench.run_rank` itself runs as two -- and as EIGHT -- gloo ranks with the solver context stubbed
     at the fsim.FlingSim seam (inside this test only).  Checked: one JSON line, from rank 0 only; n_gpus / weak scaling /
     whole-job value from the MAX over ranks; every rank sets its own global episodes up (rank r: seeds r E .. r E + E - 1);
     the headline's timed region is barrier + synchronize -> timer -> exactly K steps -> timer -> coverage gather ->
@@ -292,34 +321,35 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path):
     script.write_text(BENCH_WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), FS_ROOT=ROOT, FS_OUT=str(tmp_path))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
-        out, err = p.communicate(timeout=300)
+        out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err[-3000:]
         outs.append(out)
     lines0 = [l for l in outs[0].splitlines() if l.startswith("{")]
-    assert len(lines0) == 1 and not [l for l in outs[1].splitlines() if l.startswith("{")]   # rank 0 prints, rank 1 is silent
+    assert len(lines0) == 1 and not [l for o in outs[1:] for l in o.splitlines() if l.startswith("{")]   # rank 0 prints, the others are silent
     rec = json.loads(lines0[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
-    assert rec["config"]["episodes_per_gpu"] == 4 and rec["config"]["parallelism"] == "episodes x2"
+    assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["config"]["episodes_per_gpu"] == 4 and rec["config"]["parallelism"] == f"episodes x{world}"
     assert rec["unit"] == "sim steps/s" and rec["higher_is_better"] is True and rec["vs_baseline"] is None
     # whole-job value = all ranks' episode-steps / the SLOWEST rank's time: rank 1 sleeps 3 ms per step, rank 0 1 ms
-    assert rec["value"] == pytest.approx(4 * 2 * 3 / (rec["ms_per_step"] * 3e-3))
+    assert rec["value"] == pytest.approx(4 * world * 3 / (rec["ms_per_step"] * 3e-3))
     assert rec["ms_per_step"] >= 3.0
     assert rec["roofline"]["bound"] == "hbm" and rec["roofline"]["kernel"] == "fs_k_fused_grid64"
-    assert rec["mean_coverage"] == pytest.approx(np.mean([0, 1, 2, 3, 1000, 1001, 1002, 1003]))   # both ranks' rewards, gathered
+    assert rec["mean_coverage"] == pytest.approx(np.mean([1000.0 * r + e for r in range(world) for e in range(4)]))   # every rank's rewards, gathered
     assert "cpu_baseline" not in rec and "eval_loop" not in rec                                 # N = 1 only
     sec = rec["configs"][1]
-    assert sec["episodes_per_gpu"] == 64 and "128 episodes over 2 GPUs" in sec["name"] and sec["windows"] == 3
+    assert sec["episodes_per_gpu"] == 64 and f"{64 * world} episodes over {world} GPUs" in sec["name"] and sec["windows"] == 3
+    assert ("configs[3]" in sec["baseline_config"]) == (world == 8)          # 512 episodes over 8 GPUs IS configs[3]
     assert sec["steps"] == 100 and sec["value_min"] <= sec["value"] <= sec["value_max"]
-    assert sec["value"] == pytest.approx(64 * 2 * 100 / (sec["ms_per_step"] * 0.1)) and sec["ms_per_step"] >= 3.0
-    assert sec["mean_coverage"] == pytest.approx((np.arange(64).sum() * 2 + 1000.0 * 64) / 128)
-    for r in range(2):
+    assert sec["value"] == pytest.approx(64 * world * 100 / (sec["ms_per_step"] * 0.1)) and sec["ms_per_step"] >= 3.0
+    assert sec["mean_coverage"] == pytest.approx(np.mean([1000.0 * r + e for r in range(world) for e in range(64)]))
+    for r in range(world):
         got = json.load(open(tmp_path / f"rank{r}.json"))
         assert got["seeds_ok"] and got["sizes"] == [4, 64]
         log = [tuple(x) for x in got["log"]]

@@ -33,7 +33,7 @@ def test_module_exports_the_reference_surface():
     assert len(REFERENCE_NAMES) == 40
     for name in REFERENCE_NAMES:
         assert callable(getattr(pyflex, name, None)), f"pyflex.{name} missing"
-    for name in ("picker_reset", "movep", "wait_until_stable"):  # additive device-side loops
+    for name in ("picker_reset", "movep", "step_n", "wait_until_stable"):  # additive device-side loops
         assert callable(getattr(pyflex, name, None)), f"pyflex.{name} missing"
     # init takes four REQUIRED positionals like the reference (m.def without py::arg, pyflex.cpp:1138)
     with pytest.raises(TypeError):
@@ -121,6 +121,9 @@ def test_reference_call_pattern_matches_oracle(gpu_required):
     targets = cur + [[0.01, -0.03, 0.02], [-0.02, -0.03, 0.0]]
     it = pyflex.movep(targets, [1, 0], speed=4e-3)
     assert it == tool.movep(targets, [True, False], speed=4e-3)
+    # the same entry point under the name SURVEY 8(f) gives it: step_n(targets, speed, grasp, max_steps)
+    back = cur + [[0.0, -0.03, 0.0], [0.0, -0.03, 0.0]]
+    assert pyflex.step_n(back, 4e-3, [1, 0], 500) == tool.movep(back, [True, False], speed=4e-3, limit=500)
     stable, steps = pyflex.wait_until_stable(max_steps=25, tolerance=1e-2)
     done, ok = 0, False
     for _ in range(25):

@@ -1,0 +1,115 @@
+"""Task storage without HDF5: flingbot_amd/taskio.py (.npz interchange, Task, TaskLoader) and the
+evaluation loop running from a stored file."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+
+def _generated_tasks():
+    """The two seeded hard / easy tasks of tests/golden/task_golden.npz, regenerated on the CPU oracle by the product's
+    generator (they are pinned to the reference's own generate_randomization there)."""
+    from fling_helpers import OracleTaskSim, check_tasks_against_golden
+
+    res = check_tasks_against_golden(lambda n: OracleTaskSim(n))
+    return [res[k] for k in sorted(res)]
+
+
+def test_task_file_round_trip_and_loader_semantics(tmp_path, capsys):
+    """save_tasks -> TaskLoader: every field of every task comes back bit for bit with the type the consumers expect, the keys
+    are the reference writer's (sha1 of the running count, tasks.py:306), get_next_task wraps around like tasks.py:445-463
+    (repeat) or stops (no repeat), and Task answers get_config / get_state / get_stats with the reference's key sets."""
+    import hashlib
+    from flingbot_amd import taskio
+
+    tasks = _generated_tasks()
+    assert len(tasks) >= 2
+    path = str(tmp_path / "tasks.npz")
+    assert taskio.save_tasks(path, [tasks[0], None, tasks[1]]) == 2            # a rejected task (None) is not stored
+    loader = taskio.TaskLoader(path)
+    assert loader.keys == [hashlib.sha1(f"{i}".encode()).hexdigest() for i in range(2)] and len(loader) == 2
+    seen = [loader.get_next_task() for _ in range(5)]                           # 0 1 0 1 0: wrap-around
+    assert [t.name for t in seen] == [loader.keys[i % 2] for i in range(5)]
+    for t, src in zip(seen[:2], tasks[:2]):
+        for f in taskio.ARRAY_FIELDS:
+            a, b = np.asarray(t[f]), np.asarray(src[f])
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), f
+        for f in taskio.SCALAR_FIELDS:
+            assert t[f] == src[f] and type(t[f]) in (float, int, str), (f, type(t[f]))
+        assert set(t.get_config()) == {"cloth_pos", "cloth_size", "cloth_stiff", "cloth_mass", "camera_name", "camera_params",
+                                       "flip_mesh", "flatten_area", "mesh_verts", "mesh_stretch_edges", "mesh_bend_edges",
+                                       "mesh_shear_edges", "mesh_faces"}
+        assert set(t.get_state()) == {"particle_pos", "particle_vel", "shape_pos", "phase", "camera_params"}
+        assert set(t.get_stats()) == {"task_name", "cloth_mass", "cloth_size", "cloth_stiff", "max_coverage", "task_difficulty",
+                                      "init_coverage"}
+        assert t.get_config()["camera_params"]["default_camera"]["pos"].tolist() == [0, 2, 0] and "[Task]" in str(t)
+    once = taskio.TaskLoader(path, repeat=False)
+    once.get_next_task(); once.get_next_task()
+    with pytest.raises(StopIteration):
+        once.get_next_task()
+    # a Task loads into a simulator exactly like the dictionary it was made from (scene arguments + state)
+    from flingbot_amd import tasks as ftasks
+    for t, src in zip(seen[:2], tasks[:2]):
+        a, b = ftasks.task_scene_arguments(t), ftasks.task_scene_arguments(src)
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
+    with pytest.raises(ValueError):
+        np.savez(str(tmp_path / "other.npz"), format=np.array("something else"), names=np.array([]))
+        taskio.TaskLoader(str(tmp_path / "other.npz"))
+    # a mesh task has no grid size (tasks.py:357-358)
+    m = taskio.Task("m", 1.0, 0.5, "hard", cloth_size=[10, 10], mesh_verts=np.zeros(9))
+    assert m.cloth_size.tolist() == [-1, -1]
+
+
+def test_converter_script_is_standalone():
+    """scripts/convert_tasks_hdf5.py must run on a machine that has h5py and nothing of this repository or the reference:
+    its imports are h5py, numpy and the standard library, and its field lists are the ones taskio reads."""
+    import ast
+    from flingbot_amd import taskio
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "convert_tasks_hdf5.py")).read()
+    tree = ast.parse(src)
+    mods = {n.names[0].name.split(".")[0] for n in ast.walk(tree) if isinstance(n, ast.Import)} | \
+           {n.module.split(".")[0] for n in ast.walk(tree) if isinstance(n, ast.ImportFrom)}
+    assert mods <= {"sys", "h5py", "numpy"}, mods
+    consts = {t.targets[0].id: ast.literal_eval(t.value) for t in tree.body if isinstance(t, ast.Assign) and
+              isinstance(t.targets[0], ast.Name) and t.targets[0].id in ("ARRAY_FIELDS", "SCALAR_FIELDS")}
+    assert consts["ARRAY_FIELDS"] == taskio.ARRAY_FIELDS and consts["SCALAR_FIELDS"] == taskio.SCALAR_FIELDS
+    assert '"flingbot_amd tasks v1"' in src and taskio.FORMAT == "flingbot_amd tasks v1"
+
+
+@pytest.mark.gpu
+def test_evaluation_loop_runs_from_a_stored_task_file(gpu_required, tmp_path):
+    """generate -> save_tasks -> TaskLoader.all_tasks -> evaluate.run_tasks gives exactly the statistics the loop gives on the
+    generator's dictionaries (the stored file is a faithful stand-in for the HDF5 sets the reference evaluates on)."""
+    import torch
+    from flingbot_amd import nets, sim as fsim, taskio, tasks as ftasks
+    from flingbot_amd.env import BatchedFlingEnv
+    from flingbot_amd.evaluate import run_tasks
+
+    random.seed(2); np.random.seed(2); torch.manual_seed(2)
+    n = 3
+    gen = fsim.FlingSim(n_envs=n, solver=0)
+    made = ftasks.generate_tasks(gen, [ftasks.draw_task_parameters(min_cloth_size=24, strict_min_edge_length=24, max_cloth_size=32) for _ in range(n)])
+    gen.close()
+    made = [t for t in made if t is not None]
+    path = str(tmp_path / "set.npz")
+    taskio.save_tasks(path, made)
+    stored = taskio.TaskLoader(path, repeat=False).all_tasks()
+
+    def run(tasks):
+        torch.manual_seed(5)
+        ctx = fsim.FlingSim(n_envs=2, solver=0)
+        env = BatchedFlingEnv(ctx, image_dim=128, episode_length=2)
+        policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
+                                         obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
+                                         depth_only=False, action_expl_prob=0.0, action_expl_decay=1.0, value_expl_prob=0.0,
+                                         value_expl_decay=1.0, device="cuda:0")
+        stats = run_tasks(policy, env, tasks)
+        ctx.close()
+        return stats
+
+    a, b = run(made), run(stored)
+    for k in ("init_coverage", "final_coverage", "episode_length", "coverage_steps"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["action_primitive_counts"] == b["action_primitive_counts"] and a["simulation_steps"] == b["simulation_steps"]
