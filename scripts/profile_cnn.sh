@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel stats + MFMA counters of the value network forward (scripts/cnn_timing.py).  GPU box, repo root.
-ROOT=$(pwd)
+ROOT=$(pwd); TAG=${1:-r04}
 OUT=$ROOT/gpurun_out/prof_cnn
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +14,7 @@ python3 scripts/pmc_kernels.py $OUT/pmc2 > $OUT/pmc2_kernels.txt 2>&1
 grep -h "fs_k_vn\|igemm\|TOTAL\|MFMA" $OUT/pmc_kernels.txt $OUT/pmc2_kernels.txt
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -r head -8
 mkdir -p $ROOT/gpurun_out/cnn_summary
-python3 - $OUT/stats $ROOT/gpurun_out/cnn_summary/r01_cnn_kernel_stats.csv <<'PY'
+python3 - $OUT/stats $ROOT/gpurun_out/cnn_summary/${TAG}_cnn_kernel_stats.csv <<'PY'
 import csv, os, sqlite3, sys
 db = [os.path.join(r, f) for r, _, fs in os.walk(sys.argv[1]) for f in fs if f.endswith(".db")][0]
 con = sqlite3.connect(db)
@@ -25,6 +25,6 @@ with open(sys.argv[2], "w", newline="") as fh:
         if pct >= 0.2:
             w.writerow([name[:120], calls, f"{total:.3f}", f"{avg:.3f}", f"{pct:.2f}"])
 PY
-cat $OUT/pmc_kernels.txt $OUT/pmc2_kernels.txt > $ROOT/gpurun_out/cnn_summary/r01_cnn_pmc.txt
-grep SpatialValueNet $OUT/stats.log > $ROOT/gpurun_out/cnn_summary/r01_cnn_timing.txt
+cat $OUT/pmc_kernels.txt $OUT/pmc2_kernels.txt > $ROOT/gpurun_out/cnn_summary/${TAG}_cnn_pmc.txt
+grep SpatialValueNet $OUT/stats.log > $ROOT/gpurun_out/cnn_summary/${TAG}_cnn_timing.txt
 find $OUT -name "*.db" -delete

@@ -1,18 +1,18 @@
 #!/bin/bash
 # rocprofv3 kernel stats of the streaming back-end on BASELINE.json configs[2]: 64 crumpled 64x64 episodes in one launch
-# sequence (tests/soak/ab_fused.py 64 1).  GPU box, repo root; writes gpurun_out/stream_summary/r03_stream64_kernel_stats.csv.
-ROOT=$(pwd)
+# sequence (tests/soak/ab_fused.py 64 1).  GPU box, repo root; writes gpurun_out/stream_summary/${TAG}_stream64_kernel_stats.csv.
+ROOT=$(pwd); TAG=${1:-r04}
 mkdir -p $ROOT/gpurun_out/stream_summary
 rm -rf $ROOT/gpurun_out/prof_s64
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_s64 -o s64 -- python3 $ROOT/tests/soak/ab_fused.py 64 1 > /dev/null 2>&1
 cd $ROOT
-python3 - <<'PY'
-import csv, sqlite3, glob, statistics
+TAG=$TAG python3 - <<'PY'
+import csv, sqlite3, glob, statistics, os
 f = glob.glob('gpurun_out/prof_s64/**/*.db', recursive=True)[0]
 con = sqlite3.connect(f)
 rows = list(con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-with open('gpurun_out/stream_summary/r03_stream64_kernel_stats.csv', 'w', newline='') as fh:
+with open('gpurun_out/stream_summary/' + os.environ.get('TAG', 'r04') + '_stream64_kernel_stats.csv', 'w', newline='') as fh:
     w = csv.writer(fh)
     w.writerow(["kernel (rocprofv3 --kernel-trace --stats -- python3 tests/soak/ab_fused.py 64 1: streaming back-end, 64 crumpled 64x64 episodes)", "calls", "total_us", "average_us", "percent"])
     for name, calls, total, avg, pct in rows:

@@ -24,7 +24,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 FRAMES = (1, 10, 100)
 
 ROWS = [  # (variant, what it changes)
-    ("exact", "arithmetic: IEEE sqrt / divide instead of the spelled-out reciprocal root, unfused multiply-adds (noise floor)"),
+    ("exact", "arithmetic only: IEEE sqrt / divide instead of the hardware reciprocal root, unfused multiply-adds (the noise floor: no model change at all)"),
     ("alt_friction_post", "friction once per substep after the position solve, Coulomb bound = accumulated normal correction"),
     ("alt_neighbors_by_distance", "candidate lists above 96 keep the nearest instead of the smallest ids"),
     ("alt_shape_end_pose", "kinematic spheres at their end-of-frame pose in every substep"),
