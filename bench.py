@@ -168,18 +168,24 @@ VALU_PEAK_TLANEOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # 256 CUs x 4 SIMDs x 16 lane
 
 
 def valu_roofline(limiter, episodes, kern_ms):
-    """The roofline that physically bounds the LDS-resident kernel: VALU lane-operations per second against the
-    non-packed issue peak.  Instructions per launch come from the committed PMC pass (`limiter`), scaled per episode;
-    the time is this run's HIP-event kernel time."""
+    """The roofline that physically bounds the LDS-resident kernel: VALU issue slots per second against the non-packed
+    issue peak.  Instructions per launch come from the committed PMC pass (`limiter`: SQ_INSTS_VALU), scaled per episode;
+    a quarter-rate instruction occupies the VALU for four slots, and the one such instruction of the inner loops is the
+    reciprocal root -- v_rsq_f32, one per spring endpoint = 12 per particle and iteration (counted analytically; contacts add
+    a few per cent more) -- so three extra slots are charged for each; the time is this run's HIP-event kernel time."""
     if not limiter or "valu_instructions_per_launch" not in limiter:
         return None
     per_ep = limiter["valu_instructions_per_launch"] / limiter.get("episodes", 256)
-    lane_ops = per_ep * episodes * 64
-    achieved = lane_ops / (kern_ms * 1e-3) / 1e12
-    return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+    rsq_per_ep = N_PART * 12 * SUBSTEPS * ITERS / 64.0 if limiter["source"].split("/")[-1] >= "r04" else 0.0
+    slots = (per_ep + 3.0 * rsq_per_ep) * episodes
+    achieved = slots * 64 / (kern_ms * 1e-3) / 1e12
+    return {"bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-slots/s",
             "frac": achieved / VALU_PEAK_TLANEOPS, "wave_instructions_per_launch": per_ep * episodes,
-            "source": f"SQ_INSTS_VALU of {limiter['source']} (per episode) x 64 lanes / this run's kernel time; peak = "
-                      f"256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz"}
+            "quarter_rate_wave_instructions_per_launch": rsq_per_ep * episodes,
+            "valu_busy_fraction_pmc": limiter.get("valu_active_per_wave_cycle", 0.0) * limiter.get("waves_per_simd", 4),
+            "source": f"SQ_INSTS_VALU of {limiter['source']} (per episode) + 3 extra slots per v_rsq_f32, x 64 lanes / this run's "
+                      f"kernel time; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz; valu_busy_fraction_pmc = SQ_ACTIVE_INST_VALU x "
+                      f"waves per SIMD / SQ_WAVE_CYCLES of the same pass (how much of the time a SIMD's VALU is occupied)"}
 
 
 def stream_limiter_from_profile():

@@ -275,6 +275,7 @@ extern "C" int fs_set_stream_groups(fs_ctx *ctx, int groups) {
 extern "C" int fs_last_stream_groups(const fs_ctx *ctx) { return ctx ? ctx->last_stream_groups : FS_ERR_ARG; }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
 extern "C" int fs_last_kernel_form(const fs_ctx *ctx) { return ctx ? ctx->last_form : FS_ERR_ARG; }
+extern "C" int fs_last_boundary_form(const fs_ctx *ctx) { return ctx ? ctx->last_boundary : FS_ERR_ARG; }
 extern "C" void *fs_stream(fs_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 static FsEnv *get_env(fs_ctx *ctx, int env, bool need_scene = true) {

@@ -59,6 +59,7 @@ def load_library(build_if_missing=True):
         "fs_set_solver": (ci, [vp, ci]),
         "fs_get_solver": (ci, [vp]),
         "fs_last_kernel_form": (ci, [vp]),
+        "fs_last_boundary_form": (ci, [vp]),
         "fs_set_stream_groups": (ci, [vp, ci]),
         "fs_last_stream_groups": (ci, [vp]),
         "fs_set_scene": (ci, [vp, ci, fp, ci, fp, ci, ip, ci, ip, ci, ip, ci, ip, ci]),
@@ -203,6 +204,10 @@ class FlingSim:
     def last_kernel_form(self):
         """FS_FORM_* of the most recent solver launch (white box for the parity tests)."""
         return self._ck(self.lib.fs_last_kernel_form(self.h))
+
+    def last_boundary_form(self):
+        """0 four kernels / 1 fs_k_boundary / 2 fs_k_boundary_wide in the most recent streaming launch (white box)."""
+        return self._ck(self.lib.fs_last_boundary_form(self.h))
 
     def set_stream_groups(self, groups):
         """Concurrent launch chains of the streaming back-end: 0 = measured default, 1..4 = forced (fs_set_stream_groups)."""

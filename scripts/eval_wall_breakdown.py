@@ -22,6 +22,7 @@ for k in range(0, N, S):
     gen = fsim.FlingSim(n_envs=min(S, N - k), solver=0)
     tasks += ftasks.generate_tasks(gen, [ftasks.draw_task_parameters() for _ in range(min(S, N - k))])
     gen.close()
+tasks = [t for t in tasks if t is not None]        # (a rejected task is not part of the set, like the reference's generation loop)
 ctx = fsim.FlingSim(n_envs=S, solver=0)
 env = BatchedFlingEnv(ctx, episode_length=steps)
 policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
