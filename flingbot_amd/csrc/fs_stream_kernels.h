@@ -369,12 +369,21 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary_wide(const FsE
     }
     if (!PRE) return;
     // the ticket: release what this workgroup wrote, draw, and -- for the last one -- acquire what the others wrote
+#ifdef FS_BW_LIGHT  // experiment: coherence through the XCD's L2 only (every workgroup of an episode runs on one XCD)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#else
     __threadfence();
+#endif
     __syncthreads();
     if (t == 0) wave_tot[16] = atomicAdd(&E.cell_count[FS_GRID_BUCKETS], 1);
     __syncthreads();
     if (wave_tot[16] != parts - 1) return;
+#ifdef FS_BW_LIGHT
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
     __threadfence();
+#endif
     // exclusive scan of the histogram: 16 consecutive buckets per thread, lanes, waves (fs_k_grid_scan)
     int loc[16], sum = 0;
 #pragma unroll

@@ -7,6 +7,18 @@ import numpy as np
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _each(fn, items):
+    """[fn(x) for x in items] with the calls on threads of their own when there is more than one: the oracle stand-ins below
+    hold one INDEPENDENT CPU oracle per episode, orc_step runs without the GIL (ctypes), and the suite's wall time is mostly
+    those steps.  Order of the results = order of the items; every call touches its own episode only."""
+    items = list(items)
+    if len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(items), os.cpu_count() or 1)) as pool:
+        return list(pool.map(fn, items))
+
+
 def picker_centres():
     """Picker.reset([0, 0.1, 0]) sphere centres (flex_utils.py:82-97)."""
     r = np.sqrt(2 - 1) * 0.02 * 2.
@@ -54,8 +66,7 @@ class OracleBatch:
         t.particle_inv_mass = self.sims[e].get_positions().reshape(-1, 4)[:, 3]
 
     def step_list(self, envs, n_steps=1):
-        for e in envs:
-            self.sims[e].step(n_steps)
+        _each(lambda e: self.sims[e].step(n_steps), envs)
 
     def coverage(self):
         from oracle.coverage import covered_area
@@ -77,8 +88,9 @@ class OracleBatch:
 
     def movep(self, envs, targets, grasp, speed=0.1, limit=1000, min_steps=None, eps=1e-4):
         targets = np.asarray(targets)
-        iters = np.array([self.tools[e].movep(targets[k], [bool(g) for g in grasp[k]], speed=speed, limit=limit,
-                                              min_steps=min_steps, eps=eps) for k, e in enumerate(envs)], np.int32)
+        iters = np.array(_each(lambda ke: self.tools[ke[1]].movep(targets[ke[0]], [bool(g) for g in grasp[ke[0]]], speed=speed,
+                                                                 limit=limit, min_steps=min_steps, eps=eps),
+                               list(enumerate(envs))), np.int32)
         self.last_movep_steps = sum(self.tools[e].last_sim_steps for e in envs)
         return iters
 
@@ -92,7 +104,8 @@ class OracleBatch:
         self.advance_calls = getattr(self, "advance_calls", 0) + 1
         chunk = cap if not any(k == 0 for k in kind) else max(cap_min, 1)  # CPU stand-in: fixed short chunks (worst case for resumption)
         tols = np.broadcast_to(np.asarray(tolerance, np.float64), (n,))
-        for a, e in enumerate(envs):
+        def one(ae):
+            a, e = ae
             if kind[a] == 0:
                 tg = np.asarray(targets[a], np.float32 if f32[a] else np.float64).reshape(-1, 3)
                 ms = None if min_steps[a] < 0 else int(min_steps[a])
@@ -114,6 +127,8 @@ class OracleBatch:
                     self.sims[e].step(1)
                     done += 1
                 prog[a], status[a], steps[a] = start[a] + done, (1 if st == 2 and kind[a] == 2 else st), done
+
+        _each(one, list(enumerate(envs)))
         return prog, status, steps
 
     # ---- fs_advance_begin / fs_advance_end / fs_service_lane on the CPU oracles, with the PROTOCOL checked: the work of a
@@ -219,8 +234,7 @@ class OracleBatch:
         return np.array(single), np.array(near, np.float32)
 
     def wait_until_stable(self, envs, max_steps=300, tolerance=1e-2):
-        stable, steps = [], []
-        for e in envs:
+        def one(e):
             done, ok = 0, False
             for _ in range(max_steps):  # flex_utils.py:430-441
                 if np.abs(self.sims[e].get_velocities()).max() < tolerance:
@@ -228,9 +242,10 @@ class OracleBatch:
                     break
                 self.sims[e].step(1)
                 done += 1
-            stable.append(ok)
-            steps.append(done)
-        return np.array(stable), np.array(steps, np.int32)
+            return ok, done
+
+        res = _each(one, envs)
+        return np.array([r[0] for r in res]), np.array([r[1] for r in res], np.int32)
 
 
 def load_primitives_golden():
@@ -279,8 +294,7 @@ class OracleTaskSim:
         self.sims[e].set_scene(scene_params)
 
     def step_list(self, envs, n_steps=1):
-        for e in envs:
-            self.sims[e].step(n_steps)
+        _each(lambda e: self.sims[e].step(n_steps), envs)
 
     def add_sphere(self, e, radius, pos, quat):
         self.sims[e].add_sphere(radius, pos, quat)
@@ -321,8 +335,7 @@ class OracleTaskSim:
         return out
 
     def wait_until_stable(self, envs, max_steps=300, tolerance=1e-2):
-        stable, steps = [], []
-        for e in envs:
+        def one(e):
             done, ok = 0, False
             for _ in range(max_steps):
                 if np.abs(self.sims[e].get_velocities()).max() < tolerance:
@@ -330,14 +343,25 @@ class OracleTaskSim:
                     break
                 self.sims[e].step(1)
                 done += 1
-            stable.append(ok)
-            steps.append(done)
-        return np.array(stable), np.array(steps, np.int32)
+            return ok, done
+
+        res = _each(one, envs)
+        return np.array([r[0] for r in res]), np.array([r[1] for r in res], np.int32)
 
     def coverage(self):
         from oracle.coverage import covered_area
 
         return [covered_area(s.get_positions()) if s.n else 0.0 for s in self.sims]
+
+
+_TASKS_ON_ORACLE = {}
+
+
+def oracle_generated_tasks():
+    """The golden tasks regenerated on the CPU oracle (checked against the reference's), made once per test session."""
+    if "tasks" not in _TASKS_ON_ORACLE:
+        _TASKS_ON_ORACLE["tasks"] = check_tasks_against_golden(lambda n: OracleTaskSim(n))
+    return _TASKS_ON_ORACLE["tasks"]
 
 
 def check_tasks_against_golden(make_sim):

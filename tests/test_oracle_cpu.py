@@ -338,7 +338,7 @@ def test_model_alternatives_are_live_and_bounded(capsys):
     (64 x 64, all frames) is PARITY.md, made by tests/parity_table.py."""
     import parity_table as pt
 
-    out = pt.table(quick=True, jobs=4, scenarios=("c2", "fling"))
+    out = pt.table(quick=True, jobs=8, scenarios=("c2", "fling"))
     for s in ("c2", "fling"):
         assert out[(s, "alt_neighbors_by_distance")]["divergence"] == [0.0] * len(out[(s, "exact")]["frames"])
         assert out[(s, "exact")]["max_list"][0] < 96
@@ -713,9 +713,9 @@ def test_scheduled_drag_place_stretchdrag_programs_reproduce_reference_golden():
 def test_task_generator_host_logic_reproduces_reference_golden():
     """flingbot_amd.tasks.generate_hard_tasks on the CPU oracle retraces the REFERENCE's generate_randomization
     (tests/golden/task_golden.npz: two seeded hard tasks), including the random draws, bit for bit."""
-    from fling_helpers import OracleTaskSim, check_tasks_against_golden
+    from fling_helpers import oracle_generated_tasks
 
-    check_tasks_against_golden(lambda n: OracleTaskSim(n))
+    assert len(oracle_generated_tasks()) >= 2      # (the checks are inside; the result is shared with tests/test_taskio.py)
 
 
 def test_observe_oracle_known_answers():

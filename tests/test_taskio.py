@@ -10,9 +10,9 @@ import pytest
 def _generated_tasks():
     """The two seeded hard / easy tasks of tests/golden/task_golden.npz, regenerated on the CPU oracle by the product's
     generator (they are pinned to the reference's own generate_randomization there)."""
-    from fling_helpers import OracleTaskSim, check_tasks_against_golden
+    from fling_helpers import oracle_generated_tasks
 
-    res = check_tasks_against_golden(lambda n: OracleTaskSim(n))
+    res = oracle_generated_tasks()
     return [res[k] for k in sorted(res)]
 
 
