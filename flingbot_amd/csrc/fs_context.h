@@ -116,7 +116,7 @@ struct fs_ctx {
     hipStream_t svc_stream = nullptr;   // high priority: reductions / observation / resets of episodes that are NOT part of a chunk in flight
     hipEvent_t svc_event = nullptr;
     bool on_svc = false;
-    int last_boundary = 0;  // substep-boundary form of the most recent streaming launch: 0 four kernels, 1 fs_k_boundary, 2 fs_k_boundary_wide
+    int last_boundary = 0;  // substep-boundary form of the most recent streaming launch: 0 four kernels, 1 fs_k_boundary
     // concurrent chains of the streaming back-end (fs_solver.hip): streams / join events per group, the fork event
     hipStream_t aux_streams[FS_MAX_STREAM_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t aux_events[FS_MAX_STREAM_GROUPS] = {nullptr, nullptr, nullptr, nullptr};

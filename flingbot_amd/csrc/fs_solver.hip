@@ -111,15 +111,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     // (one workgroup per episode: launches of fewer than 16 episodes are 2-3 % faster with the four small kernels spread
     // over the chip -- measured, scripts/boundary_timing.py -- and keep them unless FS_SOLVER_STREAM_MERGED asks otherwise)
     const bool merged = max_n <= FS_BOUND_MAX && !ctx->force_split_boundary && (ne >= 16 || ctx->force_merged_boundary);
-    // ... and as tiles of 4096 particles (fs_k_boundary_wide) when the launch holds cloths above one tile but fewer episodes
-    // than the chip has compute units: one workgroup per episode would leave CUs idle behind the largest cloth
-    bool wide = merged && max_n > FS_BW_TILE && ne < 256;
-    if (const char *w = getenv("FLINGSIM_BOUNDARY_WIDE")) wide = merged && atoi(w) != 0;   // development override (A/B runs)
-    ctx->last_boundary = !merged ? 0 : (wide ? 2 : 1);
+    ctx->last_boundary = merged ? 1 : 0;
     if (merged && !ctx->bound_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary_wide<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary_wide<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary_wide<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void *)fs_k_boundary<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, FS_BOUND_LDS_BYTES));
@@ -134,7 +127,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     if (groups > FS_MAX_STREAM_GROUPS) groups = FS_MAX_STREAM_GROUPS;
     if (groups > (ne + 7) / 8) groups = (ne + 7) / 8;
     if (groups < 1) groups = 1;
-    struct Chain { int first, count, gx, wgx; dim3 grid, wgrid; hipStream_t st; };
+    struct Chain { int first, count, gx; dim3 grid; hipStream_t st; };
     Chain chain[FS_MAX_STREAM_GROUPS];
     {
         const int blocks8 = (ne + 7) / 8;
@@ -149,8 +142,6 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             for (int k = 0; k < c.count; ++k) mx = std::max(mx, ctx->envs[ids[c.first + k]].host.n);
             c.gx = (mx + FS_TILE - 1) / FS_TILE;
             c.grid = dim3((unsigned)(((c.count + 7) / 8) * 8) * (unsigned)c.gx);
-            c.wgx = (mx + FS_BW_TILE - 1) / FS_BW_TILE;
-            c.wgrid = dim3((unsigned)(((c.count + 7) / 8) * 8) * (unsigned)c.wgx);
             c.st = st;
         }
     }
@@ -189,18 +180,9 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             const int *cids = d_ids + c.first;
             const dim3 bgrid((unsigned)c.count), bblock(FS_BOUND_THREADS);
             switch (kind) {
-                case K_BOUND_FIRST:
-                    if (wide) hipLaunchKernelGGL((fs_k_boundary_wide<false, true>), c.wgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, 0, c.wgx, c.count);
-                    else hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, 0);
-                    break;
-                case K_BOUND_MID:
-                    if (wide) hipLaunchKernelGGL((fs_k_boundary_wide<true, true>), c.wgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip, c.wgx, c.count);
-                    else hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip);
-                    break;
-                case K_BOUND_LAST:
-                    if (wide) hipLaunchKernelGGL((fs_k_boundary_wide<true, false>), c.wgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip, c.wgx, c.count);
-                    else hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip);
-                    break;
+                case K_BOUND_FIRST: hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, 0); break;
+                case K_BOUND_MID: hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip); break;
+                case K_BOUND_LAST: hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip); break;
                 case K_PREDICT: hipLaunchKernelGGL(fs_k_predict, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
                 case K_SCAN: hipLaunchKernelGGL(fs_k_grid_scan, bgrid, dim3(1024), 0, c.st, tab, cids); break;
                 case K_SCATTER: hipLaunchKernelGGL(fs_k_grid_scatter, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;

@@ -152,7 +152,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 // thread keeps its (up to 16) predicted positions in registers from the first pass to the last.  The arithmetic is that of
 // the four kernels, statement for statement; the order of the particles INSIDE a bucket differs (it was the order of the
 // global atomics before), which the search cannot see: its lists are sorted sets.  A frame is 129 dependent launches instead
-// of 140; measured in EXPERIMENTS.md (round-2 notes, 4.2 "The launch floor").
+// of 140; measured in EXPERIMENTS.md (round-2 notes, 4.2 "The launch floor").  (Round 4 built the same boundary as tiles of
+// 4096 particles per workgroup with a last-ticket workgroup doing scan + scatter, for launches whose episodes cannot fill the
+// chip: slower at every size -- global histogram atomics and the fences cost more than the idle CUs; EXPERIMENTS R4.2.)
 #define FS_BOUND_THREADS 1024
 #define FS_BOUND_PPT 16
 #define FS_BOUND_MAX (FS_BOUND_THREADS * FS_BOUND_PPT)
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 // stride 16 words = 2 banks for a whole wave) spread over all banks (measured: fs_k_boundary 24.5 -> 17.3 us, EXPERIMENTS.md round-2 notes 4.2)
 #define FS_BOUND_IDX(b) ((b) + ((b) >> 5))
 #define FS_BOUND_HIST (FS_GRID_BUCKETS + FS_GRID_BUCKETS / 32)
-#define FS_BOUND_LDS_BYTES (FS_BOUND_HIST * 4 + 128)  // + wave totals [16] and the wide form's ticket
+#define FS_BOUND_LDS_BYTES (FS_BOUND_HIST * 4 + 64)
 template <bool FIN, bool PRE>
 __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev *envs, const int *ids, int flip) {
     static_assert(FS_GRID_BUCKETS == FS_BOUND_THREADS * 16 && FS_BOUND_MAX <= (1 << 14), "16 buckets per thread, 14-bit ranks");
@@ -279,148 +281,6 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
             const int slot = hist[FS_BOUND_IDX(code[k] & (FS_GRID_BUCKETS - 1))] + (code[k] >> 14);
             fs_st4o(E.xb, (unsigned)slot, FsVec4{xpk[k].x, xpk[k].y, xpk[k].z, __int_as_float(t + k * FS_BOUND_THREADS)});
         }
-    }
-}
-
-// ---- the substep boundary of LARGE cloths in launches that cannot fill the chip with one workgroup per episode (round 4).
-// fs_k_boundary moves ~144 B per particle through ONE compute unit: 31 us for a 104 x 104 cloth, whatever else the chip does,
-// and the evaluation loop runs ~130 such episodes at a time -- half the CUs idle for 9 % of the GPU time.  Here an episode is
-// cut into tiles of 4096 particles, one workgroup each (XCD-affine like every per-particle kernel: fs_stream_tile): finalize +
-// predict + the bucket histogram -- global atomics on cell_count, whose return value is the particle's rank inside its bucket --
-// run in parallel; every workgroup leaves (bucket | rank << 14) in cell_items and takes a ticket (cell_count[FS_GRID_BUCKETS]);
-// the workgroup that draws the LAST ticket of its episode sees everything the others wrote (release / acquire fences at
-// agent scope around the ticket) and finishes alone what needs the whole histogram: the exclusive scan (starts into LDS, ends
-// into cell_fill, histogram and ticket back to zero) and the bucket-ordered copy of the predicted positions.  No workgroup
-// ever waits for another one.  The arithmetic is fs_k_boundary's statement for statement; the order of the particles inside
-// a bucket differs, which the search cannot see (its lists are sorted sets).
-#define FS_BW_PPT 4
-#define FS_BW_TILE (FS_BOUND_THREADS * FS_BW_PPT)
-template <bool FIN, bool PRE>
-__global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary_wide(const FsEnvDev *envs, const int *ids, int flip, int gx, int ne) {
-    extern __shared__ __attribute__((aligned(16))) int bound_smem[];
-    int *hist = bound_smem, *wave_tot = bound_smem + FS_BOUND_HIST;
-    int bx, by;
-    if (!fs_stream_tile(gx, ne, bx, by)) return;
-    const FsEnvDev &E = envs[by];
-    if (E.slot_env < 0) return;  // retired slot
-    const int n = E.n, t = threadIdx.x;
-    const int parts = (n + FS_BW_TILE - 1) / FS_BW_TILE;  // workgroups that hold particles of this episode
-    if (bx >= parts) return;
-    const FsParams &p = E.p;
-    const float h = p.dt / (float)p.numSubsteps;
-    const float inv_cell = 1.0f / (p.radius + p.particleCollisionMargin);
-#pragma unroll
-    for (int k = 0; k < FS_BW_PPT; ++k) {
-        const unsigned i = (unsigned)(bx * FS_BW_TILE + t + k * FS_BOUND_THREADS);
-        if ((int)i < n) {
-            FsVec4 x, v;
-            if (FIN) {  // fs_k_finalize
-                const float inv_h = 1.0f / h;
-                const FsVec4 x0 = fs_ld4o(E.x0, i);
-                x = x0;
-                v = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (x0.w > 0.0f) {
-                    const FsVec4 xp = fs_ld4o(flip ? E.xb : E.xa, i);
-                    const FsVec4 v0 = fs_ld4o(E.v0, i);
-                    float vx = (xp.x - x0.x) * inv_h, vy = (xp.y - x0.y) * inv_h, vz = (xp.z - x0.z) * inv_h;
-                    float ax = vx - v0.x, ay = vy - v0.y, az = vz - v0.z;
-                    float dv2 = ax * ax + ay * ay + az * az;
-                    const float maxdv = p.maxAcceleration * h;
-                    if (dv2 > maxdv * maxdv) {
-                        float sc = maxdv / sqrtf(dv2);
-                        vx = v0.x + ax * sc; vy = v0.y + ay * sc; vz = v0.z + az * sc;
-                    }
-                    float v2 = vx * vx + vy * vy + vz * vz;
-                    if (p.maxSpeed < 3.402823466e+38f && v2 > p.maxSpeed * p.maxSpeed) {
-                        float sc = p.maxSpeed / sqrtf(v2);
-                        vx = vx * sc; vy = vy * sc; vz = vz * sc;
-                        v2 = vx * vx + vy * vy + vz * vz;
-                    }
-                    const float thr2 = p.sleepThreshold * p.sleepThreshold;
-                    if (!(v2 < thr2)) {
-                        v = FsVec4{vx, vy, vz, 0.0f};
-                        x = FsVec4{xp.x, xp.y, xp.z, x0.w};
-                        fs_st4o(E.pos, i, x);
-                    }
-                }
-                fs_st4o(E.vel, i, v);
-            } else {
-                x = fs_ld4o(E.pos, i);
-                v = fs_ld4o(E.vel, i);
-            }
-            if (PRE) {  // fs_k_predict + the particle's bucket and rank
-                fs_st4o(E.x0, i, x);
-                fs_st4o(E.v0, i, v);
-                FsVec4 xp = x;
-                if (x.w > 0.0f) {
-                    float vx = v.x + h * (p.gravity[0] - p.damping * v.x);
-                    float vy = v.y + h * (p.gravity[1] - p.damping * v.y);
-                    float vz = v.z + h * (p.gravity[2] - p.damping * v.z);
-                    xp.x = x.x + h * vx;
-                    xp.y = x.y + h * vy;
-                    xp.z = x.z + h * vz;
-                }
-                fs_st4o(E.xa, i, xp);
-                const int b = fs_stream_bucket((int)floorf(xp.x * inv_cell), (int)floorf(xp.y * inv_cell), (int)floorf(xp.z * inv_cell));
-                const int rank = atomicAdd(&E.cell_count[b], 1);
-                E.cell_items[i] = b | (rank << 14);
-            }
-        }
-    }
-    if (!PRE) return;
-    // the ticket: release what this workgroup wrote, draw, and -- for the last one -- acquire what the others wrote
-#ifdef FS_BW_LIGHT  // experiment: coherence through the XCD's L2 only (every workgroup of an episode runs on one XCD)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#else
-    __threadfence();
-#endif
-    __syncthreads();
-    if (t == 0) wave_tot[16] = atomicAdd(&E.cell_count[FS_GRID_BUCKETS], 1);
-    __syncthreads();
-    if (wave_tot[16] != parts - 1) return;
-#ifdef FS_BW_LIGHT
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#else
-    __threadfence();
-#endif
-    // exclusive scan of the histogram: 16 consecutive buckets per thread, lanes, waves (fs_k_grid_scan)
-    int loc[16], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        loc[k] = E.cell_count[t * 16 + k];
-        sum += loc[k];
-    }
-    const int lane = t & 63, wave = t >> 6;
-    int inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    int run = inc - sum;
-    for (int w2 = 0; w2 < wave; ++w2) run += wave_tot[w2];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        hist[FS_BOUND_IDX(t * 16 + k)] = run;  // first slot of the bucket
-        run += loc[k];
-        E.cell_count[t * 16 + k] = 0;          // the histogram is all zeros between two boundaries
-    }
-    if (t == 0) E.cell_count[FS_GRID_BUCKETS] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int b = t + k * FS_BOUND_THREADS;
-        E.cell_fill[b] = b + 1 < FS_GRID_BUCKETS ? hist[FS_BOUND_IDX(b + 1)] : n;
-    }
-    // bucket-ordered copy of the predicted positions with the particle id in w (fs_k_grid_scatter), ranks from the tiles
-    for (int i = t; i < n; i += FS_BOUND_THREADS) {
-        const int code = E.cell_items[i];
-        const FsVec4 xp = fs_ld4o(E.xa, (unsigned)i);
-        const int slot = hist[FS_BOUND_IDX(code & (FS_GRID_BUCKETS - 1))] + (code >> 14);
-        fs_st4o(E.xb, (unsigned)slot, FsVec4{xp.x, xp.y, xp.z, __int_as_float(i)});
     }
 }
 

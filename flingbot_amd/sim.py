@@ -206,7 +206,7 @@ class FlingSim:
         return self._ck(self.lib.fs_last_kernel_form(self.h))
 
     def last_boundary_form(self):
-        """0 four kernels / 1 fs_k_boundary / 2 fs_k_boundary_wide in the most recent streaming launch (white box)."""
+        """0 four kernels / 1 fs_k_boundary in the most recent streaming launch (white box)."""
         return self._ck(self.lib.fs_last_boundary_form(self.h))
 
     def set_stream_groups(self, groups):

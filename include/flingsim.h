@@ -144,8 +144,7 @@ int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
 #define FS_FORM_FUSED_GRID64 8   /* fs_k_fused_grid64: 64-wide grid cloths, packed two-particle springs, no adjacency */
 int fs_last_kernel_form(const fs_ctx *ctx);
 /* white box: how the most recent streaming launch did its substep boundaries (finalize + predict + bucket sort): 0 = four
-   kernels, 1 = fs_k_boundary (one workgroup per episode), 2 = fs_k_boundary_wide (tiles of 4096 particles: cloths above one
-   tile in launches of fewer than 256 episodes) */
+   kernels (launches of fewer than 16 episodes, cloths above 16384 particles), 1 = fs_k_boundary (one launch per boundary) */
 int fs_last_boundary_form(const fs_ctx *ctx);
 /* Streaming back-end: a launch list that cannot fill the chip is split into `groups` slot ranges whose launch chains run
    concurrently on streams of their own (episodes are independent; results do not change).  0 = the library's measured

@@ -16,7 +16,6 @@ on distinct-seed episodes, and sampled episodes are compared with the CPU oracle
                           16 x 104x104 episodes (the upper end of the reference's cloth sizes, environment/tasks.py:108-121)
     fs_k_iterate<true>    64 x 64x64 episodes, FS_SOLVER_STREAM_CODED (non-canonical cloths at that size)
     fs_k_iterate<false>   64 x 64x64 episodes, FS_SOLVER_STREAM_ELL
-    fs_k_boundary_wide    the 104x104 batch and a launch that mixes 64 / 72 / 96-wide cloths (tiles of 4096 particles per workgroup)
     fs_k_boundary         every streaming case above (finalize + predict + bucket sort in one launch per substep boundary);
                           FS_SOLVER_STREAM_SPLIT (7) runs the 64-episode case with the four separate kernels that cloths
                           above 16384 particles take
@@ -336,7 +335,7 @@ def test_large_cloth_104_batch_bit_exact(gpu_required):
         setup(ctx.env(e), e)
     ctx.step(steps)
     assert ctx.last_kernel_form() == fsim.FS_FORM_STREAM_GRIDL
-    assert ctx.last_boundary_form() == 2      # fs_k_boundary_wide: three tiles of 4096 particles per episode
+    assert ctx.last_boundary_form() == 1      # fs_k_boundary: 11 particles per thread
     sample = [0, 9, 15]
     orcs = _oracle_runs([lambda o, s=s: setup(o, s) for s in sample], steps)
     for s, o in zip(sample, orcs):
@@ -346,11 +345,9 @@ def test_large_cloth_104_batch_bit_exact(gpu_required):
     ctx.close()
 
 
-def test_boundary_forms_on_mixed_cloth_sizes_bit_exact(gpu_required, monkeypatch):
-    """The substep boundary in its two one-launch forms on ONE launch list that mixes cloth sizes -- 64 x 64 (one tile), 72 x 72
-    (two tiles, the second almost empty), 96 x 96 (three tiles) -- so that the tiled form's per-episode ticket sees different
-    numbers of workgroups side by side: fs_k_boundary_wide (what such a launch gets) and fs_k_boundary (forced) give the
-    oracle's bits, and the histogram is left clean (a second run of steps continues correctly)."""
+def test_boundary_on_mixed_cloth_sizes_bit_exact(gpu_required):
+    """The one-launch substep boundary on ONE launch list that mixes cloth sizes -- 64 x 64, 72 x 72, 96 x 96 -- in two fs_step
+    calls (the second continues from the state the first left, histogram included): the oracle's bits."""
     from flingbot_amd import sim as fsim
 
     dims = [64, 72, 96, 72, 64, 96, 72, 64, 96, 72, 64, 96, 72, 64, 96, 72, 64, 96]
@@ -366,17 +363,12 @@ def test_boundary_forms_on_mixed_cloth_sizes_bit_exact(gpu_required, monkeypatch
 
     sample = [0, 1, 2, 17]
     orcs = _oracle_runs([lambda o, s=s: setup(o, s) for s in sample], steps)
-    for force, form in ((None, 2), ("0", 1)):
-        if force is None:
-            monkeypatch.delenv("FLINGSIM_BOUNDARY_WIDE", raising=False)
-        else:
-            monkeypatch.setenv("FLINGSIM_BOUNDARY_WIDE", force)
-        ctx = fsim.FlingSim(n_envs=len(dims), solver=fsim.FS_SOLVER_AUTO)
-        for e in range(len(dims)):
-            setup(ctx.env(e), e)
-        ctx.step(steps // 2)
-        ctx.step(steps - steps // 2)
-        assert ctx.last_boundary_form() == form
-        for s, o in zip(sample, orcs):
-            _assert_bits(ctx, s, o, f"boundary form {form}, episode {s} ({dims[s]} x {dims[s]})")
-        ctx.close()
+    ctx = fsim.FlingSim(n_envs=len(dims), solver=fsim.FS_SOLVER_AUTO)
+    for e in range(len(dims)):
+        setup(ctx.env(e), e)
+    ctx.step(steps // 2)
+    ctx.step(steps - steps // 2)
+    assert ctx.last_boundary_form() == 1
+    for s, o in zip(sample, orcs):
+        _assert_bits(ctx, s, o, f"episode {s} ({dims[s]} x {dims[s]})")
+    ctx.close()
