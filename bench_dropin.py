@@ -11,6 +11,7 @@ Workloads:
   picker  the call pattern of Picker.step around every simulation step (environment/flex_utils.py:104-205):
           get_shape_states + get_positions (Picker._get_pos), get_shape_states + set_shape_states + set_positions
           (Picker._set_pos), pyflex.step() -- on a 64 x 64 cloth with the two picker spheres.
+The 16-process case is run twice: as is, and with FLINGSIM_SHARED_GPU=1 (the module's switch for exactly this deployment).
 Processes: the reference runs one PyFleX per Ray worker (`--num_processes 16`, README.md:147-148, utils.py:144-157); here 16
 fresh interpreters, each with its own pyflex.init, started together and released by a wall-clock start time, share one
 MI355X.  The parent of the workers never touches the GPU.  Reported next to the batched face's numbers in bench.py.
@@ -68,11 +69,13 @@ def worker(mode, steps, start_at):
     print(json.dumps({"mode": mode, "steps": steps, "t0": t0, "t1": t1}), flush=True)
 
 
-def run(mode, n_procs, steps, timeout=300):
-    """n_procs fresh interpreters, released together; returns aggregate steps/s over [first start, last end]."""
+def run(mode, n_procs, steps, timeout=300, shared_gpu=False):
+    """n_procs fresh interpreters, released together; returns aggregate steps/s over [first start, last end].
+    shared_gpu: the workers run with FLINGSIM_SHARED_GPU=1 (csrc/pyflex_module.cpp: prefer the one-launch-per-frame kernel)."""
     start_at = time.time() + 6.0 + 0.5 * n_procs          # enough for every child to import, init and warm up
+    env = dict(os.environ, FLINGSIM_SHARED_GPU="1" if shared_gpu else "0")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", mode, "--steps", str(steps),
-                               "--start-at", repr(start_at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                               "--start-at", repr(start_at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
              for _ in range(n_procs)]
     recs, errs = [], []
     for p in procs:
@@ -90,7 +93,7 @@ def run(mode, n_procs, steps, timeout=300):
         return {"processes": n_procs, "error": str(errs[:2])}
     late = sum(1 for r in recs if r["t0"] > start_at + 0.05)
     span = max(r["t1"] for r in recs) - min(r["t0"] for r in recs)
-    return {"processes": n_procs, "finished": len(recs), "steps_per_process": steps, "seconds": span,
+    return {"processes": n_procs, "shared_gpu_switch": bool(shared_gpu), "finished": len(recs), "steps_per_process": steps, "seconds": span,
             "steps_per_s": sum(r["steps"] for r in recs) / span,
             "slowest_process_steps_per_s": min(r["steps"] / (r["t1"] - r["t0"]) for r in recs),
             "late_starters": late, "failed": len(errs)}
@@ -101,8 +104,12 @@ def measure(procs=(1, 16)):
            "note": "one cloth per process like the reference (Ray worker = PyFleX instance); every getter / setter is a "
                    "synchronous copy as in pyflex.cpp.  The batched face (FlingSim: all episodes of a process in one launch "
                    "sequence, movep on the device) is the supported throughput path; this is what unmodified callers get."}
-    out["c1_32x32_200_steps"] = [run("c1", n, 200) for n in procs]
-    out["picker_pattern_64x64"] = [run("picker", n, 200) for n in procs]
+    out["c1_32x32_200_steps"] = [run("c1", n, 200) for n in procs] + [run("c1", max(procs), 200, shared_gpu=True)]
+    out["picker_pattern_64x64"] = [run("picker", n, 200) for n in procs] + [run("picker", max(procs), 200, shared_gpu=True)]
+    out["shared_gpu_switch"] = ("FLINGSIM_SHARED_GPU=1 in the workers' environment: the module steps a cloth that fits it on the fused "
+                                "kernel (one launch per frame on one compute unit) instead of the streaming kernels (129 launches per "
+                                "frame): slower for a lone process, but sixteen of them run side by side where sixteen launch chains "
+                                "share the chip's dispatch rate")
     return out
 
 

@@ -61,16 +61,6 @@ __device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float 
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
     float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float inv_len = fs_rsqrt(l2);
-#ifdef FS_SPRING_U
-    if (!(l2 > 0.0f)) return;
-    float u = FS_FMA(-L, inv_len, 1.0f);
-    if (k < 0.0f) {
-        if (!(u > 0.0f)) return;
-        k = -k;
-    }
-    float ratio = fs_mass_ratio(wi, xj.w);
-    float sc = (k * ratio) * u;
-#else
     float len = l2 * inv_len;
     if (!(len > 0.0f)) return;
     float C = len - L;
@@ -80,7 +70,6 @@ __device__ __forceinline__ void fs_spring(FsAcc &a, float xi0, float xi1, float 
     }
     float ratio = fs_mass_ratio(wi, xj.w);
     float sc = (k * ratio) * (C * inv_len);
-#endif
     a.d0 = FS_FMA(-ex, sc, a.d0);
     a.d1 = FS_FMA(-ey, sc, a.d1);
     a.d2 = FS_FMA(-ez, sc, a.d2);
@@ -95,14 +84,8 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
     float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float inv_len = fs_rsqrt(l2);
-#ifdef FS_SPRING_U
-    const float C = FS_FMA(-L, inv_len, 1.0f), len = l2;  // (C = 1 - L / |e|: what the old form called C * inv_len)
-#define FS_CINV(C, inv) (C)
-#else
     float len = l2 * inv_len;
     float C = len - L;
-#define FS_CINV(C, inv) ((C) * (inv))
-#endif
     // (bitwise, not short-circuit, logic: short-circuit forms become exec-mask branches)
     const bool tether = k < 0.0f;
     const bool active = (len > 0.0f) & (!tether | (C > 0.0f));
@@ -118,7 +101,7 @@ __device__ __forceinline__ void fs_spring_bf(FsAcc &a, float xi0, float xi1, flo
     }
     // an inactive constraint contributes sc = +0: fma(-e, 0, d) == d for every finite e (the accumulators start at +0
     // and can never become -0), so one select on the scale replaces three on the accumulators
-    float sc = active ? (kk * ratio) * FS_CINV(C, inv_len) : 0.0f;
+    float sc = active ? (kk * ratio) * (C * inv_len) : 0.0f;
     a.d0 = FS_FMA(-ex, sc, a.d0);
     a.d1 = FS_FMA(-ey, sc, a.d1);
     a.d2 = FS_FMA(-ez, sc, a.d2);
@@ -135,12 +118,8 @@ __device__ __forceinline__ void fs_spring_bfm(FsAcc &a, float xi0, float xi1, fl
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
     float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float inv_len = fs_rsqrt(l2);
-#ifdef FS_SPRING_U
-    const float C = FS_FMA(-L, inv_len, 1.0f), len = l2;
-#else
     float len = l2 * inv_len;
     float C = len - L;
-#endif
     const bool tether = !POSK && k < 0.0f;
     const bool active = POSK ? (in & (len > 0.0f)) : (in & (len > 0.0f) & (!tether | (C > 0.0f)));
     const float kk = tether ? -k : k;
@@ -151,7 +130,7 @@ __device__ __forceinline__ void fs_spring_bfm(FsAcc &a, float xi0, float xi1, fl
         const bool odd = active & (wj != wi) & (wj != 0.0f);
         if (__builtin_amdgcn_ballot_w64(odd) != 0ull) ratio = odd ? wi / (wi + wj) : ratio;
     }
-    float sc = active ? (kk * ratio) * FS_CINV(C, inv_len) : 0.0f;
+    float sc = active ? (kk * ratio) * (C * inv_len) : 0.0f;
     a.d0 = FS_FMA(-ex, sc, a.d0);
     a.d1 = FS_FMA(-ey, sc, a.d1);
     a.d2 = FS_FMA(-ez, sc, a.d2);
@@ -167,14 +146,10 @@ __device__ __forceinline__ void fs_spring_fast(FsAcc &a, float xi0, float xi1, f
     float ex = xi0 - xj.x, ey = xi1 - xj.y, ez = xi2 - xj.z;
     float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
     float inv_len = fs_rsqrt(l2);
-#ifdef FS_SPRING_U
-    const float C = FS_FMA(-L, inv_len, 1.0f), len = l2;
-#else
     float len = l2 * inv_len;
     float C = len - L;
-#endif
     const bool active = len > 0.0f;
-    float sc = active ? kh * FS_CINV(C, inv_len) : 0.0f;
+    float sc = active ? kh * (C * inv_len) : 0.0f;
     a.d0 = FS_FMA(-ex, sc, a.d0);
     a.d1 = FS_FMA(-ey, sc, a.d1);
     a.d2 = FS_FMA(-ez, sc, a.d2);

@@ -109,13 +109,9 @@ __device__ __forceinline__ void fg_spring_pq(FgAcc2 &acc, fs_f2 xi0, fs_f2 xi1, 
     const float ez = xi2.x - xj2.x, fz = xi2.y - xj2.y;
     const float l2 = fs_dot3(ex, ey, ez, ex, ey, ez), m2 = fs_dot3(fx, fy, fz, fx, fy, fz);
     const float inv = fs_rsqrt(l2), jnv = fs_rsqrt(m2);
-#ifdef FS_SPRING_U
-    const float sc = kP * FS_FMA(-LP, inv, 1.0f), sd = kQ * FS_FMA(-LQ, jnv, 1.0f);
-#else
     const float len = l2 * inv, men = m2 * jnv;
     const float C = len - LP, D = men - LQ;
     const float sc = kP * (C * inv), sd = kQ * (D * jnv);
-#endif
     acc.d0.x = FS_FMA(-ex, sc, acc.d0.x); acc.d0.y = FS_FMA(-fx, sd, acc.d0.y);
     acc.d1.x = FS_FMA(-ey, sc, acc.d1.x); acc.d1.y = FS_FMA(-fy, sd, acc.d1.y);
     acc.d2.x = FS_FMA(-ez, sc, acc.d2.x); acc.d2.y = FS_FMA(-fz, sd, acc.d2.y);

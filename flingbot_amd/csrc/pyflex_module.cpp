@@ -28,6 +28,7 @@ static void fail(const char *what) { throw std::runtime_error(std::string(what) 
 static void ck(int rc, const char *what) {
     if (rc < 0) fail(what);
 }
+static int g_shared_gpu = -1;  // FLINGSIM_SHARED_GPU (see pyflex_step): -1 unread, 0 off, 1 on, 2 on but the scene does not fit
 static fs_ctx *ctx() {
     if (!g_ctx) throw std::runtime_error("pyflex.init() has not been called");
     return g_ctx;
@@ -54,6 +55,7 @@ static void pyflex_set_scene(int scene_idx, farr scene_params, farr vertices, ia
                              iarr shear_edges, iarr faces, int thread_idx) {
     (void)thread_idx;
     if (scene_idx != 0) throw std::runtime_error("pyflex.set_scene: only scene_idx 0 (SoftgymCloth) exists");
+    if (g_shared_gpu == 2) g_shared_gpu = 1;
     ck(fs_set_scene(ctx(), 0, scene_params.data(), (int)scene_params.size(), vertices.data(), (int)vertices.size(),
                     stretch_edges.data(), (int)stretch_edges.size(), bend_edges.data(), (int)bend_edges.size(),
                     shear_edges.data(), (int)shear_edges.size(), faces.data(), (int)faces.size()),
@@ -61,9 +63,26 @@ static void pyflex_set_scene(int scene_idx, farr scene_params, farr vertices, ia
 }
 
 // pyflex.cpp:213-222: update_params / capture / path are ignored by the cloth scene; render only toggles drawing
+// FLINGSIM_SHARED_GPU=1: this process is one of many that share the GPU, the way the reference runs its environments (one PyFleX
+// per Ray worker, `--num_processes 16`, README.md:147-148).  A lone cloth steps fastest on the streaming kernels (129 small
+// launches spread over the chip), but the chip dispatches ~250 k such launches per second IN TOTAL, so sixteen processes doing
+// that share one process's rate; the fused kernel is ONE launch per frame on one compute unit, and sixteen of those do run side
+// by side.  With the switch the module prefers the fused kernel whenever the cloth fits it (<= 4096 particles) and falls back to
+// AUTO when it does not.  Results are identical either way.
 static void pyflex_step(py::object update_params, int capture, py::object path, int render) {
     (void)update_params; (void)capture; (void)path; (void)render;
-    ck(fs_step(ctx(), 0, 1), "pyflex.step");
+    if (g_shared_gpu < 0) {
+        const char *s = std::getenv("FLINGSIM_SHARED_GPU");
+        g_shared_gpu = (s && std::atoi(s) != 0) ? 1 : 0;
+    }
+    if (g_shared_gpu == 1 && fs_get_solver(ctx()) != FS_SOLVER_FUSED) fs_set_solver(ctx(), FS_SOLVER_FUSED);
+    int rc = fs_step(ctx(), 0, 1);
+    if (rc == FS_ERR_STATE && g_shared_gpu == 1) {  // the cloth does not fit the LDS-resident kernel
+        fs_set_solver(ctx(), FS_SOLVER_AUTO);
+        g_shared_gpu = 2;                           // (asked for, not applicable to this scene; set_scene re-arms it)
+        rc = fs_step(ctx(), 0, 1);
+    }
+    ck(rc, "pyflex.step");
 }
 
 static std::tuple<py::array_t<unsigned char>, py::array_t<float>> pyflex_render() {
