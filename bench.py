@@ -218,6 +218,28 @@ def oracle_trajectory(seed, steps):
     return o.get_positions(), o.get_velocities()
 
 
+def mfma_from_profile():
+    """MFMA utilisation of the value network's block kernel from the committed rocprofv3 --pmc pass (scripts/profile_cnn.sh):
+    SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 flops over the kernel's summed duration = fp32 MFMA flops ISSUED per second (useful work
+    + the 12.5 % halo the fused blocks recompute), against the 157.3 TFLOP/s dense fp32-MFMA peak."""
+    import re
+    for tag in ("r04", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_cnn_pmc.txt")
+        try:
+            for line in open(path):
+                if line.startswith("fs_k_vn_block") and "SQ_INSTS_VALU_MFMA_MOPS_F32" in line:
+                    us = float(re.search(r"([0-9.]+) us total", line).group(1))
+                    mops = float(re.search(r"SQ_INSTS_VALU_MFMA_MOPS_F32=([0-9.e+]+)", line).group(1))
+                    n = int(re.search(r"launches\s+(\d+)", line).group(1))
+                    tf = mops * 512 / (us * 1e-6) / 1e12
+                    return {"source": f"profiles/{tag}_cnn_pmc.txt", "kernel": "fs_k_vn_block", "launches": n,
+                            "average_us": us / n, "mfma_tflops_issued_f32": tf, "mfma_frac_of_peak": tf / 157.3,
+                            "counter": "SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / summed kernel duration"}
+        except Exception:
+            continue
+    return None
+
+
 def perception_leg(device):
     """Secondary, after the timed region (rank 0, N = 1): the per-action perception kernels of the same path on this GPU --
     SpatialValueNet forward of one observation (96 transforms x 64 x 64, random-init weights, hand-written fp32-MFMA
@@ -240,6 +262,7 @@ def perception_leg(device):
         out = {"value_net_ms_per_observation": ms, "value_net_useful_tflops_f32": 96 * 306.7e6 / (ms * 1e-3) / 1e12,
                "value_net_fraction_of_f32_mfma_peak": 96 * 306.7e6 / (ms * 1e-3) / 1e12 / 157.3,
                "value_net_path": "fs_value_net_forward" if net._hip is not None else "pytorch"}
+        out["value_net_mfma"] = mfma_from_profile()
         out.update(render_leg(device.index or 0))
         return out
     except Exception as exc:  # the headline number must not depend on this leg

@@ -275,6 +275,7 @@ class StubSim:
         sim = self
         class View:
             def set_scene(self, p): pass
+            def step(self, n=1): pass
             def get_positions(self): return np.full(4 * 4096, 8192.0, np.float32)
             def set_positions(self, p):
                 sim.pos[e] = np.array(p, np.float32)
@@ -294,14 +295,24 @@ class StubSim:
     def set_positions(self, e, p): self.pos[e] = np.array(p, np.float32)
     def set_velocities(self, e, v): pass
     def close(self): LOG.append(("close", self.n_envs))
+    # what the C2 entries touch beyond the above (bench.c2_crumple / c2_fling_script / FlingPrimitives.place_pickers)
+    def set_particles(self, envs, pids, pos4, zero_velocity=True): pass
+    def step_list(self, envs, n=1): self.steps += n; LOG.append(("step_list", n))
+    def movep(self, envs, targets, grasp, speed=0.1, limit=1000, min_steps=None, eps=1e-4):
+        self.last_movep_steps = 3 * len(envs); LOG.append(("movep", len(envs))); return np.full(len(envs), 3, np.int32)
+    def add_sphere(self, e, radius, pos, quat): self.shapes = getattr(self, "shapes", {}); self.shapes.setdefault(e, []).append(list(pos))
+    def get_shape_states(self, e): return np.zeros(14 * len(self.shapes.get(e, [])), np.float32)
+    def set_shape_states(self, e, s): pass
+    def picker_reset(self, e, *a, **k): pass
 
 fsim.FlingSim = StubSim
 import bench
 args = types.SimpleNamespace(episodes=4, steps=3, warmup=1, preroll=2, solver=2, no_parity=True, no_cpu_baseline=True,
-                             no_secondary=False, no_eval_loop=True, no_c2=True, no_dropin=True, gpus=int(os.environ["WORLD_SIZE"]))
+                             no_secondary=False, no_eval_loop=True, no_c2=os.environ["WORLD_SIZE"] != "2", no_dropin=True,
+                             gpus=int(os.environ["WORLD_SIZE"]))
 bench.run_rank(args)
 seeds_ok = all(np.array_equal(s.first_pos[e], bench.initial_state(RANK * s.n_envs + e, 8192.0).ravel())
-               for s in StubSim.instances for e in range(s.n_envs))
+               for s in StubSim.instances[:2] for e in range(s.n_envs))
 with open(os.path.join(os.environ["FS_OUT"], f"rank{RANK}.json"), "w") as fh:
     json.dump({"log": LOG, "seeds_ok": bool(seeds_ok), "sizes": [s.n_envs for s in StubSim.instances]}, fh)
 """
@@ -316,6 +327,9 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
     barrier + synchronize -> max-over-ranks; the secondary entry is 64 episodes per rank = 128 over 2 GPUs (configs[3]'s
     shape: 512 at 8), three windows of 100 frames, on every rank."""
     import json
+    sys.path.insert(0, ROOT)
+    import bench as _bench
+    bench_fling_settle = _bench.C2_FLING_SETTLE
 
     script = tmp_path / "bench_worker.py"
     script.write_text(BENCH_WORKER)
@@ -349,9 +363,15 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
     assert sec["steps"] == 100 and sec["value_min"] <= sec["value"] <= sec["value_max"]
     assert sec["value"] == pytest.approx(64 * world * 100 / (sec["ms_per_step"] * 0.1)) and sec["ms_per_step"] >= 3.0
     assert sec["mean_coverage"] == pytest.approx(np.mean([1000.0 * r + e for r in range(world) for e in range(64)]))
+    if world == 2:   # the C2 / C3 entries: every rank crumples and flings its own episodes, the step counts are summed over ranks
+        c2a, c2b = rec["configs"][2], rec["configs"][3]
+        assert c2a["episodes_per_gpu"] == 4 and c2b["episodes_per_gpu"] == 64 and "C2 scripted fling" in c2a["name"]
+        per_rank = 7 * 3 * 4 + 4 * bench_fling_settle    # seven movep legs of 3 steps per episode + the settle steps
+        assert c2a["episode_steps"] == 2 * per_rank and c2a["value"] == pytest.approx(c2a["episode_steps"] / c2a["seconds"])
+        assert rec["fling_phase_ratio"] == pytest.approx(c2a["value"] / rec["value"])
     for r in range(world):
         got = json.load(open(tmp_path / f"rank{r}.json"))
-        assert got["seeds_ok"] and got["sizes"] == [4, 64]
+        assert got["seeds_ok"] and got["sizes"] == ([4, 64, 4, 64] if world == 2 else [4, 64])   # (+ the two C2 contexts at world 2)
         log = [tuple(x) for x in got["log"]]
         assert log[0] == ("set_device", r) and log[1] == ("init", "nccl")
         ev = [e for e, _ in log]
@@ -364,7 +384,7 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
                                   "cuda_sync", "max"]
         assert log[t0 + 5] == ("gather", "cuda") and log[t0 + 9] == ("max", "cuda")
         # secondary: three bracketed windows of 100 steps each on the 64-episode context
-        starts = [i for i, e in enumerate(ev) if e == "timer_start"][1:]
+        starts = [i for i, e in enumerate(ev) if e == "timer_start"][1:4]
         assert len(starts) == 3
         for i in starts:
             assert ev[i - 3:i] == ["barrier", "ctx_sync", "cuda_sync"]

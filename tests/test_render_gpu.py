@@ -203,6 +203,32 @@ def test_render_matches_raster_oracle(gpu_required, side, seed):
     diff = np.abs(a[:, :3] - b[:, :3])
     assert diff.max() <= 1, f"max colour difference {diff.max()}"
     assert (diff > 0).mean() < 0.02
+    # ... and with NOTHING of the product on the checker's side: the camera / light matrices printed by the reference's own
+    # core/maths.cpp (oracle/_ref/camera_ref, compiled by oracle/Makefile where the reference lies; the binary travels) and the
+    # vertex normals the oracle computes from the positions (main.cpp:904-919).  The product's matrices agree with the
+    # reference's to 2e-6, so a handful of silhouette pixels may land on the other side of an edge: tolerances, not bits -- but a
+    # wrong camera, light or normal would move every pixel.
+    import os
+    import subprocess
+    from oracle import OracleSim
+    from conftest import cloth_params
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "camera_ref")
+    if os.path.exists(exe):
+        out = subprocess.run([exe] + [repr(float(v)) for v in (*cam[2:8], cam[0], cam[1], *lo, *up)], capture_output=True, text=True,
+                             check=True).stdout
+        rows = {ln.split()[0]: np.array(ln.split()[1:], np.float64).astype(np.float32) for ln in out.splitlines() if ln.strip()}
+        ref_mats = np.concatenate([rows["view"], rows["proj"], rows["light"], rows["lightpos"], rows["lightdir"]])
+        assert np.abs(ref_mats - mats).max() <= 2e-5 * max(1.0, float(np.abs(ref_mats).max()))
+        orc = OracleSim()
+        orc.set_scene(cloth_params(side, side, pos=(0.0, -0.2, 0.0)))
+        orc.set_positions(env.get_positions())
+        ind_rgba, ind_depth = orc_render(ref_mats, cam[2:5], int(cam[0]), int(cam[1]), orc.get_positions(), orc.get_normals(),
+                                         orc.get_faces(), env.get_shape_states(), [0.02, 0.02])
+        dd = np.abs(depth - ind_depth)
+        assert (dd <= 2e-5).mean() >= 0.999, f"{(dd > 2e-5).sum()} depth pixels off against the independent render"
+        c2 = np.abs(a[:, :3] - ind_rgba.reshape(-1, 4).astype(int)[:, :3]).max(1)
+        assert (c2 <= 2).mean() >= 0.995, f"{(c2 > 2).sum()} colour pixels off against the independent render"
     # the scene really contains all three kinds of primitives
     d = depth.reshape(720, 720)
     assert ((d > 1.55) & (d < 1.65)).sum() > 50 and ((d > 1.85) & (d < 1.95)).sum() > 50  # spheres at y = 0.4 and 0.1
