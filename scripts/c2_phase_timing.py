@@ -13,12 +13,26 @@ ctx = fsim.FlingSim(n_envs=E, solver=0)
 bench.c2_crumple(ctx, list(range(E)))
 ctx.sync()
 ctx.timer_start(); ctx.step(20); ms = ctx.timer_stop()
-print("crumpled by C2's recipe, no pickers: %.3f ms per step" % (ms / 20))
+print("crumpled by C2's recipe, no pickers: %.3f ms per step (one launch of 20 frames)" % (ms / 20))
+ctx.timer_start()
+for _ in range(20):
+    ctx.step(1)
+ms = ctx.timer_stop()
+print("                                     %.3f ms per step (20 launches of one frame)" % (ms / 20))
 prim = FlingPrimitives(ctx, range(E))
 for e in range(E):
     prim.place_pickers(e)
 ctx.timer_start(); ctx.step(20); ms = ctx.timer_stop()
-print("the same with the two pickers parked above: %.3f ms per step" % (ms / 20))
+print("the same with the two pickers parked above: %.3f ms per step (one launch of 20 frames)" % (ms / 20))
+ctx.timer_start()
+for _ in range(20):
+    ctx.step(1)
+ms = ctx.timer_stop()
+print("                                            %.3f ms per step (20 launches of one frame)" % (ms / 20))
+stay = np.stack([ctx.get_shape_states(e).reshape(-1, 14)[:, :3] for e in range(E)]).astype(np.float64)
+stay[:, :, 1] += 1e-3 * 20
+ctx.timer_start(); ctx.movep(np.arange(E, dtype=np.int32), stay, np.zeros((E, 2), int), speed=1e-3, limit=2000); ms = ctx.timer_stop()
+print("                                            %.3f ms per step (movep of 20 steps, pickers creeping upwards, nothing grasped)" % (ms / max(ctx.last_movep_steps / E, 1)))
 corners = np.stack([ctx.get_positions(e).reshape(-1, 4)[[0, 63], :3] for e in range(E)]).astype(np.float64)
 envs = np.arange(E, dtype=np.int32)
 
