@@ -533,7 +533,6 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
     // fails, so that an error return leaves the host describing what the device really executed
     struct Undo { int env; char over; int gen; bool shapes; FsShapesDev sh; };
     std::vector<Undo> undo;
-    const long long movep_steps_planned = ctx->last_movep_steps;
     auto rollback = [&]() {
         for (const Undo &u : undo) {
             ctx->wait_over[u.env] = u.over; ctx->wait_gen[u.env] = u.gen;
@@ -541,7 +540,6 @@ static int advance_begin(fs_ctx *ctx, int n, const int *envs, const int *kind, c
         }
         ctx->last_movep_steps = 0;
     };
-    (void)movep_steps_planned;
     for (int q = 0; q < nw_all; ++q) {
         const int a = waiters[q];
         if (start[a] >= 0 && limit[a] - start[a] <= 0) {  // wait_until_stable returns False, plain steps are done
