@@ -598,10 +598,11 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
             particles += (size_t)ctx->envs[id].host.n;
             grid64 = grid64 && ctx->envs[id].dev.g64_ok;
         }
-        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py, end of round 2, concurrent
-        // chains): streaming 1.20 / 1.74 / 3.46 ms per step at 64 / 128 / 256 episodes against a flat 2.39-2.46 ms of the
-        // grid-64 fused kernel (~176 episodes); the dictionary-coded fused kernel (2.9 ms) crosses at ~214
-        if (particles < (size_t)(grid64 ? 176 : 214) * 4096) solver = FS_SOLVER_STREAM;
+        // measured crossover on the crumpled 64x64 bench scenario (scripts/solver_crossover.py; round 4, hardware reciprocal
+        // root): streaming 1.46 / 1.73 / 1.95 / 2.15 / 2.31 / 2.61 / 3.62 ms per step at 96 / 128 / 144 / 160 / 176 / 192 / 256
+        // episodes against a flat 2.04-2.16 ms of the grid-64 fused kernel (~158 episodes) and 2.46-2.63 ms of the
+        // dictionary-coded fused kernel (~190)
+        if (particles < (size_t)(grid64 ? 160 : 192) * 4096) solver = FS_SOLVER_STREAM;
     } else if (solver == FS_SOLVER_FUSED) {
         for (int id : ids)
             if (!fs_fused_supported(ctx, ctx->envs[id])) {
