@@ -113,3 +113,26 @@ def test_evaluation_loop_runs_from_a_stored_task_file(gpu_required, tmp_path):
     for k in ("init_coverage", "final_coverage", "episode_length", "coverage_steps"):
         assert np.array_equal(a[k], b[k]), k
     assert a["action_primitive_counts"] == b["action_primitive_counts"] and a["simulation_steps"] == b["simulation_steps"]
+
+
+@pytest.mark.gpu
+def test_evaluate_command_line_runs_a_stored_set(gpu_required, tmp_path, capsys):
+    """`python -m flingbot_amd.evaluate --tasks set.npz` (run_sim.py --eval on a converted task set): generated tasks -> file ->
+    the command's own main() -> one JSON line with the reference's summary statistics."""
+    import json
+    import torch
+    from flingbot_amd import evaluate, sim as fsim, taskio, tasks as ftasks
+
+    random.seed(4); np.random.seed(4); torch.manual_seed(4)
+    gen = fsim.FlingSim(n_envs=3, solver=0)
+    made = [t for t in ftasks.generate_tasks(gen, [ftasks.draw_task_parameters(min_cloth_size=24, strict_min_edge_length=24,
+                                                                              max_cloth_size=30) for _ in range(3)]) if t is not None]
+    gen.close()
+    path = str(tmp_path / "set.npz")
+    taskio.save_tasks(path, made)
+    capsys.readouterr()
+    evaluate.main(["--tasks", path, "--slots", "2", "--episode-length", "1"])
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["tasks"] == len(made) and rec["episode_length"] == 1.0 and rec["simulation_steps"] > 0
+    assert 0.0 < rec["init_coverage"] < 1.05 and set(rec["action_primitive_counts"]) == {"fling"}
