@@ -81,7 +81,8 @@ def eval_rsqrt(x):
 def _load(variant=None):
     if variant in _libs:
         return _libs[variant]
-    assert variant is None or variant in VARIANTS or (variant.startswith("alt_") and variant[4:] in MODEL_ALTERNATIVES), variant
+    assert variant is None or variant in VARIANTS or (
+        variant.startswith("alt_") and all(a in MODEL_ALTERNATIVES for a in variant[4:].split("+"))), variant   # "alt_a+b": both
     path = oracle_lib_path() if variant is None else os.path.join(_HERE, f"liboracle_{variant}.so")
     if variant is not None and variant.startswith("alt_"):
         srcs = [os.path.join(_HERE, f) for f in ("flex_oracle.c", "flex_oracle.h", "Makefile")]

@@ -139,9 +139,54 @@ def render(out, scenarios=("c1", "c2", "fling")):
     return "\n".join(lines)
 
 
+def _fit_one(job):
+    path, variant = job
+    import test_external_fixtures as tef
+    from oracle import OracleSim
+
+    res = tef.replay_pyflex_fixture(path, lambda: OracleSim(variant))
+    return variant, {name: (float(np.median(r["resync"])), float(max(r["resync"])), float(r["free"][-1])) for name, r in res.items()}
+
+
+def fit_fixture(path, jobs=8, pairs=False):
+    """Which reading of the solver does a recorded PyFleX fixture (tests/golden/capture_pyflex.py) agree with?  Replays the
+    fixture's scenarios on the default oracle and on every single alternative (pairs=True: also every pair), re-synchronised at
+    every recorded frame, and returns [(variant, {scenario: (median, max one-interval error, free-running end error)})] sorted
+    by the worst scenario's median: the reading at the top is the one to adopt (or to combine further)."""
+    import itertools
+    alts = [v for v, _ in ROWS if v.startswith("alt_")]
+    variants = [None] + alts
+    if pairs:
+        excl = {"alt_sleep_velocity_only", "alt_sleep_at_predict", "alt_no_sleep"}
+        variants += ["alt_" + a[4:] + "+" + b[4:] for a, b in itertools.combinations(alts, 2) if not (a in excl and b in excl)]
+    for v in variants:   # build the libraries before the pool forks (make is not re-entrant on one target)
+        if v is not None:
+            from oracle.flex import _load
+            _load(v)
+    with Pool(min(jobs, len(variants))) as pool:
+        res = pool.map(_fit_one, [(path, v) for v in variants], chunksize=1)
+    # worst scenario's median, then its maximum; ties keep the order default, singles, pairs (a no-op alternative -- the list
+    # truncation rule on these workloads -- ties with whatever it is combined with)
+    return sorted(res, key=lambda vr: (max(m for m, _, _ in vr[1].values()), max(x for _, x, _ in vr[1].values())))
+
+
+def render_fit(res):
+    names = sorted(res[0][1])
+    lines = ["| reading | " + " | ".join(f"{n}: median / max per interval, free-running end" for n in names) + " |", "|---|" + "---|" * len(names)]
+    for v, per in res:
+        lines.append(f"| `{v or 'default oracle'}` | " + " | ".join("%.1e / %.1e, %.1e" % per[n] for n in names) + " |")
+    return "\n".join(lines)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--quick", action="store_true", help="32 x 32 cloths, shorter phases (what the CPU test runs)")
+    ap.add_argument("--quick", action="store_true", help="24 x 24 cloths, shorter phases (what the CPU test runs)")
     ap.add_argument("--jobs", type=int, default=8)
+    ap.add_argument("--fixture", default=None, help="a PyFleX fixture (tests/golden/capture_pyflex.py): rank the default oracle and "
+                                                    "every alternative reading by their one-interval error against it")
+    ap.add_argument("--pairs", action="store_true", help="with --fixture: also every pair of alternatives")
     a = ap.parse_args()
-    print(render(table(a.quick, a.jobs)))
+    if a.fixture:
+        print(render_fit(fit_fixture(a.fixture, a.jobs, a.pairs)))
+    else:
+        print(render(table(a.quick, a.jobs)))

@@ -128,6 +128,29 @@ def test_pyflex_fixture_ingest_path_on_a_self_made_fixture(self_made_fixture, ca
         print("\n" + _report(other, "oracle[alt_damping_mult]"))
 
 
+def test_a_fixture_identifies_the_reading_that_made_it(tmp_path):
+    """tests/parity_table.py --fixture: the tool that tells, the day a PyFleX fixture exists, WHICH reading of the closed solver it
+    agrees with.  Proved on fixtures whose answer is known: one recorded from the default oracle ranks the default first with
+    zero error, one recorded from an oracle with two model choices changed (friction after the solve + applyDeltas per
+    constraint type) ranks exactly that pair first with zero error, above either single change."""
+    import parity_table as pt
+    from oracle import OracleSim
+
+    kit = _kit("capture_pyflex")
+    for maker, expect in ((None, None), ("alt_friction_post+apply_per_type", "alt_friction_post+apply_per_type")):
+        path = str(tmp_path / f"fix_{expect}.npz")
+        kit.capture(lambda: OracleSim(maker), path, names=("fling",), every=1, dim=12, quick=True, backend="oracle")
+        ranked = pt.fit_fixture(path, jobs=8, pairs=True)
+        best, per = ranked[0]
+        assert best == expect and max(mx for _, mx, _ in per.values()) == 0.0, (best, per)
+        worst = {v: max(mx for _, mx, _ in p.values()) for v, p in ranked}
+        # every reading that really differs from the maker is off; the list-truncation alternative is a no-op here and ties
+        for v in ("alt_friction_post", "alt_apply_per_type", "alt_stiffness_iter", "alt_damping_mult", "alt_shape_end_pose"):
+            assert worst[v] > 0.0, v
+        assert worst[None] == (0.0 if expect is None else worst[None]) and (expect is None or worst[None] > 0.0)
+        assert worst["alt_neighbors_by_distance"] == worst[None]
+
+
 @pytest.mark.gpu
 def test_hip_path_replays_the_self_made_fixture_bit_for_bit(gpu_required, self_made_fixture):
     from flingbot_amd import sim as fsim
