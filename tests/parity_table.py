@@ -148,13 +148,13 @@ def _fit_one(job):
     return variant, {name: (float(np.median(r["resync"])), float(max(r["resync"])), float(r["free"][-1])) for name, r in res.items()}
 
 
-def fit_fixture(path, jobs=8, pairs=False):
+def fit_fixture(path, jobs=8, pairs=False, only=None):
     """Which reading of the solver does a recorded PyFleX fixture (tests/golden/capture_pyflex.py) agree with?  Replays the
     fixture's scenarios on the default oracle and on every single alternative (pairs=True: also every pair), re-synchronised at
     every recorded frame, and returns [(variant, {scenario: (median, max one-interval error, free-running end error)})] sorted
     by the worst scenario's median: the reading at the top is the one to adopt (or to combine further)."""
     import itertools
-    alts = [v for v, _ in ROWS if v.startswith("alt_")]
+    alts = [v for v, _ in ROWS if v.startswith("alt_") and (only is None or v in only)]   # only: restrict the search (tests)
     variants = [None] + alts
     if pairs:
         excl = {"alt_sleep_velocity_only", "alt_sleep_at_predict", "alt_no_sleep"}

@@ -140,7 +140,8 @@ def test_a_fixture_identifies_the_reading_that_made_it(tmp_path):
     for maker, expect in ((None, None), ("alt_friction_post+apply_per_type", "alt_friction_post+apply_per_type")):
         path = str(tmp_path / f"fix_{expect}.npz")
         kit.capture(lambda: OracleSim(maker), path, names=("fling",), every=1, dim=12, quick=True, backend="oracle")
-        ranked = pt.fit_fixture(path, jobs=8, pairs=True)
+        ranked = pt.fit_fixture(path, jobs=8, pairs=True, only=("alt_friction_post", "alt_apply_per_type", "alt_stiffness_iter",
+                                                                "alt_damping_mult", "alt_shape_end_pose", "alt_neighbors_by_distance"))
         best, per = ranked[0]
         assert best == expect and max(mx for _, mx, _ in per.values()) == 0.0, (best, per)
         worst = {v: max(mx for _, mx, _ in p.values()) for v, p in ranked}
