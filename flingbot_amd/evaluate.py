@@ -183,26 +183,41 @@ def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=None, **k
 
 
 def main(argv=None):
-    """python -m flingbot_amd.evaluate --tasks set.npz [--weights flingbot.pth] [--slots 96] [--episode-length 10]
+    """python -m flingbot_amd.evaluate --tasks set.npz [--weights flingbot.pth] [--slots 96] [--episode-length 10] [--gpus N]
 
     run_sim.py's evaluation (run_sim.py:37-109 with --eval: fling policy, 12 rotations x 8 scales, obs_dim 64) on a task
-    set converted by scripts/convert_tasks_hdf5.py; prints the reference's summary statistics as one JSON line."""
+    set converted by scripts/convert_tasks_hdf5.py; prints the reference's summary statistics as one JSON line.
+    --gpus N > 1 (or a launch under torch.distributed.run): one process per GPU, the task set cut into contiguous blocks
+    (run_episodes_sharded), per-episode coverages gathered over RCCL; rank 0 prints the statistics of ALL episodes."""
     import argparse
     import json
-
-    from . import nets, sim as fsim, taskio
-    from .env import BatchedFlingEnv
+    import os
+    import sys
 
     ap = argparse.ArgumentParser(description=main.__doc__)
     ap.add_argument("--tasks", required=True, help=".npz task set (flingbot_amd/taskio.py; scripts/convert_tasks_hdf5.py makes it)")
     ap.add_argument("--weights", default=None, help="checkpoint with the reference's state_dict layout (flingbot.pth)")
-    ap.add_argument("--slots", type=int, default=96, help="episodes resident on the GPU at a time")
+    ap.add_argument("--slots", type=int, default=96, help="episodes resident on a GPU at a time")
     ap.add_argument("--episode-length", type=int, default=10)
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, else 0)")
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args(argv)
+    if a.gpus > 1 and os.environ.get("WORLD_SIZE") is None:   # start the ranks ourselves, before this process touches the GPU
+        from .launch import launch_local_ranks
+        # (`python -m flingbot_amd.evaluate ...` again, once per rank, from the same working directory)
+        sys.exit(launch_local_ranks(a.gpus, "-m", ["flingbot_amd.evaluate"] + list(sys.argv[1:] if argv is None else argv)))
+
+    from . import distributed as fdist, nets, sim as fsim, taskio
+    from .env import BatchedFlingEnv
+
+    rank, local_rank, world = fdist.init_from_env("nccl") if os.environ.get("WORLD_SIZE") else (0, 0, 1)
+    device = local_rank if a.device is None else a.device
     tasks = taskio.TaskLoader(a.tasks, repeat=False).all_tasks()
-    dev = f"cuda:{a.device}"
-    ctx = fsim.FlingSim(n_envs=min(a.slots, len(tasks)), device=a.device, solver=0)
+    per_rank = (len(tasks) + world - 1) // world
+    mine = tasks[rank * per_rank:(rank + 1) * per_rank]
+    dev = f"cuda:{device}"
+    torch.cuda.set_device(device)
+    ctx = fsim.FlingSim(n_envs=max(1, min(a.slots, len(mine))), device=device, solver=0)
     env = BatchedFlingEnv(ctx, episode_length=a.episode_length, device=dev)
     policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
                                      obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
@@ -211,10 +226,24 @@ def main(argv=None):
     if a.weights:
         ckpt = torch.load(a.weights, map_location=dev)
         policy.load_state_dict(ckpt.get("net", ckpt))          # utils.py:116-118 stores the module under 'net'
-    stats = run_tasks(policy, env, tasks)
+    stats = run_tasks(policy, env, mine)
     ctx.close()
-    print(json.dumps({"tasks": len(tasks), **stats["mean"], "action_primitive_counts": stats["action_primitive_counts"],
-                      "simulation_steps": stats["simulation_steps"]}))
+    out = {"tasks": len(tasks), **stats["mean"], "action_primitive_counts": stats["action_primitive_counts"],
+           "simulation_steps": stats["simulation_steps"]}
+    if world > 1:   # every rank's per-episode coverages, in task order (ranks hold contiguous blocks; the last may be shorter)
+        pad = lambda v: np.concatenate([np.asarray(v, np.float32), np.full(per_rank - len(v), np.nan, np.float32)])  # noqa: E731
+        init = fdist.gather_rewards(pad(stats["init_coverage"]), device=dev).cpu().numpy()
+        final = fdist.gather_rewards(pad(stats["final_coverage"]), device=dev).cpu().numpy()
+        steps = fdist.gather_rewards([float(stats["simulation_steps"])], device=dev).cpu().numpy()
+        keep = ~np.isnan(init)
+        out.update({"gpus": world, "init_coverage": float(init[keep].mean()), "final_coverage": float(final[keep].mean()),
+                    "episode_delta_coverage": float((final[keep] - init[keep]).mean()), "simulation_steps": int(steps.sum()),
+                    "note": "coverages over all ranks; best_coverage / episode_length / action counts are rank 0's"})
+        fdist.barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if os.environ.get("WORLD_SIZE") and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

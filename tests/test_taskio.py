@@ -136,3 +136,16 @@ def test_evaluate_command_line_runs_a_stored_set(gpu_required, tmp_path, capsys)
     rec = json.loads(line)
     assert rec["tasks"] == len(made) and rec["episode_length"] == 1.0 and rec["simulation_steps"] > 0
     assert 0.0 < rec["init_coverage"] < 1.05 and set(rec["action_primitive_counts"]) == {"fling"}
+    # the same as ONE rank of a torch.distributed.run launch (process group on RCCL, LOCAL_RANK -> device): same statistics
+    import subprocess
+    import socket
+    import sys
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, "-m", "flingbot_amd.evaluate", "--tasks", path, "--slots", "2", "--episode-length", "1"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec2 = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    # (the policy is random-initialised per process, so the actions differ; the tasks and the statistics' shape do not)
+    assert rec2["tasks"] == rec["tasks"] and rec2["init_coverage"] == rec["init_coverage"] and set(rec2) == set(rec)
