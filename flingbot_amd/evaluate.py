@@ -182,6 +182,23 @@ def run_episodes_sharded(policy, env, tasks, episodes_per_rank, runner=None, **k
     return stats
 
 
+def merge_rank_statistics(stats, per_rank, device=None):
+    """The per-episode coverages of every rank's run_tasks statistics, gathered in task order (ranks hold contiguous blocks of
+    `per_rank` tasks; the last block may be shorter) and reduced to the summary the command line prints."""
+    from . import distributed as fdist
+
+    pad = lambda v: np.concatenate([np.asarray(v, np.float32), np.full(per_rank - len(v), np.nan, np.float32)])  # noqa: E731
+    init = fdist.gather_rewards(pad(stats["init_coverage"]), device=device).cpu().numpy()
+    final = fdist.gather_rewards(pad(stats["final_coverage"]), device=device).cpu().numpy()
+    steps = fdist.gather_rewards([float(stats["simulation_steps"])], device=device).cpu().numpy()
+    keep = ~np.isnan(init)
+    _, _, world = fdist.init_from_env()
+    return {"gpus": world, "episodes": int(keep.sum()), "init_coverage": float(init[keep].mean()),
+            "final_coverage": float(final[keep].mean()), "episode_delta_coverage": float((final[keep] - init[keep]).mean()),
+            "simulation_steps": int(steps.sum()),
+            "note": "coverages and steps over all ranks; best_coverage / episode_length / action counts are rank 0's"}
+
+
 def main(argv=None):
     """python -m flingbot_amd.evaluate --tasks set.npz [--weights flingbot.pth] [--slots 96] [--episode-length 10] [--gpus N]
 
@@ -230,15 +247,8 @@ def main(argv=None):
     ctx.close()
     out = {"tasks": len(tasks), **stats["mean"], "action_primitive_counts": stats["action_primitive_counts"],
            "simulation_steps": stats["simulation_steps"]}
-    if world > 1:   # every rank's per-episode coverages, in task order (ranks hold contiguous blocks; the last may be shorter)
-        pad = lambda v: np.concatenate([np.asarray(v, np.float32), np.full(per_rank - len(v), np.nan, np.float32)])  # noqa: E731
-        init = fdist.gather_rewards(pad(stats["init_coverage"]), device=dev).cpu().numpy()
-        final = fdist.gather_rewards(pad(stats["final_coverage"]), device=dev).cpu().numpy()
-        steps = fdist.gather_rewards([float(stats["simulation_steps"])], device=dev).cpu().numpy()
-        keep = ~np.isnan(init)
-        out.update({"gpus": world, "init_coverage": float(init[keep].mean()), "final_coverage": float(final[keep].mean()),
-                    "episode_delta_coverage": float((final[keep] - init[keep]).mean()), "simulation_steps": int(steps.sum()),
-                    "note": "coverages over all ranks; best_coverage / episode_length / action counts are rank 0's"})
+    if world > 1:
+        out.update(merge_rank_statistics(stats, per_rank, device=dev))
         fdist.barrier()
     if rank == 0:
         print(json.dumps(out))

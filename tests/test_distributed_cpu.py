@@ -135,6 +135,48 @@ def test_sharded_evaluation_gathers_by_global_episode(tmp_path, world):
         assert np.allclose(o["all_init"], np.arange(4 * world) * 0.01) and np.allclose(o["all_final"], np.arange(4 * world) * 0.01 + 0.5)
 
 
+MERGE_WORKER = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["FS_ROOT"])
+import torch
+from flingbot_amd import distributed as fdist
+from flingbot_amd.evaluate import merge_rank_statistics
+
+rank, _, world = fdist.init_from_env("gloo")
+n_tasks, per_rank = 5, 3                                   # 5 tasks over 2 ranks: blocks of 3 and 2
+mine = list(range(n_tasks))[rank * per_rank:(rank + 1) * per_rank]
+stats = {"init_coverage": np.array([0.1 * (t + 1) for t in mine]), "final_coverage": np.array([0.1 * (t + 1) + 0.05 * t for t in mine]),
+         "simulation_steps": 100 * (rank + 1)}
+out = merge_rank_statistics(stats, per_rank)
+print(json.dumps({"rank": rank, **out}))
+fdist.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_evaluate_command_merges_uneven_rank_blocks(tmp_path):
+    """`python -m flingbot_amd.evaluate --gpus N`: the task set is cut into contiguous blocks, the last one shorter; every
+    rank ends with the statistics over ALL episodes (two gloo ranks, 5 tasks as 3 + 2)."""
+    import json
+
+    script = tmp_path / "merge.py"
+    script.write_text(MERGE_WORKER)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port), FS_ROOT=ROOT)) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        rec = json.loads(out.strip().splitlines()[-1])
+        init = np.array([0.1 * (t + 1) for t in range(5)], np.float32)
+        final = np.array([0.1 * (t + 1) + 0.05 * t for t in range(5)], np.float32)
+        assert rec["gpus"] == 2 and rec["episodes"] == 5 and rec["simulation_steps"] == 300
+        assert rec["init_coverage"] == pytest.approx(float(init.mean())) and rec["final_coverage"] == pytest.approx(float(final.mean()))
+        assert rec["episode_delta_coverage"] == pytest.approx(float((final - init).mean()))
+
+
 LAUNCHED_WORKER = r"""
 import os, sys, json
 sys.path.insert(0, os.environ["FS_ROOT"])
