@@ -127,6 +127,41 @@ def test_config1_flat_32_200_steps_bit_exact(gpu_required, solver):
     assert np.array_equal(p[:, 3], np.ones(1024, np.float32))
 
 
+def test_canonical_c2_and_fling_workloads_bit_exact(gpu_required):
+    """SURVEY 8(d)'s C2 and scripted-fling workloads VERBATIM (tests/scenarios.py scenario_c2 / scenario_c2_fling: 64 x 64, 451 and
+    ~500 pyflex.step() with per-step position rewrites / picker moves through the pyflex-shaped accessors) on both back-ends
+    against the oracle: the trajectories PARITY.md's table, the capture kit and bench.py's C2 entries are built on.  Compared
+    every 50 steps and at the end; the oracle runs are threads (orc_step releases the GIL)."""
+    import threading
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    def run(sim, scen, out):
+        rec = sc.Recorder(every=50, also=())
+        scen(sim, record=rec)
+        rec.close()
+        out.append(rec)
+
+    for scen in (lambda s, record: sc.scenario_c2(s, seed=3, record=record), lambda s, record: sc.scenario_c2_fling(s, record=record)):
+        ref = []
+        th = threading.Thread(target=run, args=(OracleSim(), scen, ref))
+        th.start()
+        got = {}
+        for solver in (1, 2):
+            ctx = fsim.FlingSim(n_envs=1, solver=solver)
+            out = []
+            run(ctx.env(0), scen, out)
+            got[solver] = out[0]
+            ctx.close()
+        th.join()
+        for solver, rec in got.items():
+            assert rec.frames == ref[0].frames and len(rec.frames) >= 9
+            for f, a, b, va, vb in zip(rec.frames, rec.pos, ref[0].pos, rec.vel, ref[0].vel):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"solver {solver}, frame {f}: positions differ"
+                assert np.array_equal(va.view(np.uint32), vb.view(np.uint32)), f"solver {solver}, frame {f}: velocities differ"
+            assert np.array_equal(rec.shapes[-1].view(np.uint32), ref[0].shapes[-1].view(np.uint32))
+
+
 @pytest.mark.parametrize("solver", SOLVERS)
 def test_crumple_bit_exact_and_neighbors(gpu_required, solver):
     ctx, orc = _sims(solver)
