@@ -163,83 +163,123 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *env
 #define FS_BOUND_IDX(b) ((b) + ((b) >> 5))
 #define FS_BOUND_HIST (FS_GRID_BUCKETS + FS_GRID_BUCKETS / 32)
 #define FS_BOUND_LDS_BYTES (FS_BOUND_HIST * 4 + 64)
+// Round 4: the kernel was one dependent round trip after the other -- per particle `load, s_waitcnt vmcnt(0), load, ...`, the
+// second and third loads behind the `invMass > 0` branch, and behind every store a reload of the next array pointer from the
+// descriptor (a store through E.pos may alias *E as far as the compiler can tell): 32 us for a 104 x 104 cloth at 0.07
+// VALU-active.  Now the descriptor's fields are read once into registers, a particle's three inputs are requested
+// unconditionally, FS_BOUND_CHUNK particles' loads go out before the first of them is used, and the bucket-ordered copy
+// re-reads the predicted positions (L2 hits, batched the same way) instead of keeping 16 float4 per thread alive across the
+// scan.  The arithmetic per particle is unchanged.
+#define FS_BOUND_CHUNK 4
 template <bool FIN, bool PRE>
-__global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev *envs, const int *ids, int flip) {
+__global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev *__restrict__ envs, const int *ids, int flip) {
     static_assert(FS_GRID_BUCKETS == FS_BOUND_THREADS * 16 && FS_BOUND_MAX <= (1 << 14), "16 buckets per thread, 14-bit ranks");
+    static_assert(FS_BOUND_PPT % FS_BOUND_CHUNK == 0, "whole chunks");
     extern __shared__ __attribute__((aligned(16))) int bound_smem[];
     int *hist = bound_smem, *wave_tot = bound_smem + FS_BOUND_HIST;
     const FsEnvDev &E = envs[blockIdx.x];
     if (E.slot_env < 0) return;  // retired slot
     const int n = E.n, t = threadIdx.x;
-    const FsParams &p = E.p;
-    const float h = p.dt / (float)p.numSubsteps;
+    // the descriptor's fields, once
+    FsVec4 *const g_pos = E.pos, *const g_vel = E.vel, *const g_x0 = E.x0, *const g_v0 = E.v0, *const g_xa = E.xa, *const g_xb = E.xb;
+    int *const g_fill = E.cell_fill;
+    const FsVec4 *const g_last = flip ? g_xb : g_xa;  // the iterate the substep that just ended left its result in
+    const float h = E.p.dt / (float)E.p.numSubsteps;
+    const float gr0 = E.p.gravity[0], gr1 = E.p.gravity[1], gr2 = E.p.gravity[2], damping = E.p.damping;
+    const float max_acc = E.p.maxAcceleration, max_speed = E.p.maxSpeed, sleep_thr = E.p.sleepThreshold;
+    const float inv_cell = 1.0f / (E.p.radius + E.p.particleCollisionMargin);
     if (PRE) {
 #pragma unroll
         for (int k = 0; k < 17; ++k)
             if (t + k * FS_BOUND_THREADS < FS_BOUND_HIST) hist[t + k * FS_BOUND_THREADS] = 0;
         __syncthreads();
     }
-    FsVec4 xpk[FS_BOUND_PPT];
     int code[FS_BOUND_PPT];  // bucket | rank inside the bucket << 14
-    const float inv_cell = 1.0f / (p.radius + p.particleCollisionMargin);
 #pragma unroll
-    for (int k = 0; k < FS_BOUND_PPT; ++k) {
-        const unsigned i = (unsigned)(t + k * FS_BOUND_THREADS);
-        code[k] = -1;
-        if ((int)i < n) {
-            FsVec4 x, v;
-            if (FIN) {  // fs_k_finalize: velocity from displacement, maxAcceleration / maxSpeed clamps, sleeping
-                const float inv_h = 1.0f / h;
-                const FsVec4 x0 = fs_ld4o(E.x0, i);
-                x = x0;  // kinematic or asleep: the position stays (pos == x0 since the predict that copied it)
-                v = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (x0.w > 0.0f) {
-                    const FsVec4 xp = fs_ld4o(flip ? E.xb : E.xa, i);
-                    const FsVec4 v0 = fs_ld4o(E.v0, i);
-                    float vx = (xp.x - x0.x) * inv_h, vy = (xp.y - x0.y) * inv_h, vz = (xp.z - x0.z) * inv_h;
-                    float ax = vx - v0.x, ay = vy - v0.y, az = vz - v0.z;
-                    float dv2 = ax * ax + ay * ay + az * az;
-                    const float maxdv = p.maxAcceleration * h;
-                    if (dv2 > maxdv * maxdv) {
-                        float sc = maxdv / sqrtf(dv2);
-                        vx = v0.x + ax * sc; vy = v0.y + ay * sc; vz = v0.z + az * sc;
-                    }
-                    float v2 = vx * vx + vy * vy + vz * vz;
-                    if (p.maxSpeed < 3.402823466e+38f && v2 > p.maxSpeed * p.maxSpeed) {
-                        float sc = p.maxSpeed / sqrtf(v2);
-                        vx = vx * sc; vy = vy * sc; vz = vz * sc;
-                        v2 = vx * vx + vy * vy + vz * vz;
-                    }
-                    const float thr2 = p.sleepThreshold * p.sleepThreshold;
-                    if (!(v2 < thr2)) {
-                        v = FsVec4{vx, vy, vz, 0.0f};
-                        x = FsVec4{xp.x, xp.y, xp.z, x0.w};
-                        fs_st4o(E.pos, i, x);
-                    }
-                }
-                fs_st4o(E.vel, i, v);
+    for (int k0 = 0; k0 < FS_BOUND_PPT; k0 += FS_BOUND_CHUNK) {
+        if (k0 * FS_BOUND_THREADS >= n) {  // (uniform: nothing of the cloth is left for this chunk)
+#pragma unroll
+            for (int k = 0; k < FS_BOUND_CHUNK; ++k) code[k0 + k] = -1;
+            continue;
+        }
+        FsVec4 in_a[FS_BOUND_CHUNK], in_b[FS_BOUND_CHUNK], in_c[FS_BOUND_CHUNK];
+#pragma unroll
+        for (int k = 0; k < FS_BOUND_CHUNK; ++k) {  // every load of the chunk first (lanes past the end read particle n - 1)
+            const int ir = t + (k0 + k) * FS_BOUND_THREADS;
+            const unsigned i = (unsigned)(ir < n ? ir : n - 1);
+            if (FIN) {
+                in_a[k] = fs_ld4o(g_x0, i);
+                in_b[k] = fs_ld4o(g_last, i);
+                in_c[k] = fs_ld4o(g_v0, i);
             } else {
-                x = fs_ld4o(E.pos, i);
-                v = fs_ld4o(E.vel, i);
+                in_a[k] = fs_ld4o(g_pos, i);
+                in_b[k] = fs_ld4o(g_vel, i);
             }
-            if (PRE) {  // fs_k_predict
-                fs_st4o(E.x0, i, x);
-                fs_st4o(E.v0, i, v);
-                FsVec4 xp = x;
-                if (x.w > 0.0f) {
-                    float vx = v.x + h * (p.gravity[0] - p.damping * v.x);
-                    float vy = v.y + h * (p.gravity[1] - p.damping * v.y);
-                    float vz = v.z + h * (p.gravity[2] - p.damping * v.z);
-                    xp.x = x.x + h * vx;
-                    xp.y = x.y + h * vy;
-                    xp.z = x.z + h * vz;
+        }
+        int bucket[FS_BOUND_CHUNK];
+#pragma unroll
+        for (int k = 0; k < FS_BOUND_CHUNK; ++k) {
+            const unsigned i = (unsigned)(t + (k0 + k) * FS_BOUND_THREADS);
+            bucket[k] = -1;
+            if ((int)i < n) {
+                FsVec4 x, v;
+                if (FIN) {  // fs_k_finalize: velocity from displacement, maxAcceleration / maxSpeed clamps, sleeping
+                    const float inv_h = 1.0f / h;
+                    const FsVec4 x0 = in_a[k];
+                    x = x0;  // kinematic or asleep: the position stays (pos == x0 since the predict that copied it)
+                    v = FsVec4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (x0.w > 0.0f) {
+                        const FsVec4 xp = in_b[k];
+                        const FsVec4 v0 = in_c[k];
+                        float vx = (xp.x - x0.x) * inv_h, vy = (xp.y - x0.y) * inv_h, vz = (xp.z - x0.z) * inv_h;
+                        float ax = vx - v0.x, ay = vy - v0.y, az = vz - v0.z;
+                        float dv2 = ax * ax + ay * ay + az * az;
+                        const float maxdv = max_acc * h;
+                        if (dv2 > maxdv * maxdv) {
+                            float sc = maxdv / sqrtf(dv2);
+                            vx = v0.x + ax * sc; vy = v0.y + ay * sc; vz = v0.z + az * sc;
+                        }
+                        float v2 = vx * vx + vy * vy + vz * vz;
+                        if (max_speed < 3.402823466e+38f && v2 > max_speed * max_speed) {
+                            float sc = max_speed / sqrtf(v2);
+                            vx = vx * sc; vy = vy * sc; vz = vz * sc;
+                            v2 = vx * vx + vy * vy + vz * vz;
+                        }
+                        const float thr2 = sleep_thr * sleep_thr;
+                        if (!(v2 < thr2)) {
+                            v = FsVec4{vx, vy, vz, 0.0f};
+                            x = FsVec4{xp.x, xp.y, xp.z, x0.w};
+                            fs_st4o(g_pos, i, x);
+                        }
+                    }
+                    fs_st4o(g_vel, i, v);
+                } else {
+                    x = in_a[k];
+                    v = in_b[k];
                 }
-                fs_st4o(E.xa, i, xp);
-                const int b = fs_stream_bucket((int)floorf(xp.x * inv_cell), (int)floorf(xp.y * inv_cell), (int)floorf(xp.z * inv_cell));
-                const int rank = atomicAdd(&hist[FS_BOUND_IDX(b)], 1);
-                xpk[k] = xp;
-                code[k] = b | (rank << 14);
+                if (PRE) {  // fs_k_predict
+                    fs_st4o(g_x0, i, x);
+                    fs_st4o(g_v0, i, v);
+                    FsVec4 xp = x;
+                    if (x.w > 0.0f) {
+                        float vx = v.x + h * (gr0 - damping * v.x);
+                        float vy = v.y + h * (gr1 - damping * v.y);
+                        float vz = v.z + h * (gr2 - damping * v.z);
+                        xp.x = x.x + h * vx;
+                        xp.y = x.y + h * vy;
+                        xp.z = x.z + h * vz;
+                    }
+                    fs_st4o(g_xa, i, xp);
+                    bucket[k] = fs_stream_bucket((int)floorf(xp.x * inv_cell), (int)floorf(xp.y * inv_cell), (int)floorf(xp.z * inv_cell));
+                }
             }
+        }
+        if (PRE) {  // the chunk's LDS atomics together: the return value is the particle's rank inside its bucket
+            int rank[FS_BOUND_CHUNK];
+#pragma unroll
+            for (int k = 0; k < FS_BOUND_CHUNK; ++k) rank[k] = bucket[k] >= 0 ? atomicAdd(&hist[FS_BOUND_IDX(bucket[k])], 1) : 0;
+#pragma unroll
+            for (int k = 0; k < FS_BOUND_CHUNK; ++k) code[k0 + k] = bucket[k] >= 0 ? (bucket[k] | (rank[k] << 14)) : -1;
         }
     }
     if (!PRE) return;
@@ -272,14 +312,26 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int b = t + k * FS_BOUND_THREADS;
-        E.cell_fill[b] = b + 1 < FS_GRID_BUCKETS ? hist[FS_BOUND_IDX(b + 1)] : n;
+        g_fill[b] = b + 1 < FS_GRID_BUCKETS ? hist[FS_BOUND_IDX(b + 1)] : n;
     }
-    // bucket-ordered copy of the predicted positions with the particle id in w (fs_k_grid_scatter)
+    // bucket-ordered copy of the predicted positions with the particle id in w (fs_k_grid_scatter); this workgroup wrote
+    // them above, the re-read is an L2 hit
 #pragma unroll
-    for (int k = 0; k < FS_BOUND_PPT; ++k) {
-        if (code[k] >= 0) {
-            const int slot = hist[FS_BOUND_IDX(code[k] & (FS_GRID_BUCKETS - 1))] + (code[k] >> 14);
-            fs_st4o(E.xb, (unsigned)slot, FsVec4{xpk[k].x, xpk[k].y, xpk[k].z, __int_as_float(t + k * FS_BOUND_THREADS)});
+    for (int k0 = 0; k0 < FS_BOUND_PPT; k0 += FS_BOUND_CHUNK) {
+        if (k0 * FS_BOUND_THREADS >= n) continue;
+        FsVec4 xp[FS_BOUND_CHUNK];
+#pragma unroll
+        for (int k = 0; k < FS_BOUND_CHUNK; ++k) {
+            const int ir = t + (k0 + k) * FS_BOUND_THREADS;
+            xp[k] = fs_ld4o(g_xa, (unsigned)(ir < n ? ir : n - 1));
+        }
+#pragma unroll
+        for (int k = 0; k < FS_BOUND_CHUNK; ++k) {
+            const int c = code[k0 + k];
+            if (c >= 0) {
+                const int slot = hist[FS_BOUND_IDX(c & (FS_GRID_BUCKETS - 1))] + (c >> 14);
+                fs_st4o(g_xb, (unsigned)slot, FsVec4{xp[k].x, xp[k].y, xp[k].z, __int_as_float(t + (k0 + k) * FS_BOUND_THREADS)});
+            }
         }
     }
 }
