@@ -163,6 +163,56 @@ def test_canonical_c2_and_fling_workloads_bit_exact(gpu_required):
 
 
 @pytest.mark.parametrize("solver", SOLVERS)
+@pytest.mark.parametrize("dims", [(1, 1), (2, 1), (3, 2), (1, 7), (65, 3)])
+def test_degenerate_cloths_step_bit_exact(gpu_required, solver, dims):
+    """The smallest scenes pyflex.set_scene accepts -- one particle (no spring, no triangle), one spring, a 3 x 2 patch, a single
+    column, a strip one particle wider than a wavefront -- dropped onto the ground and stepped 40 frames: every back-end equals
+    the oracle (fewer particles than a wavefront, empty adjacency rows, an empty triangle list)."""
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    p = cloth_params(*dims, pos=(0.0, -0.03, 0.0))
+    for s in (hip, orc):
+        s.set_scene(p)
+        pos = s.get_positions().reshape(-1, 4).copy()
+        pos[:, 0] += np.float32(0.001) * np.arange(pos.shape[0], dtype=np.float32)     # not axis-aligned
+        s.set_positions(pos.ravel())
+    for k in range(40):
+        hip.step()
+        orc.step()
+        _assert_state_equal(hip, orc, f"{dims} step {k}")
+    assert hip.get_positions().reshape(-1, 4)[:, 1].min() < 0.0051      # it reached the ground
+
+
+def test_largest_reference_cloth_120_bit_exact(gpu_required):
+    """120 x 120 = 14 400 particles: the largest cloth of the reference's released task sets (README.md:194-200, "large" set), just
+    below the 16 384 particles the one-launch substep boundary handles; a loose heap so that lists are long, 4 episodes."""
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    p = cloth_params(120, 120, pos=(0.0, -0.15, 0.0))
+
+    def setup(sim, seed):
+        sim.set_scene(p)
+        rng = np.random.RandomState(40 + seed)
+        pos = sim.get_positions().reshape(-1, 4).copy()
+        pos[:, :3] += (rng.randn(pos.shape[0], 3) * 0.003).astype(np.float32)
+        pos[:3000, :3] = (rng.rand(3000, 3) * [0.14, 0.05, 0.14] + [0.0, 0.02, 0.0]).astype(np.float32)
+        sim.set_positions(pos.ravel())
+
+    ctx = fsim.FlingSim(n_envs=4, solver=fsim.FS_SOLVER_STREAM_MERGED)
+    for e in range(4):
+        setup(ctx.env(e), e)
+    ctx.step(5)
+    assert ctx.last_boundary_form() == 1
+    for e in (0, 3):
+        orc = OracleSim()
+        setup(orc, e)
+        orc.step(5)
+        _assert_state_equal(ctx.env(e), orc, f"120x120 episode {e}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("solver", SOLVERS)
 def test_crumple_bit_exact_and_neighbors(gpu_required, solver):
     ctx, orc = _sims(solver)
     hip = ctx.env(0)
