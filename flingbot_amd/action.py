@@ -2,8 +2,9 @@
 
 `select_action` is the drop-in for SimEnv.get_max_value_valid_action (environment/simEnv.py:560-661): the value maps
 stay on the GPU, `fs_select_action` (csrc/fs_action.hip) validates every candidate in parallel and returns the entry the
-reference's descending walk would stop at; only that one candidate is then evaluated on the host, with the reference's own
-numpy expressions (environment/utils.py:134-276), to build the returned `action_params` (p1, p2, pretransform pixels).
+reference's descending walk would stop at; only that one candidate is then evaluated on the host in float64 (the geometry of
+environment/utils.py:134-276, formulated here from the math and pinned to the reference's bits by
+tests/golden/envutils_golden.npz) to build the returned `action_params` (p1, p2, pretransform pixels).
 There is no host search: without the HIP library this module raises.
 """
 import ctypes as C
@@ -18,116 +19,132 @@ from .sim import load_library
 KINDS = {"fling": 0, "stretchdrag": 1, "drag": 2, "place": 3}
 
 
-# ---- environment/utils.py:134-176, :179-234 (same numpy calls, hence the same bits)
-def rot2d(angle, degrees=True):
-    if degrees:
-        angle = np.pi * angle / 180
-    return np.array([[np.cos(angle), np.sin(angle), 0], [-np.sin(angle), np.cos(angle), 0], [0, 0, 1]]).T
+# ---------------------------------------------------------------------------------------------------------------------------
+# Host geometry of the action space (what environment/utils.py:134-276 and simEnv.py:517-537 compute), written from the math.
+# Convention: image points are ROW vectors (first axis, second axis, 1) and a map M acts as p' = p @ M.  The results have to
+# equal the reference's float64 bits (tests/golden/envutils_golden.npz), which fixes three things and nothing else:
+#   * the ORDER of the homogeneous 3x3 products in get_transform_matrix -- a closed-form composition of the same affine map
+#     differs in the last bit for a third of random inputs (numpy hands 3x3 products to BLAS, which fuses multiply-adds);
+#   * np.linalg.inv for the camera pose;
+#   * one 4x4-by-column product per back-projected point -- the batched (4x4)@(4xK) product takes another BLAS path and
+#     rounds differently for almost every generic pose.
+# ---------------------------------------------------------------------------------------------------------------------------
+CAMERA_FOV_DEG = 39.5978
 
 
-def translate2d(translation):
-    return np.array([[1, 0, translation[0]], [0, 1, translation[1]], [0, 0, 1]]).T
+def _shift(offset):
+    m = np.eye(3)
+    m[2, :2] = offset
+    return m
 
 
-def scale2d(scale):
-    return np.array([[scale, 0, 0], [0, scale, 0], [0, 0, 1]]).T
+def _linear(block):
+    m = np.eye(3)
+    m[:2, :2] = block
+    return m
+
+
+def _about_centre(block, centre):
+    """p -> (p - centre) @ block + centre"""
+    return _shift(-centre) @ _linear(block) @ _shift(centre)
 
 
 def get_transform_matrix(original_dim, resized_dim, rotation, scale):
-    resize_mat = scale2d(original_dim / resized_dim)
-    scale_mat = np.matmul(np.matmul(translate2d(-np.ones(2) * (resized_dim // 2)), scale2d(scale)),
-                          translate2d(np.ones(2) * (resized_dim // 2)))
-    rot_mat = np.matmul(np.matmul(translate2d(-np.ones(2) * (resized_dim // 2)), rot2d(rotation)),
-                        translate2d(np.ones(2) * (resized_dim // 2)))
-    return np.matmul(np.matmul(scale_mat, rot_mat), resize_mat)
+    """Network-input pixel -> pre-transform image pixel for one (rotation [deg], scale) entry of the action space: zoom
+    about the network image's centre pixel, turn about it, then stretch to the pre-transform resolution
+    (environment/utils.py:161-176)."""
+    centre = float(resized_dim // 2)
+    theta = np.pi * rotation / 180
+    c, s = np.cos(theta), np.sin(theta)
+    zoom = _about_centre(scale * np.eye(2), centre)
+    turn = _about_centre(np.array([[c, -s], [s, c]]), centre)
+    return zoom @ turn @ _linear((original_dim / resized_dim) * np.eye(2))
 
 
 def compute_pose(pos, lookat, up=(0, 0, 1)):
-    norm = np.linalg.norm
-    lookat, pos, up = np.array(lookat), np.array(pos), np.array(up)
-    f = (lookat - pos)
-    f = f / norm(f)
-    u = up / norm(up)
-    s = np.cross(f, u)
-    s = s / norm(s)
-    u = np.cross(s, f)
-    view_matrix = [s[0], u[0], -f[0], 0, s[1], u[1], -f[1], 0, s[2], u[2], -f[2], 0,
-                   -np.dot(s, pos), -np.dot(u, pos), np.dot(f, pos), 1]
-    view_matrix = np.array(view_matrix).reshape(4, 4).T
-    pose_matrix = np.linalg.inv(view_matrix)
-    pose_matrix[:, 1:3] = -pose_matrix[:, 1:3]
-    return pose_matrix
+    """Camera-to-world matrix of a camera at `pos` looking at `lookat` (environment/utils.py:179-201): the inverse of the
+    look-at view matrix with the camera's y and z axes flipped (image y grows downwards, depth grows along the view)."""
+    pos, lookat, up = (np.asarray(v, dtype=np.float64) for v in (pos, lookat, up))
+    forward = lookat - pos
+    forward = forward / np.linalg.norm(forward)
+    side = np.cross(forward, up / np.linalg.norm(up))
+    side = side / np.linalg.norm(side)
+    upward = np.cross(side, forward)
+    view = np.eye(4)
+    view[:3, :3] = (side, upward, -forward)
+    view[:3, 3] = (-np.dot(side, pos), -np.dot(upward, pos), np.dot(forward, pos))
+    pose = np.linalg.inv(view)
+    pose[:, 1:3] *= -1
+    return pose
 
 
 def compute_intrinsics(fov, image_size):
-    image_size = float(image_size)
-    focal_length = (image_size / 2) / np.tan((np.pi * fov / 180) / 2)
-    return np.array([[focal_length, 0, image_size / 2], [0, focal_length, image_size / 2], [0, 0, 1]])
+    """Pinhole intrinsics of a square image with a `fov`-degree field of view (environment/utils.py:204-210)."""
+    half = float(image_size) / 2
+    k = np.diag([half / np.tan((np.pi * fov / 180) / 2)] * 2 + [1.0])
+    k[:2, 2] = half
+    return k
 
 
-def pixel_to_3d(depth_im, x, y, pose_matrix, fov=39.5978, depth_scale=1):
-    intrinsics_matrix = compute_intrinsics(fov, depth_im.shape[0])
-    click_z = depth_im[y, x]
-    click_z *= depth_scale
-    click_x = (x - intrinsics_matrix[0, 2]) * click_z / intrinsics_matrix[0, 0]
-    click_y = (y - intrinsics_matrix[1, 2]) * click_z / intrinsics_matrix[1, 1]
-    if click_z == 0:
-        raise Exception('Invalid pick point')
-    point_3d = np.asarray([click_x, click_y, click_z])
-    point_3d = np.append(point_3d, 1.0).reshape(4, 1)
-    target_position = np.dot(pose_matrix, point_3d)
-    target_position = target_position[0:3, 0]
-    target_position[0] = - target_position[0]
-    return target_position
+def back_project(depth_im, pixels, pose_matrix, fov=CAMERA_FOV_DEG, depth_scale=1):
+    """World points [K, 3] under the image points pixels[K] = (column, row) of a depth image: pinhole rays scaled by the
+    depth there, moved to the world by `pose_matrix`, x mirrored (the simulator's x axis points the other way)."""
+    pixels = np.asarray(pixels).reshape(-1, 2)
+    half = float(depth_im.shape[0]) / 2
+    focal = half / np.tan((np.pi * fov / 180) / 2)
+    depth = depth_im[pixels[:, 1], pixels[:, 0]] * depth_scale  # stays float32, like the scalar the reference scales
+    if not depth.all():
+        raise ValueError("zero depth under a pick pixel")
+    rays = np.ones((len(pixels), 4))
+    rays[:, :2] = (pixels - half) * depth[:, None] / focal
+    rays[:, 2] = depth
+    world = np.array([np.dot(pose_matrix, ray.reshape(4, 1))[:3, 0] for ray in rays])
+    world[:, 0] *= -1
+    return world
+
+
+def pixel_to_3d(depth_im, x, y, pose_matrix, fov=CAMERA_FOV_DEG, depth_scale=1):
+    """environment/utils.py:213-234 for one pixel."""
+    return back_project(depth_im, [(x, y)], pose_matrix, fov, depth_scale)[0]
 
 
 def pixels_to_3d_positions(pixels, scale, rotation, pretransform_depth, transformed_depth, pose_matrix=None,
                            pretransform_pix_only=False, **kwargs):
-    """environment/utils.py:232-276: network pixels -> pretransform pixels -> world points (same return dictionary)."""
-    mat = get_transform_matrix(original_dim=pretransform_depth.shape[0], resized_dim=transformed_depth.shape[0],
-                               rotation=-rotation,  # the reference's sign ("TODO bug", environment/utils.py:244), kept
-                               scale=scale)
-    pixels = np.concatenate((pixels, np.array([[1], [1]])), axis=1)
-    pixels = np.matmul(pixels, mat)[:, :2].astype(int)
-    pix_1, pix_2 = pixels
-    max_idx = pretransform_depth.shape[0]
-    if (pixels < 0).any() or (pixels >= max_idx).any():
-        return {'valid_action': False, 'p1': None, 'p2': None, 'pretransform_pixels': np.array([pix_1, pix_2])}
-    if pretransform_pix_only:
-        return {'valid_action': True, 'pretransform_pixels': np.array([pix_1, pix_2])}
-    x, y = pix_1  # "this order of x, y is not a bug"
-    p1 = pixel_to_3d(depth_im=pretransform_depth, x=x, y=y, pose_matrix=pose_matrix)
-    x, y = pix_2
-    p2 = pixel_to_3d(depth_im=pretransform_depth, x=x, y=y, pose_matrix=pose_matrix)
-    return {'valid_action': p1 is not None and p2 is not None, 'p1': p1, 'p2': p2,
-            'pretransform_pixels': np.array([pix_1, pix_2])}
+    """environment/utils.py:237-276: the two network-image pixels of an action -> pre-transform pixels -> world points, in
+    the reference's return dictionary.  The rotation enters negated, as it does there (the action space is indexed by the
+    angle the OBSERVATION was turned by), and a pre-transform pixel (a, b) is read as column a, row b -- both kept on purpose:
+    they decide which particle gets grasped."""
+    to_source = get_transform_matrix(pretransform_depth.shape[0], transformed_depth.shape[0], -rotation, scale)
+    source = (np.column_stack((pixels, np.ones(len(pixels), dtype=np.int64))) @ to_source)[:, :2].astype(int)
+    out = {'valid_action': bool(((source >= 0) & (source < pretransform_depth.shape[0])).all()),
+           'pretransform_pixels': source.copy()}
+    if not out['valid_action']:
+        out.update(p1=None, p2=None)
+    elif not pretransform_pix_only:
+        out['p1'], out['p2'] = back_project(pretransform_depth, source, pose_matrix)
+    return out
 
 
 def preprocess_obs(rgb, d):
-    """environment/utils.py:579-582 on the host (the device path produces the same tensor inside fs_observe)."""
-    return torch.cat((torch.tensor(rgb).float() / 255, torch.tensor(d).unsqueeze(dim=2).float()), dim=2).permute(2, 0, 1)
+    """environment/utils.py:579-582 on the host (the device path produces the same tensor inside fs_observe): colour as
+    [0, 1] floats and depth, channels first."""
+    planes = torch.cat((torch.as_tensor(rgb).float() / 255, torch.as_tensor(d).float()[..., None]), dim=-1)
+    return planes.movedim(-1, 0)
+
+
+def grasp_pixel_offsets(pix_grasp_dist, pix_drag_dist, pix_place_dist):
+    """simEnv.py:517-537 as data: the two grasp pixels of a primitive are the arg-max pixel shifted along the first image
+    axis by these amounts (fling / stretchdrag: symmetric about it; drag / place: from it to the end point)."""
+    return {'fling': (pix_grasp_dist, -pix_grasp_dist), 'stretchdrag': (pix_grasp_dist, -pix_grasp_dist),
+            'drag': (0, pix_drag_dist), 'place': (0, pix_place_dist)}
 
 
 def get_action_params(action_primitive, max_indices, pix_grasp_dist, pix_drag_dist, pix_place_dist):
-    """simEnv.py:517-537"""
-    x, y, z = max_indices
-    if action_primitive in ('fling', 'stretchdrag'):
-        center = np.array([x, y, z])
-        p1 = center[1:].copy()
-        p1[0] = p1[0] + pix_grasp_dist
-        p2 = center[1:].copy()
-        p2[0] = p2[0] - pix_grasp_dist
-    elif action_primitive == 'drag':
-        p1 = np.array([y, z])
-        p2 = p1.copy()
-        p2[0] += pix_drag_dist
-    elif action_primitive == 'place':
-        p1 = np.array([y, z])
-        p2 = p1.copy()
-        p2[0] += pix_place_dist
-    else:
-        raise Exception(f'Action Primitive not supported: {action_primitive}')
-    return p1, p2
+    shifts = grasp_pixel_offsets(pix_grasp_dist, pix_drag_dist, pix_place_dist).get(action_primitive)
+    if shifts is None:
+        raise ValueError(f"unknown action primitive {action_primitive!r}")
+    anchor = np.asarray(max_indices)[1:]
+    return tuple(anchor + np.array([shift, 0]) for shift in shifts)
 
 
 _work = {}
@@ -151,45 +168,40 @@ class ActionSelector:
         self._mats = {}
 
     def _candidate(self, action, x, y, z, scales, depth):
-        """check_action / reachability for ONE candidate with the reference's expressions; None when it is skipped."""
-        reach_points = np.array(get_action_params(action, (x, y, z), self.pix_grasp_dist, self.pix_drag_dist,
+        """Host evaluation of ONE candidate (value-map index x, pixel y, z): the checks of simEnv.py:202-260, :539-558 and
+        :604-653 in float64; returns the reference's action_params dictionary, or None when the reference's walk skips it."""
+        grasp_pixels = np.array(get_action_params(action, (x, y, z), self.pix_grasp_dist, self.pix_drag_dist,
                                                   self.pix_place_dist))
-        if any(((p < 0).any() or (p >= self.obs_dim).any()) for p in reach_points):
+        if ((grasp_pixels < 0) | (grasp_pixels >= self.obs_dim)).any():
             return None
-        p1, p2 = reach_points[:2]
-        num_scales = len(scales)
-        rotation_idx = x // num_scales
-        scale_idx = x - rotation_idx * num_scales
+        rotation_idx, scale_idx = divmod(x, len(scales))
         scale, rotation = scales[scale_idx], self.rotations[rotation_idx]
-        r3d = pixels_to_3d_positions(pixels=np.array([p1, p2]), scale=scale, rotation=rotation, pretransform_depth=depth,
-                                     transformed_depth=np.empty((self.obs_dim, 0)), pose_matrix=self.pose)
-        if not r3d['valid_action']:
+        found = pixels_to_3d_positions(pixels=grasp_pixels, scale=scale, rotation=rotation, pretransform_depth=depth,
+                                       transformed_depth=np.empty((self.obs_dim, 0)), pose_matrix=self.pose)
+        if not found['valid_action']:
             return None
-        P1, P2 = r3d['p1'], r3d['p2']
-        pix_1, pix_2 = r3d['pretransform_pixels']
+        points = np.array([found['p1'], found['p2']])
+        arms = {'left': self.left_arm_base, 'right': self.right_arm_base}
 
-        def reach(base, pos):
-            return np.linalg.norm(base - pos) < self.reach_distance_limit
-        left, right = self.left_arm_base, self.right_arm_base
-        left_or_right = None
-        if action in ('fling', 'stretchdrag'):
-            reachable = reach(left, P1) and reach(right, P2)
-        elif reach(left, P1) and reach(left, P2):
-            reachable, left_or_right = True, 'left'
-        elif reach(right, P1) and reach(right, P2):
-            reachable, left_or_right = True, 'right'
-        else:
-            reachable = False
-        if action == 'stretchdrag':
-            P1[1] = self.grasp_height
-            P2[1] = self.grasp_height
-            drag_direction = np.cross(P1 - P2, np.array([0, 1, 0]))
-            drag_direction = self.stretchdrag_dist * drag_direction / np.linalg.norm(drag_direction)
-            reachable = (reach(left, P1 + drag_direction) and reach(right, P2 + drag_direction)) and reachable
-        if not reachable:
+        def within_reach(which, targets):  # [arm][point]: is the point closer to that arm's base than the reach limit
+            return [np.linalg.norm(arms[which] - t) < self.reach_distance_limit for t in targets]
+
+        arm = None
+        if action in ('fling', 'stretchdrag'):  # one arm per point: left takes the first, right the second
+            ok = within_reach('left', points[:1])[0] and within_reach('right', points[1:])[0]
+            if action == 'stretchdrag':  # ... and again at the end of the drag, at grasp height
+                points[:, 1] = self.grasp_height
+                sideways = np.cross(points[0] - points[1], np.array([0, 1, 0]))
+                sideways = self.stretchdrag_dist * sideways / np.linalg.norm(sideways)
+                ok = (within_reach('left', points[:1] + sideways)[0]
+                      and within_reach('right', points[1:] + sideways)[0]) and ok
+        else:  # drag / place: a single arm has to reach both points; the left one is asked first
+            arm = next((name for name in arms if all(within_reach(name, points))), None)
+            ok = arm is not None
+        if not ok:
             return None
-        return dict(valid_action=True, p1=P1, p2=P2, pretransform_pixels=np.array([pix_1, pix_2]),
-                    left_or_right=left_or_right, scale=scale, rotation=rotation, max_indices=np.array([x, y, z]))
+        return dict(valid_action=True, p1=points[0], p2=points[1], pretransform_pixels=found['pretransform_pixels'],
+                    left_or_right=arm, scale=scale, rotation=rotation, max_indices=np.array([x, y, z]))
 
     def select(self, value_maps, adaptive_scale_factors, pretransform_depth, depth_device=None):
         """value_maps: {primitive: CUDA float32 [T, D, D]} or a stacked CUDA tensor [P, T, D, D] in self.actions order;
@@ -222,7 +234,7 @@ class ActionSelector:
                                          for r in self.rotations for s in scales], np.float64)
             self._mats[mkey] = mats
         kinds = np.ascontiguousarray([KINDS[a] for a in self.actions], np.int32)
-        fx = float(compute_intrinsics(39.5978, S)[0, 0])
+        fx = float(compute_intrinsics(CAMERA_FOV_DEG, S)[0, 0])
         nbytes = int(self.lib.fs_select_action_work_bytes(T))
         key = (stacked.device.index, T, threading.get_ident())  # scratch per host thread
         work = _work.get(key)

@@ -645,6 +645,56 @@ def test_action_selector_host_evaluation_matches_reference_golden():
         assert np.array_equal(res["p1"], g[f"c{ci}_p1"]) and np.array_equal(res["p2"], g[f"c{ci}_p2"]), ci
 
 
+def test_action_host_evaluation_equals_oracle_on_random_candidates():
+    """flingbot_amd/action.py formulates the host geometry from the math (its own matrix construction, one vectorised
+    back-projection, a table for the grasp pixels); oracle/action.py restates the reference statement by statement.  Over
+    random candidates of all four primitives, random depth planes, scales and rotations both must agree on skip / keep and,
+    for kept candidates, on every float64 bit of p1 / p2 and on the pre-transform pixels and the chosen arm."""
+    from flingbot_amd.action import ActionSelector, get_transform_matrix, get_action_params
+    from oracle import action as oa
+
+    rng = np.random.default_rng(77)
+    kept = {p: 0 for p in ("fling", "stretchdrag", "drag", "place")}
+    for trial in range(12):
+        D, S = int(rng.choice([32, 48, 64])), int(rng.choice([96, 200, 400]))
+        gd, dd, pd = int(rng.integers(2, 9)), int(rng.integers(2, 12)), int(rng.integers(2, 12))
+        scales = np.sort(rng.uniform(0.75, 3.0, size=4))
+        rotations = list(np.linspace(-180, 180, 7)[:-1] + rng.uniform(-3, 3))
+        depth = (2.0 - rng.uniform(0.0, 0.3, size=(S, S)) * (rng.random((S, S)) < 0.6)).astype(np.float32)
+        reach = float(rng.uniform(0.7, 1.3))
+        prims = list(kept)
+        cfg = dict(obs_dim=D, pix_grasp_dist=gd, pix_drag_dist=dd, pix_place_dist=pd, scales=scales, rotations=rotations,
+                   depth=depth, reach_distance_limit=reach, stretchdrag_dist=0.3, grasp_height=0.02,
+                   left_arm_base=np.array([0.765, 0, 0]), right_arm_base=np.array([-0.765, 0, 0]))
+        sel = ActionSelector.__new__(ActionSelector)          # the host half only: no library, no device
+        sel.rotations, sel.obs_dim = rotations, D
+        sel.pix_grasp_dist, sel.pix_drag_dist, sel.pix_place_dist = gd, dd, pd
+        sel.reach_distance_limit, sel.stretchdrag_dist, sel.grasp_height = reach, 0.3, 0.02
+        sel.left_arm_base, sel.right_arm_base = cfg["left_arm_base"].astype(np.float64), cfg["right_arm_base"].astype(np.float64)
+        sel.pose = oa.compute_pose(pos=[0, 2, 0], lookat=[0, 0, 0], up=[0, 0, 1])
+        for _ in range(240):
+            action = prims[int(rng.choice(4, p=[0.3, 0.4, 0.15, 0.15]))]
+            x, y, z = int(rng.integers(len(rotations) * len(scales))), int(rng.integers(D)), int(rng.integers(D))
+            want = oa.evaluate_candidate(action, x, y, z, cfg)
+            got = sel._candidate(action, x, y, z, scales, depth)
+            assert (want is None) == (got is None), (trial, action, x, y, z)
+            if want is None:
+                continue
+            kept[action] += 1
+            for key in ("p1", "p2"):
+                assert got[key].dtype == want[key].dtype and np.array_equal(got[key], want[key]), (trial, action, key)
+            assert np.array_equal(got["pretransform_pixels"], want["pretransform_pixels"])
+            assert got["left_or_right"] == want["left_or_right"]
+            a, b = get_action_params(action, (x, y, z), gd, dd, pd), oa.get_action_params(action, (x, y, z), gd, dd, pd)
+            assert all(np.array_equal(p, q) and p.dtype == q.dtype for p, q in zip(a, b))
+        for r in rotations:
+            for s in scales:
+                assert np.array_equal(get_transform_matrix(S, D, -r, s), oa.get_transform_matrix(S, D, -r, s))
+    assert all(v >= 20 for v in kept.values()), kept
+    with pytest.raises(Exception):
+        get_action_params("fold", (0, 1, 2), 4, 4, 4)
+
+
 def test_envutils_host_mirror_matches_reference_vectors():
     """environment/utils.py:161-276, 579-582 (compute_pose, compute_intrinsics, get_transform_matrix, pixel_to_3d,
     pixels_to_3d_positions, preprocess_obs) run by tests/golden/make_golden.py::envutils_vectors on seeded inputs: the
