@@ -951,6 +951,7 @@ extern "C" int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lis
     const int n = e->host.n;
     int rc = d2h(ctx, counts, e->dev.ncount, size_t(4) * n);
     if (rc != FS_OK) return rc;
+    for (int i = 0; i < n; ++i) counts[i] &= 0xff;  // (bits 8-31 of the word: the particle's shape candidates, below)
     std::vector<int> slotmajor(size_t(n) * FS_MAX_NEIGHBORS);
     rc = d2h(ctx, slotmajor.data(), e->dev.nlist, slotmajor.size() * 4);
     if (rc != FS_OK) return rc;
@@ -961,6 +962,17 @@ extern "C" int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lis
 #else
             lists[size_t(i) * FS_MAX_NEIGHBORS + s] = s < counts[i] ? slotmajor[size_t(s) * n + i] : -1;
 #endif
+    return FS_OK;
+}
+
+extern "C" int fs_get_last_shape_candidates(fs_ctx *ctx, int env, unsigned *masks) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e || !masks) return FS_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int n = e->host.n;
+    int rc = d2h(ctx, masks, e->dev.ncount, size_t(4) * n);
+    if (rc != FS_OK) return rc;
+    for (int i = 0; i < n; ++i) masks[i] >>= 8;
     return FS_OK;
 }
 

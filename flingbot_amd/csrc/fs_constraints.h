@@ -254,34 +254,89 @@ __device__ __forceinline__ void fs_shape_sweep(const FsShapesDev &sh, int q, int
     s0 = c0 - b0; s1 = c1 - b1; s2 = c2 - b2;
 }
 
-// planes + spheres for one particle (order: planes ascending, spheres ascending)
-__device__ __forceinline__ void fs_shape_contacts(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
-                                                  float ri2, const FsParams &p, const FsShapesDev &sh, int sub) {
-    for (int q = 0; q < p.numPlanes; ++q)
-        fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
-                         p.collisionDistance, p.staticFriction, p.dynamicFriction);
-    const float S = (float)p.numSubsteps;
-    for (int q = 0; q < sh.count; ++q) {
-        float c0, c1, c2, s0, s1, s2;
-        fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
-        fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, p.collisionDistance,
-                          p.staticFriction, p.dynamicFriction);
+// ---- collideShapes (the stage of NvFlex.h:205: once per substep, before the iterations; "contact planes generated within
+// NvFlexParams::shapeCollisionMargin", NvFlex.h:1074).  For one particle at its PREDICTED position: the planes and the
+// kinematic spheres whose surface is closer than collisionDistance + shapeCollisionMargin (NvFlex.h:145,147), at most
+// maxContactsPerParticle of them (NvFlex.h:361, main.cpp:828) -- planes in index order, then spheres in index order; a sphere
+// stands where the iterations of this substep see it (end of its sweep).  Result: bit q = plane q, bit 8 + q = sphere q.
+// The iterations test only this set (oracle: collide_shapes).  The mask rides in the candidate-count word of the particle
+// (FsEnvDev::ncount: bits 0-7 = particle-contact candidates, bits 8-31 = this mask), which every iteration loads anyway.
+#define FS_SHAPE_MASK_SHIFT 8
+#define FS_NCOUNT_MASK 0xff
+template <class SphereAt>  // SphereAt(q, c0, c1, c2, r): centre + radius of sphere q at the end of the substep
+__device__ __forceinline__ unsigned fs_shape_candidates_core(const FsParams &p, int n_spheres, float x0, float x1, float x2,
+                                                             SphereAt sphere_at) {
+    const float reach = p.collisionDistance + p.shapeCollisionMargin;
+    unsigned mask = 0u;
+    int listed = 0;
+    for (int q = 0; q < p.numPlanes && listed < p.maxContacts; ++q) {
+        const float sdist = fs_dot3(p.planes[q][0], p.planes[q][1], p.planes[q][2], x0, x1, x2) + p.planes[q][3];
+        if (sdist < reach) { mask |= 1u << q; ++listed; }
     }
+    for (int q = 0; q < n_spheres && listed < p.maxContacts; ++q) {
+        float c0, c1, c2, r;
+        sphere_at(q, c0, c1, c2, r);
+        const float ex = x0 - c0, ey = x1 - c1, ez = x2 - c2;
+        const float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
+        const float lim = r + reach;
+        if (l2 < lim * lim) { mask |= 1u << (8 + q); ++listed; }
+    }
+    return mask;
+}
+__device__ __forceinline__ unsigned fs_shape_candidates(const FsParams &p, const FsShapesDev &sh, int sub, float x0, float x1,
+                                                        float x2) {
+    const float S = (float)p.numSubsteps;
+    return fs_shape_candidates_core(p, sh.count, x0, x1, x2, [&](int q, float &c0, float &c1, float &c2, float &r) {
+        float s0, s1, s2;
+        fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
+        r = sh.pos[q].w;
+    });
+}
+__device__ __forceinline__ unsigned fs_swept_shape_candidates(const FsParams &p, const FsSlotSweeps &sw, int sub, float x0,
+                                                              float x1, float x2) {
+    return fs_shape_candidates_core(p, sw.count, x0, x1, x2, [&](int q, float &c0, float &c1, float &c2, float &r) {
+        const FsVec4 c = sw.c[sub][q];
+        c0 = c.x; c1 = c.y; c2 = c.z; r = c.w;
+    });
+}
+
+// planes + spheres for one particle: the candidates of `mask` (fs_shape_candidates), planes ascending, then spheres ascending.
+// A wavefront none of whose lanes has a candidate -- every row of a cloth that is far from the ground and the pickers --
+// skips the block; within it a sphere's sweep + test run only where some lane lists that sphere.
+__device__ __forceinline__ void fs_shape_contacts(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
+                                                  float ri2, const FsParams &p, const FsShapesDev &sh, int sub, unsigned mask) {
+    if (__builtin_amdgcn_ballot_w64(mask != 0u) == 0ull) return;
+    for (int q = 0; q < p.numPlanes; ++q)
+        if ((mask >> q) & 1u)
+            fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
+                             p.collisionDistance, p.staticFriction, p.dynamicFriction);
+    const float S = (float)p.numSubsteps;
+    for (int q = 0; q < sh.count; ++q)
+        if ((mask >> (8 + q)) & 1u) {
+            float c0, c1, c2, s0, s1, s2;
+            fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
+            fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, p.collisionDistance,
+                              p.staticFriction, p.dynamicFriction);
+        }
 }
 
 // the same with the spheres' sweeps of this substep taken from the launch slot's table (FsSlotSweeps, built once per launch
 // sequence by fs_k_slot_table with fs_shape_sweep's expressions: identical numbers, scalar loads instead of ~28 vector
 // instructions per sphere, particle and iteration)
 __device__ __forceinline__ void fs_swept_shape_contacts(FsAcc &a, float xi0, float xi1, float xi2, float ri0, float ri1,
-                                                        float ri2, const FsParams &p, const FsSlotSweeps &sw, int sub) {
+                                                        float ri2, const FsParams &p, const FsSlotSweeps &sw, int sub,
+                                                        unsigned mask) {
+    if (__builtin_amdgcn_ballot_w64(mask != 0u) == 0ull) return;
     for (int q = 0; q < p.numPlanes; ++q)
-        fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
-                         p.collisionDistance, p.staticFriction, p.dynamicFriction);
-    for (int q = 0; q < sw.count; ++q) {
-        const FsVec4 c = sw.c[sub][q], s = sw.s[sub][q];
-        fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.x, c.y, c.z, c.w, s.x, s.y, s.z, p.collisionDistance,
-                          p.staticFriction, p.dynamicFriction);
-    }
+        if ((mask >> q) & 1u)
+            fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
+                             p.collisionDistance, p.staticFriction, p.dynamicFriction);
+    for (int q = 0; q < sw.count; ++q)
+        if ((mask >> (8 + q)) & 1u) {
+            const FsVec4 c = sw.c[sub][q], s = sw.s[sub][q];
+            fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.x, c.y, c.z, c.w, s.x, s.y, s.z, p.collisionDistance,
+                              p.staticFriction, p.dynamicFriction);
+        }
 }
 
 // applyDeltas with local relaxation

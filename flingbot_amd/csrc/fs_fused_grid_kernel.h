@@ -16,7 +16,7 @@
 //     of the thread's particles (P, Q) in a register PAIR: 36 LDS instructions per pair of particles and iteration
 //     instead of 2 x 24, conflict-free (a wave reads one row).
 //   * Two particles per trip as TWO INDEPENDENT SCALAR STREAMS (fg_spring_pq: .x = P, .y = Q): the whole spring
-//     (difference, length^2, the spelled-out reciprocal root, scale, accumulation) is evaluated for both, bit for bit the
+//     (difference, length^2, the hardware reciprocal root v_rsq_f32, scale, accumulation) is evaluated for both, bit for bit the
 //     operations of fs_spring_fast in the same order per particle, and each stream fills the other's dependency stalls.
 //     (The register pairs are also the operand shape of v_pk_add/mul/fma_f32, and the kernel was first written on those:
 //     bit-identical and 14 % slower -- a packed multiply / add costs 1.5-1.7 scalar ones on this part, scripts/ubench --
@@ -45,7 +45,8 @@
 #define FG_OFF_ROWL (FG_OFF_CHIST + 512)       // float[4][64]: rest length of the z-direction slots 8..11 per row
 #define FG_OFF_COLL (FG_OFF_ROWL + 1024)       // float[4][64]: rest length of the x-direction slots 0, 1, 4, 5 per column
 #define FG_OFF_RCNT (FG_OFF_COLL + 1024)       // float[128]: relaxationFactor / count, the IEEE quotient fs_apply computes
-#define FG_LDS_BYTES (FG_OFF_RCNT + 512)
+#define FG_OFF_SWEEP (FG_OFF_RCNT + 512)     // FsVec4[2][16]: the substep's sphere table (fs_fused_stage_sweeps)
+#define FG_LDS_BYTES (FG_OFF_SWEEP + 2 * FS_MAX_SHAPES * 16)
 // The overflow queue: a particle with contact candidates that found no room in the contact set (which takes the 1024 longest
 // lists; what is left over has one candidate, in a crowded episode two) used to evaluate them inside the main loop, where
 // every one of a wavefront's four particle slots has a few such lanes and so pays full contact evaluations for them.  They
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
     unsigned short *items = (unsigned short *)(smem + FG_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FG_OFF_SCAN);
     float *rowL = (float *)(smem + FG_OFF_ROWL);
+    FsVec4 *const sweep = (FsVec4 *)(smem + FG_OFF_SWEEP);
 
 #ifdef FS_BLOCK_CLOCKS  // developer build: how long every workgroup runs (scripts/block_clocks.py)
     const unsigned long long tc_start = __builtin_amdgcn_s_memtime(), tr_start = __builtin_amdgcn_s_memrealtime();
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
             // ---- predict from (X0, vel); build the spatial hash (XS = bucket-ordered copy in the X0 region)
+            fs_fused_stage_sweeps(c, sh, sub, sweep);
             for (int q = t; q < FS_FUSED_BUCKETS / 2; q += FS_FUSED_THREADS) ((unsigned *)cursor)[q] = 0u;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
@@ -289,21 +292,24 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
             for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
                 const int i = items[qs];
                 const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
+                // collideShapes rides along: the particle's shape candidates go into the upper bits of its count word
+                const int shape_bits = (int)(fs_fused_shape_candidates(c, E.p, sweep, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
                 if (find_mode == 4) {  // grid cloth: no packed rest-near ids to carry through the search
                     FsNearWords none;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) none.w[q] = 0xffffffffu;
                     g_ncount[i] = fs_fused_find_neighbors<true>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase, g_rest, g_nlist,
-                                                                none, (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
+                                                                none, (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x) | shape_bits;
                     continue;
                 }
                 FsNearWords near;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
-                g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors<false>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
-                                                                              g_rest, g_nlist, near,
-                                                                              (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x);
+                g_ncount[i] = (find_mode == 3 ? 0
+                                              : fs_fused_find_neighbors<false>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
+                                                                               g_rest, g_nlist, near,
+                                                                               (fs_lus)(smem + FG_OFF_XX) + t, (fs_lcf)X0x)) |
+                              shape_bits;
             }
             FS_TS(2)
             __syncthreads();  // every wave is done with XS, the hash and the queues (which covered the planes)
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
             for (int k = 0; k < FS_FUSED_PPT; ++k) {
                 const int i = t + k * FS_FUSED_THREADS;
                 int cc = 0;
-                if (i < n && Xw[i] > 0.0f) cc = g_ncount[i];
+                if (i < n && Xw[i] > 0.0f) cc = g_ncount[i] & FS_NCOUNT_MASK;
                 ccls[k] = cc > 96 ? 96 : cc;
                 if (ccls[k] > 0) atomicAdd(&chist[ccls[k]], 1);
             }
@@ -364,10 +370,13 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
             FsVec4 *squeue = (FsVec4 *)(smem + FG_OFF_CUR);
             const int i2 = t < csize ? (int)cset[t] : -1;
             int cnt2 = 0, cj2[FS_FUSED_PREFETCH_CAND];
+            unsigned smask2 = 0u;
 #pragma unroll
             for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = 0;
             if (i2 >= 0) {
-                cnt2 = g_ncount[i2];
+                const int word = g_ncount[i2];
+                cnt2 = word & FS_NCOUNT_MASK;
+                smask2 = (unsigned)word >> FS_SHAPE_MASK_SHIFT;
 #pragma unroll
                 for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = g_nlist[(unsigned)q * un + (unsigned)i2];
             }
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
             // ---- Jacobi iterations
 #pragma unroll 1
             for (int it = 0; it < c.iters; ++it) {
-                // candidate count + list head of the pair's two particles, requested one pair ahead
+                // candidate count (| shape candidates << 8) + list head of the pair's two particles, requested one pair ahead
                 int cntP, cntQ, cjP[FG_PREFETCH_CAND], cjQ[FG_PREFETCH_CAND];
                 {
                     unsigned i0 = t < n ? (unsigned)t : 0u, i1 = t + 1024 < n ? (unsigned)(t + 1024) : 0u;
@@ -541,7 +550,9 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                         const float xi0s = h == 0 ? xi0.x : xi0.y, xi1s = h == 0 ? xi1.x : xi1.y, xi2s = h == 0 ? xi2.x : xi2.y;
                         const float wis = h == 0 ? wi.x : wi.y;
                         FsAcc a = h == 0 ? aP : aQ;
-                        int cnt = h == 0 ? cntP : cntQ;
+                        const int cntw = h == 0 ? cntP : cntQ;
+                        const int cnt = cntw & FS_NCOUNT_MASK;
+                        const unsigned smask = (unsigned)cntw >> FS_SHAPE_MASK_SHIFT;
                         int cj[FG_PREFETCH_CAND];
 #pragma unroll
                         for (int q = 0; q < FG_PREFETCH_CAND; ++q) cj[q] = h == 0 ? cjP[q] : cjQ[q];
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                                                         xj.y - X0y[j], xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
                                 }
                             }
-                            fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0s, xi1s, xi2s, ri0, ri1, ri2);
+                            fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0s, xi1s, xi2s, ri0, ri1, ri2);
                             fg_apply(a, c.relax, rcnt, nx, ny, nz);
                         }
 #pragma unroll
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cn[q];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sweep, smask2, xi0, xi1, xi2, ri0, ri1, ri2);
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fg_apply(a, c.relax, rcnt, n2x, n2y, n2z);
                 }
@@ -630,6 +641,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                     const int i = (int)(word & 0xfffu), more = (int)(word >> 28);
                     int j = (int)((word >> 12) & 0xfffu);
                     int jn = more > 0 ? g_nlist[un + (unsigned)i] : 0;  // (the second candidate travels while the first is evaluated)
+                    const unsigned smask = (unsigned)g_ncount[i] >> FS_SHAPE_MASK_SHIFT;  // (the entry's word has no room for it)
                     FsAcc a = {pa.x, pa.y, pa.z, (int)((word >> 24) & 15u)};
                     float xi0 = Xx[i], xi1 = Xy[i], xi2 = Xz[i];
                     const float wi = Xw[i];
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                         j = jn;
                         if (sq + 2 <= more) jn = g_nlist[(unsigned)(sq + 2) * un + (unsigned)i];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0, xi1, xi2, ri0, ri1, ri2);
                     fg_apply(a, c.relax, rcnt, xi0, xi1, xi2);
                     squeue[q] = FsVec4{xi0, xi1, xi2, pa.w};
                 }

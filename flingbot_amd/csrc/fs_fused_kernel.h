@@ -59,7 +59,10 @@
 #define FS_FUSED_OFF_CSET (FS_FUSED_OFF_SCAN + 64)
 #define FS_FUSED_OFF_CACC (FS_FUSED_OFF_CSET + FS_FUSED_CSET_CAP * 2)
 #define FS_FUSED_OFF_CHIST (FS_FUSED_OFF_CACC + FS_FUSED_CSET_CAP * 16)
-#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_CHIST + 512)
+// the kinematic spheres of this substep: FsVec4[16] centre at its end (w = radius) | FsVec4[16] displacement during it
+// (fs_shape_sweep, worked out by the first threads at the top of every substep instead of per particle and iteration)
+#define FS_FUSED_OFF_SWEEP (FS_FUSED_OFF_CHIST + 512)
+#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_SWEEP + 2 * FS_MAX_SHAPES * 16)
 #ifndef FS_FUSED_PREFETCH_CAND
 #define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
 #endif
@@ -516,22 +519,46 @@ __device__ __forceinline__ void fs_fused_count_offsets(int *chist, int t) {
 }
 
 // planes + kinematic spheres for one particle
+// The substep's sphere table in LDS (see FS_FUSED_OFF_SWEEP): written by fs_fused_stage_sweeps before the barrier that follows
+// the predict stage, read (uniform address: one broadcast ds_read_b128) by the candidate stage and by every iteration.
+__device__ __forceinline__ void fs_fused_stage_sweeps(const FsFusedConsts &c, const FsShapesDev &sh, int sub, FsVec4 *sweep) {
+    const int q = threadIdx.x;
+    if (q < c.n_shapes) {
+        float c0, c1, c2, s0, s1, s2;
+        fs_shape_sweep(sh, q, sub, (float)c.substeps, c0, c1, c2, s0, s1, s2);
+        sweep[q] = FsVec4{c0, c1, c2, sh.pos[q].w};
+        sweep[FS_MAX_SHAPES + q] = FsVec4{s0, s1, s2, 0.0f};
+    }
+}
+// collideShapes for one particle (fs_shape_candidates with the sweeps taken from the table: the same numbers)
+__device__ __forceinline__ unsigned fs_fused_shape_candidates(const FsFusedConsts &c, const FsParams &p, const FsVec4 *sweep,
+                                                              float x0, float x1, float x2) {
+    return fs_shape_candidates_core(p, c.n_shapes, x0, x1, x2, [&](int q, float &c0, float &c1, float &c2, float &r) {
+        const FsVec4 s = sweep[q];
+        c0 = s.x; c1 = s.y; c2 = s.z; r = s.w;
+    });
+}
 __device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedConsts &c, const FsParams &p,
-                                                        const FsShapesDev &sh, int sub, float xi0, float xi1, float xi2,
-                                                        float ri0, float ri1, float ri2) {
+                                                        const FsVec4 *sweep, unsigned mask, float xi0, float xi1,
+                                                        float xi2, float ri0, float ri1, float ri2) {
+    // `mask`: the particle's collideShapes candidates of this substep (fs_shape_candidates).  The plane test is per lane (a
+    // sheet on the ground lists it for every particle: a wave-level skip would only add instructions there); the sphere block
+    // is skipped by every wavefront none of whose lanes lists a sphere -- all of them while the pickers are parked -- and a
+    // sphere's test runs only where a lane lists it.
     if (c.n_planes == 1) {
-        fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.pl0, c.pl1, c.pl2, c.pl3, c.cd, c.mu_s, c.mu_k);
+        if (mask & 1u) fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.pl0, c.pl1, c.pl2, c.pl3, c.cd, c.mu_s, c.mu_k);
     } else {
         for (int q = 0; q < c.n_planes; ++q)
-            fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2],
-                             p.planes[q][3], c.cd, c.mu_s, c.mu_k);
+            if ((mask >> q) & 1u)
+                fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2],
+                                 p.planes[q][3], c.cd, c.mu_s, c.mu_k);
     }
-    const float S = (float)c.substeps;
-    for (int q = 0; q < c.n_shapes; ++q) {
-        float c0, c1, c2, s0, s1, s2;
-        fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
-        fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, c.cd, c.mu_s, c.mu_k);
-    }
+    if (c.n_shapes == 0 || __builtin_amdgcn_ballot_w64((mask >> 8) != 0u) == 0ull) return;
+    for (int q = 0; q < c.n_shapes; ++q)
+        if ((mask >> (8 + q)) & 1u) {
+            const FsVec4 sc = sweep[q], sd = sweep[FS_MAX_SHAPES + q];
+            fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, sc.x, sc.y, sc.z, sc.w, sd.x, sd.y, sd.z, c.cd, c.mu_s, c.mu_k);
+        }
 }
 
 // The spring sweep of one particle over the packed adjacency: one spring per scheduling region; the LDS gather and
@@ -590,6 +617,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
     float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
     unsigned short *cursor = (unsigned short *)(smem + FS_FUSED_OFF_CUR);
+    FsVec4 *const sweep = (FsVec4 *)(smem + FS_FUSED_OFF_SWEEP);
     unsigned short *items = (unsigned short *)(smem + FS_FUSED_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FS_FUSED_OFF_SCAN);
 
@@ -695,6 +723,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
             // ---- predict from (X0, vel) into X; build the spatial hash
+            fs_fused_stage_sweeps(c, sh, sub, sweep);
             for (int q = t; q < FS_FUSED_BUCKETS / 2; q += FS_FUSED_THREADS) ((unsigned *)cursor)[q] = 0u;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
@@ -718,21 +747,24 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             for (int qs = t; qs < n; qs += FS_FUSED_THREADS) {
                 const int i = items[qs];
                 const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
+                // collideShapes rides along: the particle's shape candidates go into the upper bits of its count word
+                const int shape_bits = (int)(fs_fused_shape_candidates(c, E.p, sweep, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
                 if (find_mode == 4) {  // grid cloth: no packed rest-near ids to carry through the search
                     FsNearWords none;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) none.w[q] = 0xffffffffu;
                     g_ncount[i] = fs_fused_find_neighbors<true>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase, g_rest, g_nlist,
-                                                                none, (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
+                                                                none, (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x) | shape_bits;
                     continue;
                 }
                 FsNearWords near;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) near.w[q] = find_mode == 1 ? g_near[(unsigned)q * un + (unsigned)i] : 0xffffffffu;
-                g_ncount[i] = find_mode == 3 ? 0
-                                             : fs_fused_find_neighbors<false>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
-                                                                              g_rest, g_nlist, near,
-                                                                              (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x);
+                g_ncount[i] = (find_mode == 3 ? 0
+                                              : fs_fused_find_neighbors<false>(fc, i, xi, (fs_lcus)cursor, (fs_lcus)items, g_phase,
+                                                                               g_rest, g_nlist, near,
+                                                                               (fs_lus)(smem + FS_FUSED_OFF_X) + t, (fs_lcf)X0x)) |
+                              shape_bits;
             }
             FS_TS(2)
             __syncthreads();  // every wave is done with XS and the hash
@@ -766,7 +798,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             for (int k = 0; k < FS_FUSED_PPT; ++k) {
                 const int i = t + k * FS_FUSED_THREADS;
                 int cc = 0;
-                if (i < n && X[i].w > 0.0f) cc = g_ncount[i];
+                if (i < n && X[i].w > 0.0f) cc = g_ncount[i] & FS_NCOUNT_MASK;
                 ccls[k] = cc > 96 ? 96 : cc;
                 if (ccls[k] > 0) atomicAdd(&chist[ccls[k]], 1);
             }
@@ -804,10 +836,13 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
             // the substep's iterations)
             const int i2 = t < csize ? (int)cset[t] : -1;
             int cnt2 = 0, cj2[FS_FUSED_PREFETCH_CAND];
+            unsigned smask2 = 0u;
 #pragma unroll
             for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = 0;
             if (i2 >= 0) {
-                cnt2 = g_ncount[i2];
+                const int word = g_ncount[i2];
+                cnt2 = word & FS_NCOUNT_MASK;
+                smask2 = (unsigned)word >> FS_SHAPE_MASK_SHIFT;
 #pragma unroll
                 for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj2[q] = g_nlist[(unsigned)q * un + (unsigned)i2];
             }
@@ -819,7 +854,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 // software pipeline over the thread's particles: adjacency words / candidate head of particle k+1 are
                 // requested before particle k is computed
                 uint32_t jw[JW], cw[JW];
-                int cnt = 0, cj[FS_FUSED_PREFETCH_CAND];
+                int cntw = 0, cj[FS_FUSED_PREFETCH_CAND];  // cntw: candidate count | shape candidates << 8
                 {
                     unsigned i0 = t < n ? (unsigned)t : 0u;
                     asm volatile("" : "+v"(i0));  // keep these iteration-invariant loads inside the loop
@@ -827,7 +862,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                         for (int q = 0; q < JW; ++q) { jw[q] = g_nbr[(unsigned)q * un + i0]; cw[q] = g_code[(unsigned)q * un + i0]; }
                     }
-                    cnt = g_ncount[i0];
+                    cntw = g_ncount[i0];
 #pragma unroll
                     for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = g_nlist[(unsigned)q * un + i0];
                 }
@@ -841,7 +876,9 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     const int i_raw = t + k * FS_FUSED_THREADS;
                     const int i = i_raw < n ? i_raw : 0;  // lanes past the end recompute particle 0 and discard it
                     uint32_t jw_n[JW], cw_n[JW];
-                    int cnt_n, cj_n[FS_FUSED_PREFETCH_CAND];
+                    int cntw_n, cj_n[FS_FUSED_PREFETCH_CAND];
+                    const int cnt = cntw & FS_NCOUNT_MASK;
+                    const unsigned smask = (unsigned)cntw >> FS_SHAPE_MASK_SHIFT;
                     const FsVec4 xi = X[i];
                     float nx = xi.x, ny = xi.y, nz = xi.z;
                     FsAcc a = {0.0f, 0.0f, 0.0f, 0};
@@ -872,7 +909,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                             for (int q = 0; q < JW; ++q) { jw_n[q] = g_nbr[(unsigned)q * un + in]; cw_n[q] = g_code[(unsigned)q * un + in]; }
                         }
-                        cnt_n = g_ncount[in];
+                        cntw_n = g_ncount[in];
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj_n[q] = g_nlist[(unsigned)q * un + in];
                     }
@@ -907,7 +944,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                                                     xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
                             }
                         }
-                        fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                        fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0, xi1, xi2, ri0, ri1, ri2);
                         fs_apply(a, c.relax, nx, ny, nz);
                     }
 #pragma unroll
@@ -917,7 +954,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                         for (int q = 0; q < JW; ++q) { jw[q] = jw_n[q]; cw[q] = cw_n[q]; }
                     }
-                    cnt = cnt_n;
+                    cntw = cntw_n;
 #pragma unroll
                     for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cj[q] = cj_n[q];
                     FS_TS(6)
@@ -954,7 +991,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cn[q];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sweep, smask2, xi0, xi1, xi2, ri0, ri1, ri2);
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fs_apply(a, c.relax, n2x, n2y, n2z);
                 }
@@ -968,6 +1005,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                     const int i = (int)(word & 0xfffu), more = (int)(word >> 29);
                     int j = (int)((word >> 12) & 0xfffu);
                     int jn = more > 0 ? g_nlist[un + (unsigned)i] : 0;  // (the second candidate travels while the first is evaluated)
+                    const unsigned smask = (unsigned)g_ncount[i] >> FS_SHAPE_MASK_SHIFT;  // (the entry's word has no room for it)
                     FsAcc a = {pa.x, pa.y, pa.z, (int)((word >> 24) & 31u)};
                     const FsVec4 xi = X[i];
                     float xi0 = xi.x, xi1 = xi.y, xi2 = xi.z;
@@ -981,7 +1019,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                         j = jn;
                         if (sq + 2 <= more) jn = g_nlist[(unsigned)(sq + 2) * un + (unsigned)i];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sh, sub, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0, xi1, xi2, ri0, ri1, ri2);
                     fs_apply(a, c.relax, xi0, xi1, xi2);
                     squeue[q] = FsVec4{xi0, xi1, xi2, pa.w};
                 }

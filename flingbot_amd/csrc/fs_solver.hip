@@ -187,8 +187,8 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
                 case K_SCAN: hipLaunchKernelGGL(fs_k_grid_scan, bgrid, dim3(1024), 0, c.st, tab, cids); break;
                 case K_SCATTER: hipLaunchKernelGGL(fs_k_grid_scatter, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
                 case K_FIND:
-                    if (find_stencil) hipLaunchKernelGGL(fs_k_find_neighbors<true>, c.grid, block, 0, c.st, tab, cids, c.gx, c.count);
-                    else hipLaunchKernelGGL(fs_k_find_neighbors<false>, c.grid, block, 0, c.st, tab, cids, c.gx, c.count);
+                    if (find_stencil) hipLaunchKernelGGL(fs_k_find_neighbors<true>, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, c.gx, c.count);
+                    else hipLaunchKernelGGL(fs_k_find_neighbors<false>, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, c.gx, c.count);
                     break;
                 case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, flip, c.gx, c.count); break;
                 default: hipLaunchKernelGGL(fs_k_finalize, c.grid, block, 0, c.st, tab, cids, flip, c.gx, c.count); break;

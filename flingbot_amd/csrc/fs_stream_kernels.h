@@ -347,7 +347,8 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
 // STENCIL: every episode of the launch is a grid cloth in find mode 4 (the host checks the launch list): the packed rest-near
 // ids are never loaded and the kernel fits 5 waves per SIMD instead of 4.
 template <bool STENCIL>
-__global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const int *ids, int gx, int ne) {
+__global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
+                                                               int sub, int gx, int ne) {
     int bx, by;
     if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
@@ -366,8 +367,11 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
     const FsVec4 xsi = fs_ld4(E.xb, qs);
     const FsVec4 xi = FsVec4{xsi.x, xsi.y, xsi.z, 0.0f};
     const int i = __float_as_int(xsi.w);
+    // collideShapes rides along (this kernel is the once-per-substep pass over the predicted positions): the particle's shape
+    // candidates go into the upper bits of its candidate-count word
+    const int shape_bits = (int)(fs_swept_shape_candidates(p, shapes[by], sub, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
     if (c.mode == 3) {  // one phase without the SelfCollide flag: no pairs at all
-        E.ncount[i] = 0;
+        E.ncount[i] = shape_bits;
         return;
     }
     FsNearWords near;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *e
             }
         }
     drain();
-    E.ncount[i] = fs_fused_nb_finish(c, i, L, nlist);
+    E.ncount[i] = fs_fused_nb_finish(c, i, L, nlist) | shape_bits;
 }
 
 // ---- one Jacobi iteration: solveSprings + solveContacts + applyDeltas for particle i
@@ -469,7 +473,7 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
     int nc = 0, cj0[4] = {-1, -1, -1, -1};
     {   // both forms: the loads whose addresses depend on nothing but i go out first
         x0i = E.x0[i];
-        nc = E.ncount[i];
+        nc = E.ncount[i];  // (count | shape candidates << 8: split below)
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj0[k] = E.nlist[(size_t)k * E.n + i];  // slots beyond the count hold stale ids: masked below
     }
@@ -477,6 +481,8 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
         dst[i] = xi;
         return;
     }
+    const unsigned shape_mask = (unsigned)nc >> FS_SHAPE_MASK_SHIFT;
+    nc &= FS_NCOUNT_MASK;
     FsAcc a = {0.0f, 0.0f, 0.0f, 0};
     // slot-major (ELL) adjacency: the wave's loads of slot s are contiguous (the CSR rows of neighbouring particles are 12
     // entries apart, i.e. one cache line per lane); slots ascend with the spring id, like the CSR rows.  CHUNK slots per
@@ -558,7 +564,7 @@ __device__ __forceinline__ void fs_iterate_particle(const FsEnvDev &E, const FsS
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
-    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub, shape_mask);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     dst[i] = xi;
 }
@@ -584,7 +590,9 @@ __device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, cons
     FsVec4 xi = src[i];
     const FsU32x4 cw = E.scode[i];
     const FsVec4 x0i = E.x0[i];
-    const int nc = valid ? E.ncount[i] : 0;
+    const int ncw = valid ? E.ncount[i] : 0;
+    const int nc = ncw & FS_NCOUNT_MASK;
+    const unsigned shape_mask = (unsigned)ncw >> FS_SHAPE_MASK_SHIFT;
     int cj0[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) cj0[k] = E.nlist[(size_t)k * E.n + i];  // slots beyond the count hold stale ids: masked below
@@ -644,7 +652,7 @@ __device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, cons
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
-    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub, shape_mask);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     dst[i] = xi;
 }
@@ -679,7 +687,9 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
     const unsigned un = (unsigned)E.n, ui = (unsigned)i;
     FsVec4 xi = fs_ld4o(src, ui);
     const FsVec4 x0i = fs_ld4o(E.x0, ui);
-    const int nc = fs_ldo(E.ncount, ui);
+    const int ncw = fs_ldo(E.ncount, ui);
+    const int nc = ncw & FS_NCOUNT_MASK;
+    const unsigned shape_mask = (unsigned)ncw >> FS_SHAPE_MASK_SHIFT;
     int cj0[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) cj0[k] = fs_ldo(E.nlist, (unsigned)k * un + ui);  // slots beyond the count hold stale ids: masked below
@@ -734,7 +744,7 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
 #pragma unroll
         for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
     }
-    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub);
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub, shape_mask);
     fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
     fs_st4o(dst, ui, xi);
 }

@@ -143,9 +143,12 @@ def load_library(build_if_missing=True):
         "fs_host_sphere_mesh": (ci, [cf, fp, fp, fp, fp, ip]),
         "fs_camera_matrices": (ci, [fp, fp, ci, ci, fp, fp, fp]),
         "fs_get_last_neighbors": (ci, [vp, ci, ip, ip]),
+        "fs_get_last_shape_candidates": (ci, [vp, ci, ip]),
         "fs_device_positions": (vp, [vp, ci]),
     }
     for name, (res, args) in proto.items():
+        if "FLINGSIM_LIB" in os.environ and not hasattr(lib, name):
+            continue  # development override with an older build of the library (A/B timing): entry points it predates stay unbound
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -590,6 +593,12 @@ class FlingSim:
         lists = np.empty(n * 96, np.int32)
         self._ck(self.lib.fs_get_last_neighbors(self.h, env, _ip(counts), _ip(lists)))
         return counts, lists.reshape(n, 96)
+
+    def get_last_shape_candidates(self, env=0):
+        """collideShapes of the last substep: per particle, bit q = plane q, bit 8 + q = kinematic sphere q."""
+        masks = np.empty(self.n_particles(env), np.int32)
+        self._ck(self.lib.fs_get_last_shape_candidates(self.h, env, _ip(masks)))
+        return masks.view(np.uint32)
 
 
 class EnvView:

@@ -131,6 +131,10 @@ int fs_coverage(fs_ctx *ctx, double *out, int n_doubles);
 
 /* white-box access for tests: particle-contact candidate lists of the last substep, counts[N], lists[N*96] */
 int fs_get_last_neighbors(fs_ctx *ctx, int env, int *counts, int *lists);
+/* white-box access for tests: the collideShapes stage of the last substep (NvFlex.h:205; candidates within collisionDistance +
+   shapeCollisionMargin of the predicted position, NvFlex.h:145-147, at most maxContactsPerParticle, NvFlex.h:361), masks[N]:
+   bit q = plane q, bit 8 + q = kinematic sphere q */
+int fs_get_last_shape_candidates(fs_ctx *ctx, int env, unsigned *masks);
 /* white-box access for tests: which kernel form the most recent fs_step* launch of this context ran (0 = none yet).
    The launch size selects the form (fs_solver.hip), so a parity test asserts that it compared the form it meant to. */
 #define FS_FORM_FUSED_12 1       /* fs_k_fused_step<12>: register-resident coded adjacency, <= 12 springs per particle */

@@ -31,12 +31,13 @@ def oracle_lib_path():
 
 # bounding builds of the same step (oracle/Makefile): plain IEEE arithmetic, and each arithmetic choice alone.  Tests use
 # them to measure how far the default oracle's spelled-out approximations move a step; they are never the parity oracle.
-VARIANTS = ("exact", "exact_rsqrt", "nofma", "newton")
+VARIANTS = ("exact", "exact_rsqrt", "nofma", "newton", "host")  # host: exact_rsqrt at -O3 -mfma = bench.py's CPU baseline
 # sensitivity builds of the model-level [I] choices (flex_oracle.c "MODEL switches"): one alternative reading each, built on
 # first use (liboracle_alt_<name>.so).  They measure how far another reading of the closed solver would move a trajectory
 # (PARITY.md); they are never the parity oracle either.
 MODEL_ALTERNATIVES = ("friction_post", "neighbors_by_distance", "shape_end_pose", "sleep_velocity_only", "sleep_at_predict",
-                      "no_sleep", "apply_per_type", "damping_mult", "stiffness_iter")
+                      "no_sleep", "apply_per_type", "damping_mult", "stiffness_iter", "shape_every_iteration", "contact_planes",
+                      "count_candidates")
 
 
 def build_oracle(force=False):
@@ -83,6 +84,8 @@ def _load(variant=None):
         return _libs[variant]
     assert variant is None or variant in VARIANTS or (
         variant.startswith("alt_") and all(a in MODEL_ALTERNATIVES for a in variant[4:].split("+"))), variant   # "alt_a+b": both
+    if variant == "host" and not _cpu_has_fma():
+        variant = "exact_rsqrt"  # the same arithmetic through libm's fmaf
     path = oracle_lib_path() if variant is None else os.path.join(_HERE, f"liboracle_{variant}.so")
     if variant is not None and variant.startswith("alt_"):
         srcs = [os.path.join(_HERE, f) for f in ("flex_oracle.c", "flex_oracle.h", "Makefile")]
@@ -112,6 +115,8 @@ def _load(variant=None):
     lib.orc_clear_shapes.argtypes = [vp]
     lib.orc_get_last_neighbors.argtypes = [vp, ip, ip]
     lib.orc_max_neighbor_list.argtypes = [vp]
+    lib.orc_get_last_shape_candidates.argtypes = [vp, ip]
+    lib.orc_missed_shape_contacts.argtypes = [vp]
     _libs[variant] = lib
     return lib
 
@@ -260,3 +265,11 @@ class OracleSim:
         lists = np.empty(self.n * 96, np.int32)
         self.lib.orc_get_last_neighbors(self.h, _ip(counts), _ip(lists))
         return counts, lists.reshape(self.n, 96)
+
+    def get_last_shape_candidates(self):
+        """collideShapes of the last substep: per particle, bit q = plane q, bit 8 + q = sphere q."""
+        return self._geti("orc_get_last_shape_candidates", self.n).view(np.uint32)
+
+    def missed_shape_contacts(self):
+        """How often an iteration found a plane / sphere violated that collideShapes had not listed (since set_scene)."""
+        return self.lib.orc_missed_shape_contacts(self.h)

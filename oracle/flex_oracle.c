@@ -65,6 +65,9 @@ struct orc_sim {
     int *ncount, *nlist;
     int *cell_key, *cell_order;
     int max_list;  /* longest candidate list any particle has had since set_scene (white-box: PARITY.md) */
+    unsigned *smask; /* n: shape-contact candidates of the substep (collideShapes): bit q = plane q, bit 8 + q = sphere q */
+    float *splane;   /* ORC_ALT_CONTACT_PLANES only: n x ORC_MAX_SHAPES x 4, the frozen tangent plane of each sphere candidate */
+    int missed_shape_contacts; /* white box: contacts that violated inside an iteration without being a candidate (since set_scene) */
     float *lam;    /* ORC_ALT_FRICTION_POST only */
 };
 
@@ -72,7 +75,7 @@ static void free_scene(orc_sim *s) {
     free(s->pos); free(s->vel); free(s->phase); free(s->rest); free(s->sidx); free(s->slen); free(s->sk);
     free(s->tris); free(s->tnrm); free(s->nrm); free(s->adj_off); free(s->adj_spr);
     free(s->xp); free(s->xn); free(s->x0); free(s->v0); free(s->ncount); free(s->nlist);
-    free(s->cell_key); free(s->cell_order); free(s->lam);
+    free(s->cell_key); free(s->cell_order); free(s->lam); free(s->smask); free(s->splane);
     memset(s, 0, sizeof(*s));
 }
 
@@ -308,6 +311,11 @@ int orc_set_scene(orc_sim *s, const float *ptr, const float *verts, int n_vert_f
     s->cell_key = (int *)malloc(sizeof(int) * 4 * (n + 1));
     s->cell_order = (int *)malloc(sizeof(int) * (n + 1));
     s->ns = 0;
+    s->smask = (unsigned *)calloc(n + 1, sizeof(unsigned));
+    s->missed_shape_contacts = 0;
+#ifdef ORC_ALT_CONTACT_PLANES
+    s->splane = (float *)calloc((size_t)ORC_MAX_SHAPES * 4 * (n + 1), sizeof(float));
+#endif
 #ifdef ORC_ALT_FRICTION_POST
     s->lam = (float *)calloc((size_t)(ORC_MAX_NEIGHBORS + 8 + ORC_MAX_SHAPES) * (n + 1), sizeof(float));
 #endif
@@ -370,12 +378,30 @@ static int cell_lower_bound(const orc_sim *s, const int *keys, int cx, int cy, i
  *   -DORC_ALT_DAMPING_MULT           v = (v + h g) (1 - h damping)   (default: v += h (g - damping v))
  *   -DORC_ALT_STIFFNESS_ITER         spring stiffness made iteration-count independent, k' = 1 - (1 - k)^(1/iterations)
  *                                    (Mueller 2007 section 3.3)   (default: k used as is in every iteration)
+ *   -DORC_ALT_SHAPE_EVERY_ITERATION  no collideShapes stage: every plane and every sphere is tested for every particle in
+ *                                    every iteration (rounds 1-4 of this repo; default: only the candidates found once per
+ *                                    substep within collisionDistance + shapeCollisionMargin, at most maxContactsPerParticle)
+ *   -DORC_ALT_CONTACT_PLANES         a sphere candidate is FROZEN at collideShapes into its tangent plane at the predicted
+ *                                    position -- the data model NvFlexGetContacts documents (NvFlex.h:1074-1080: "contact
+ *                                    planes", "velocity of the contact point on the shape") -- and the iterations project
+ *                                    on that plane (default: the sphere itself, normal re-derived from the current iterate)
+ *   -DORC_ALT_COUNT_CANDIDATES       the Local-relaxation divisor counts every LISTED contact of the particle (particle
+ *                                    candidates and shape candidates), violated or not (NvFlex.h:89 "divided by the
+ *                                    particle's constraint count"; default: only the constraints that pushed this iteration)
  * The static-friction branch has no alternative worth a build: with mu_s <= mu_k (0 <= 0.75 for shapes, 1 = 1 between
  * particles) "full stick below mu_s * depth" and "clamp to mu_k * depth" give the same scale for every input
  * (tests/test_oracle_cpu.py::test_static_friction_branch_is_redundant).
  */
 #if defined(ORC_ALT_SLEEP_VELOCITY_ONLY) + defined(ORC_ALT_SLEEP_AT_PREDICT) + defined(ORC_ALT_NO_SLEEP) > 1
 #error "one sleep alternative at a time"
+#endif
+#if defined(ORC_ALT_CONTACT_PLANES) && (defined(ORC_ALT_SHAPE_EVERY_ITERATION) || defined(ORC_ALT_FRICTION_POST))
+#error "contact planes need the candidate stage and the in-iteration friction"
+#endif
+#ifdef ORC_ALT_COUNT_CANDIDATES
+#define ORC_COUNT_LISTED(cnt) ((cnt)++)
+#else
+#define ORC_COUNT_LISTED(cnt) ((void)0)
 #endif
 
 /*
@@ -599,7 +625,7 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
             const float wj = xp[4 * j + 3];
             float ex = xi0 - xp[4 * j], ey = xi1 - xp[4 * j + 1], ez = xi2 - xp[4 * j + 2];
             float l2 = dot3(ex, ey, ez, ex, ey, ez);
-            if (!(l2 < restd2)) continue;
+            if (!(l2 < restd2)) { ORC_COUNT_LISTED(cnt); continue; }
             float inv = orc_rsqrt(l2);
             float dist = ORC_LEN(l2, inv);
             float nx, ny, nz;
@@ -629,12 +655,14 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
             cn_now[a] = cn;
 #endif
         }
-        /* 4c. planes (NvFlex.h:145 collisionDistance, :149 plane form, :105-106 friction) */
+        /* 4c. planes (NvFlex.h:145 collisionDistance, :149 plane form, :105-106 friction): the candidates of collideShapes */
+        const unsigned smask = s->smask[i];
         if (types & ORC_T_SHAPES)
         for (int q = 0; q < p->numPlanes; ++q) {
             const float *pl = p->planes[q];
             float sdist = dot3(pl[0], pl[1], pl[2], xi0, xi1, xi2) + pl[3];
-            if (!(sdist < cd)) continue;
+            if (!((smask >> q) & 1u)) { if (sdist < cd) s->missed_shape_contacts++; continue; } /* (white box only) */
+            if (!(sdist < cd)) { ORC_COUNT_LISTED(cnt); continue; }
             float pen = cd - sdist;
             float c0 = pl[0] * pen, c1 = pl[1] * pen, c2 = pl[2] * pen;
 #ifndef ORC_ALT_FRICTION_POST
@@ -656,16 +684,26 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
         /* 4d. kinematic spheres (NvFlex.h:941-987), all channels set so every particle collides (NvFlex.h:163,965) */
         if (types & ORC_T_SHAPES)
         for (int q = 0; q < s->ns; ++q) {
+#ifdef ORC_ALT_CONTACT_PLANES
+            if (!((smask >> (8 + q)) & 1u)) continue;
+            const float *tp = s->splane + ((size_t)ORC_MAX_SHAPES * i + q) * 4; /* frozen tangent plane of this candidate */
+            const float nx = tp[0], ny = tp[1], nz = tp[2];
+            float sdist = dot3(nx, ny, nz, xi0, xi1, xi2) + tp[3];
+            if (!(sdist < cd)) { ORC_COUNT_LISTED(cnt); continue; }
+            float pen = cd - sdist;
+#else
             float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
             float l2 = dot3(ex, ey, ez, ex, ey, ez);
             float lim = s->sh_radius[q] + cd;
-            if (!(l2 < lim * lim)) continue;
+            if (!((smask >> (8 + q)) & 1u)) { if (l2 < lim * lim) s->missed_shape_contacts++; continue; } /* (white box only) */
+            if (!(l2 < lim * lim)) { ORC_COUNT_LISTED(cnt); continue; }
             float inv = orc_rsqrt(l2);
             float dist = ORC_LEN(l2, inv);
             float nx, ny, nz;
             if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
             else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
             float pen = lim - dist;
+#endif
             float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
 #ifndef ORC_ALT_FRICTION_POST
             float rx = ri0 - sd[q][0], ry = ri1 - sd[q][1], rz = ri2 - sd[q][2];
@@ -757,6 +795,54 @@ static void friction_pass(orc_sim *s, const float *xp, float *xn, const float *x
 }
 #endif
 
+/*
+ * 3. collideShapes -- once per substep, before the iterations ([D] stage order NvFlex.h:205 vs the per-iteration timers
+ *    :211-215; "will include all contact planes generated within NvFlexParams::shapeCollisionMargin", NvFlex.h:1074).
+ *    Per dynamic particle: the planes and kinematic spheres whose surface is closer to the PREDICTED position than
+ *    collisionDistance + shapeCollisionMargin (NvFlex.h:145 "distance particles maintain against shapes", :147 "increases
+ *    the radius used during contact finding against kinematic shapes"; softgym_cloth.h:163,170: 0.005 + 0.04), at most
+ *    maxContactsPerParticle of them (NvFlex.h:361; main.cpp:828: 6) -- planes in index order, then spheres in index order
+ *    [I: which ones survive the cap; FlingBot's scenes have 1 + 2 <= 6, so the cap never bites].  A sphere is taken at the
+ *    pose the iterations of this substep use (end of its sweep over the substep) [I].  The iterations test ONLY this set.
+ */
+static void collide_shapes(orc_sim *s, float (*sc)[3]) {
+    const orc_params *p = &s->p;
+    const float reach = p->collisionDistance + p->shapeCollisionMargin;
+    for (int i = 0; i < s->n; ++i) {
+        unsigned mask = 0u;
+        int listed = 0;
+#ifdef ORC_ALT_SHAPE_EVERY_ITERATION
+        mask = ~0u; (void)listed; (void)reach; (void)sc;
+#else
+        const float *x = s->xp + 4 * i; /* (kinematic particles get a list as well; nothing ever reads it) */
+        {
+            for (int q = 0; q < p->numPlanes && listed < p->maxContacts; ++q) {
+                const float *pl = p->planes[q];
+                float sdist = dot3(pl[0], pl[1], pl[2], x[0], x[1], x[2]) + pl[3];
+                if (sdist < reach) { mask |= 1u << q; listed++; }
+            }
+            for (int q = 0; q < s->ns && listed < p->maxContacts; ++q) {
+                float ex = x[0] - sc[q][0], ey = x[1] - sc[q][1], ez = x[2] - sc[q][2];
+                float l2 = dot3(ex, ey, ez, ex, ey, ez);
+                float lim = s->sh_radius[q] + reach;
+                if (!(l2 < lim * lim)) continue;
+                mask |= 1u << (8 + q); listed++;
+#ifdef ORC_ALT_CONTACT_PLANES
+                float inv = orc_rsqrt(l2);
+                float dist = ORC_LEN(l2, inv);
+                float nx = 0.0f, ny = 1.0f, nz = 0.0f;
+                if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
+                float *tp = s->splane + ((size_t)ORC_MAX_SHAPES * i + q) * 4; /* signed distance to it: n . (x - c) - r */
+                tp[0] = nx; tp[1] = ny; tp[2] = nz;
+                tp[3] = -(dot3(nx, ny, nz, sc[q][0], sc[q][1], sc[q][2]) + s->sh_radius[q]);
+#endif
+            }
+        }
+#endif
+        s->smask[i] = mask;
+    }
+}
+
 static void substep(orc_sim *s, int sub, float h, float inv_h) {
     const orc_params *p = &s->p;
     const int n = s->n;
@@ -797,7 +883,7 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
     /* 2. neighbours (once per substep) */
     find_neighbors(s);
 
-    /* 3. shapes at this substep: linear sweep prev -> current over the frame [I] (prev transforms: NvFlex.h:981-982) */
+    /* 3a. shapes at this substep: linear sweep prev -> current over the frame [I] (prev transforms: NvFlex.h:981-982) */
     float sc[ORC_MAX_SHAPES][3], sd[ORC_MAX_SHAPES][3];
     for (int q = 0; q < s->ns; ++q) {
         float a1 = (float)(sub + 1) / S, a0 = (float)sub / S;
@@ -815,6 +901,8 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
 #endif
         }
     }
+
+    collide_shapes(s, sc);
 
 #ifdef ORC_ALT_FRICTION_POST
     memset(s->lam, 0, sizeof(float) * (size_t)ORC_LAM_STRIDE * n);
@@ -959,6 +1047,8 @@ int orc_set_shape_states(orc_sim *s, const float *in) {
 }
 
 int orc_max_neighbor_list(const orc_sim *s) { return s->max_list; }
+int orc_get_last_shape_candidates(const orc_sim *s, unsigned *masks) { memcpy(masks, s->smask, sizeof(unsigned) * s->n); return 0; }
+int orc_missed_shape_contacts(const orc_sim *s) { return s->missed_shape_contacts; }
 
 int orc_get_last_neighbors(const orc_sim *s, int *counts, int *lists) {
     memcpy(counts, s->ncount, sizeof(int) * s->n);

@@ -72,6 +72,12 @@ int orc_max_neighbor_list(const orc_sim *s);
 
 int orc_get_last_neighbors(const orc_sim *s, int *out_counts, int *out_lists);
 
+/* collideShapes of the LAST substep run (white box): per particle the candidate mask, bit q = plane q, bit 8 + q = sphere q;
+   and how often, since set_scene, an iteration found a plane / sphere violated that was NOT a candidate (0 = the candidate
+   stage never changed a result) */
+int orc_get_last_shape_candidates(const orc_sim *s, unsigned *out_masks);
+int orc_missed_shape_contacts(const orc_sim *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,9 @@ ROWS = [  # (variant, what it changes)
     ("alt_apply_per_type", "applyDeltas after each constraint type (springs, particle contacts, shapes)"),
     ("alt_damping_mult", "damping as v = (v + h g)(1 - h damping)"),
     ("alt_stiffness_iter", "stiffness made iteration-count independent: k' = 1 - (1 - k)^(1/30)"),
+    ("alt_shape_every_iteration", "no collideShapes stage: every plane / sphere tested for every particle in every iteration (rounds 1-4)"),
+    ("alt_contact_planes", "a sphere candidate frozen at collideShapes into its tangent plane (the data model of NvFlexGetContacts, NvFlex.h:1074-1080)"),
+    ("alt_count_candidates", "Local-relaxation divisor counts every listed contact (particle and shape candidates), violated or not"),
 ]
 
 

@@ -600,6 +600,51 @@ def test_scheduled_fling_programs_reproduce_reference_golden():
     assert out[3]["skipped"] and prim.sim_steps > 0  # (the device test compares the step count with the lock-step run's)
 
 
+def test_collide_shapes_stage_lists_candidates_once_per_substep_and_never_changes_a_result():
+    """NvFlex.h:205 (collideShapes, once per substep) + :145-147 (collisionDistance + shapeCollisionMargin) + :361 / main.cpp:828
+    (maxContactsPerParticle = 6): the oracle lists, per particle, the planes / spheres within 0.005 + 0.04 of the predicted
+    position and its iterations test only those.  (a) the list is exactly that set, (b) capped at 6 -- plane first, then the
+    lowest-numbered spheres, (c) no iteration of a fling ever finds a violated contact outside the list, so (d) the trajectory
+    equals the build without the stage (-DORC_ALT_SHAPE_EVERY_ITERATION = rounds 1-4) bit for bit."""
+    from oracle import OracleSim
+
+    import scenarios as sc
+
+    # (a) one step of a resting sheet under two spheres: recompute the lists from the state before the step
+    s = OracleSim()
+    s.set_scene(cloth_params(16, 16, pos=(0.0, -0.03, 0.0)))
+    centres = np.array([(0.02, 0.06, 0.03), (0.3, 0.5, 0.3)], np.float64)
+    for c in centres:
+        s.add_sphere(0.02, c, [1, 0, 0, 0])
+    s.set_shape_states(np.array(s.get_shape_states(), np.float32))
+    s.step(3)
+    pos = s.get_positions().reshape(-1, 4).astype(np.float64)
+    m = s.get_last_shape_candidates()
+    near_ground = pos[:, 1] < 0.045 - 2e-3            # well inside / outside the reach (the lists are built on the last
+    far_ground = pos[:, 1] > 0.045 + 2e-3             # substep's PREDICTED positions, a fraction of a millimetre away)
+    assert ((m[near_ground] & 1) == 1).all() and ((m[far_ground] & 1) == 0).all()
+    d0 = np.linalg.norm(pos[:, :3] - centres[0], axis=1) - 0.02
+    assert ((m[d0 < 0.045 - 2e-3] & 0x100) != 0).all() and ((m[d0 > 0.045 + 2e-3] & 0x100) == 0).all()
+    assert (m & 0x100).any() and not (m & 0x200).any() and not (m >> 10).any()
+    # (b) the cap
+    s = OracleSim()
+    s.set_scene(cloth_params(8, 8, pos=(0.0, -0.03, 0.0)))
+    for q in range(8):
+        s.add_sphere(0.02, (0.02 + 0.002 * q, 0.04, 0.02), [1, 0, 0, 0])
+    s.set_shape_states(np.array(s.get_shape_states(), np.float32))
+    s.step(1)
+    m = s.get_last_shape_candidates()
+    assert (m == 0x1f01).all(), np.unique(m)
+    assert s.get_params()[28] == 6.0 and abs(s.get_params()[9] - 0.04) < 1e-9
+    # (c), (d): a fling with grasped corners
+    a, b = OracleSim(), OracleSim("alt_shape_every_iteration")
+    ra, rb = [], []
+    sc.scenario_fling(a, 16, 16, settle_steps=20, record=lambda sim: ra.append(sim.get_positions().copy()))
+    sc.scenario_fling(b, 16, 16, settle_steps=20, record=lambda sim: rb.append(sim.get_positions().copy()))
+    assert a.missed_shape_contacts() == 0
+    assert len(ra) == len(rb) > 100 and np.array_equal(np.array(ra).view(np.uint32), np.array(rb).view(np.uint32))
+
+
 def test_action_selection_restatement_matches_reference_golden():
     """oracle/action.py against tests/golden/action_golden.npz -- SimEnv.get_max_value_valid_action of the REFERENCE run
     on synthetic value maps and depth images (fling only / three primitives with tied values / stretchdrag / nothing

@@ -238,6 +238,82 @@ def test_fling_with_pickers_bit_exact(gpu_required, solver):
     assert np.array_equal(hip.get_shape_states(), orc.get_shape_states())
 
 
+def _with_hovering_spheres(sim, centres, radius=0.02):
+    for c in centres:
+        sim.add_sphere(radius, c, [1, 0, 0, 0])
+    sim.set_shape_states(np.array(sim.get_shape_states(), np.float32))
+
+
+@pytest.mark.parametrize("solver", SOLVERS + [0])
+def test_collide_shapes_candidates_match_oracle(gpu_required, solver):
+    """The collideShapes stage (NvFlex.h:205: once per substep; candidates within collisionDistance + shapeCollisionMargin,
+    NvFlex.h:145-147; at most maxContactsPerParticle = 6, NvFlex.h:361 / main.cpp:828): the per-particle candidate masks of
+    every back-end equal the oracle's bit for bit -- while a cloth falls past two hovering spheres onto the ground (masks go
+    from 0 to sphere bits to plane bits), during a fling (moving spheres), and with EIGHT spheres around the cloth, where the
+    cap keeps the plane and the five lowest-numbered spheres.  Positions stay bit-exact throughout; the oracle reports that no
+    iteration ever found a violated shape contact that was not a candidate."""
+    ctx, orc = _sims(solver)
+    hip = ctx.env(0)
+    # 1. falling sheet, two parked spheres on its way
+    for s in (hip, orc):
+        s.set_scene(cloth_params(32, 32, pos=(0.0, -0.12, 0.0)))
+        _with_hovering_spheres(s, [(0.03, 0.07, 0.05), (0.15, 0.02, 0.12)])
+    seen = set()
+    for k in range(45):
+        hip.step()
+        orc.step()
+        mh, mo = ctx.get_last_shape_candidates(0), orc.get_last_shape_candidates()
+        assert np.array_equal(mh, mo), f"falling sheet, step {k}"
+        seen |= set(np.unique(mo).tolist())
+    _assert_state_equal(hip, orc, "falling sheet past two spheres")
+    assert {0, 1}.issubset(seen) and any(m & 0x100 for m in seen) and any(m & 0x200 for m in seen), seen
+    # 2. scripted fling: grasped corners, moving spheres
+    ph, po = sc.scenario_fling(hip, 32, 32, settle_steps=10), sc.scenario_fling(orc, 32, 32, settle_steps=10)
+    assert ph.picked == po.picked
+    assert np.array_equal(ctx.get_last_shape_candidates(0), orc.get_last_shape_candidates())
+    _assert_state_equal(hip, orc, "fling")
+    assert orc.missed_shape_contacts() == 0
+    # 3. the cap: plane + 8 spheres within reach of the same particles -> plane and spheres 0..4 survive
+    for s in (hip, orc):
+        s.set_scene(cloth_params(32, 32, pos=(0.0, -0.03, 0.0)))
+        _with_hovering_spheres(s, [(0.1 + 0.004 * q, 0.03 + 0.002 * q, 0.1) for q in range(8)])
+    for k in range(6):
+        hip.step()
+        orc.step()
+        assert np.array_equal(ctx.get_last_shape_candidates(0), orc.get_last_shape_candidates()), f"cap, step {k}"
+    mo = orc.get_last_shape_candidates()
+    assert (mo == 0x1f01).any() and max(bin(int(m)).count("1") for m in mo) == 6
+    _assert_state_equal(hip, orc, "eight spheres")
+    assert orc.missed_shape_contacts() > 0  # (spheres 5..7 push nothing: that is what the cap means)
+    ctx.close()
+
+
+def test_collide_shapes_candidates_grid64_fused(gpu_required):
+    """The same white box on the bench kernel (fs_k_fused_grid64, 64 x 64 cloths): parked pickers far away (every wave skips the
+    sphere block), then a fling whose spheres sit inside the sheet."""
+    from flingbot_amd import sim as fsim
+
+    ctx, orc = _sims(2)
+    hip = ctx.env(0)
+    for s in (hip, orc):
+        s.set_scene(cloth_params(64, 64, pos=(0.0, -0.06, 0.0)))
+        _with_hovering_spheres(s, [(0.5, 0.5, -0.5), (-0.5, 0.5, -0.5)])
+    for k in range(12):
+        hip.step()
+        orc.step()
+        assert np.array_equal(ctx.get_last_shape_candidates(0), orc.get_last_shape_candidates()), k
+    assert ctx.last_kernel_form() == fsim.FS_FORM_FUSED_GRID64
+    assert set(np.unique(orc.get_last_shape_candidates()).tolist()) <= {0, 1}
+    _assert_state_equal(hip, orc, "parked pickers")
+    ph, po = sc.scenario_fling(hip, 64, 64, settle_steps=5, lift=0.1), sc.scenario_fling(orc, 64, 64, settle_steps=5, lift=0.1)
+    assert ph.picked == po.picked and ctx.last_kernel_form() == fsim.FS_FORM_FUSED_GRID64
+    mo = orc.get_last_shape_candidates()
+    assert np.array_equal(ctx.get_last_shape_candidates(0), mo)
+    _assert_state_equal(hip, orc, "64 x 64 fling")
+    assert orc.missed_shape_contacts() == 0
+    ctx.close()
+
+
 def test_crumple_64_fused(gpu_required):
     ctx, orc = _sims(2)
     hip = ctx.env(0)
