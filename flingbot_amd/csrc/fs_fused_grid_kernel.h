@@ -45,8 +45,7 @@
 #define FG_OFF_ROWL (FG_OFF_CHIST + 512)       // float[4][64]: rest length of the z-direction slots 8..11 per row
 #define FG_OFF_COLL (FG_OFF_ROWL + 1024)       // float[4][64]: rest length of the x-direction slots 0, 1, 4, 5 per column
 #define FG_OFF_RCNT (FG_OFF_COLL + 1024)       // float[128]: relaxationFactor / count, the IEEE quotient fs_apply computes
-#define FG_OFF_SWEEP (FG_OFF_RCNT + 512)     // FsVec4[2][16]: the substep's sphere table (fs_fused_stage_sweeps)
-#define FG_LDS_BYTES (FG_OFF_SWEEP + 2 * FS_MAX_SHAPES * 16)
+#define FG_LDS_BYTES (FG_OFF_RCNT + 512)
 // The overflow queue: a particle with contact candidates that found no room in the contact set (which takes the 1024 longest
 // lists; what is left over has one candidate, in a crowded episode two) used to evaluate them inside the main loop, where
 // every one of a wavefront's four particle slots has a few such lanes and so pays full contact evaluations for them.  They
@@ -147,7 +146,6 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
     unsigned short *items = (unsigned short *)(smem + FG_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FG_OFF_SCAN);
     float *rowL = (float *)(smem + FG_OFF_ROWL);
-    FsVec4 *const sweep = (FsVec4 *)(smem + FG_OFF_SWEEP);
 
 #ifdef FS_BLOCK_CLOCKS  // developer build: how long every workgroup runs (scripts/block_clocks.py)
     const unsigned long long tc_start = __builtin_amdgcn_s_memtime(), tr_start = __builtin_amdgcn_s_memrealtime();
@@ -271,7 +269,6 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
             // ---- predict from (X0, vel); build the spatial hash (XS = bucket-ordered copy in the X0 region)
-            fs_fused_stage_sweeps(c, sh, sub, sweep);
             for (int q = t; q < FS_FUSED_BUCKETS / 2; q += FS_FUSED_THREADS) ((unsigned *)cursor)[q] = 0u;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
@@ -293,7 +290,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                 const int i = items[qs];
                 const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
                 // collideShapes rides along: the particle's shape candidates go into the upper bits of its count word
-                const int shape_bits = (int)(fs_fused_shape_candidates(c, E.p, sweep, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
+                const int shape_bits = (int)(fs_shape_candidates(E.p, sh, sub, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
                 if (find_mode == 4) {  // grid cloth: no packed rest-near ids to carry through the search
                     FsNearWords none;
 #pragma unroll
@@ -583,7 +580,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                                                         xj.y - X0y[j], xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
                                 }
                             }
-                            fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0s, xi1s, xi2s, ri0, ri1, ri2);
+                            fs_fused_shape_contacts(a, c, E.p, sh, sub, smask, xi0s, xi1s, xi2s, ri0, ri1, ri2);
                             fg_apply(a, c.relax, rcnt, nx, ny, nz);
                         }
 #pragma unroll
@@ -628,7 +625,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cn[q];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sweep, smask2, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, smask2, xi0, xi1, xi2, ri0, ri1, ri2);
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fg_apply(a, c.relax, rcnt, n2x, n2y, n2z);
                 }
@@ -654,7 +651,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_grid64(const FsEn
                         j = jn;
                         if (sq + 2 <= more) jn = g_nlist[(unsigned)(sq + 2) * un + (unsigned)i];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, smask, xi0, xi1, xi2, ri0, ri1, ri2);
                     fg_apply(a, c.relax, rcnt, xi0, xi1, xi2);
                     squeue[q] = FsVec4{xi0, xi1, xi2, pa.w};
                 }

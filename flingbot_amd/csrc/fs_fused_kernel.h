@@ -59,10 +59,7 @@
 #define FS_FUSED_OFF_CSET (FS_FUSED_OFF_SCAN + 64)
 #define FS_FUSED_OFF_CACC (FS_FUSED_OFF_CSET + FS_FUSED_CSET_CAP * 2)
 #define FS_FUSED_OFF_CHIST (FS_FUSED_OFF_CACC + FS_FUSED_CSET_CAP * 16)
-// the kinematic spheres of this substep: FsVec4[16] centre at its end (w = radius) | FsVec4[16] displacement during it
-// (fs_shape_sweep, worked out by the first threads at the top of every substep instead of per particle and iteration)
-#define FS_FUSED_OFF_SWEEP (FS_FUSED_OFF_CHIST + 512)
-#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_SWEEP + 2 * FS_MAX_SHAPES * 16)
+#define FS_FUSED_LDS_BYTES (FS_FUSED_OFF_CHIST + 512)
 #ifndef FS_FUSED_PREFETCH_CAND
 #define FS_FUSED_PREFETCH_CAND 4  // contact candidates fetched ahead of the spring block
 #endif
@@ -519,32 +516,17 @@ __device__ __forceinline__ void fs_fused_count_offsets(int *chist, int t) {
 }
 
 // planes + kinematic spheres for one particle
-// The substep's sphere table in LDS (see FS_FUSED_OFF_SWEEP): written by fs_fused_stage_sweeps before the barrier that follows
-// the predict stage, read (uniform address: one broadcast ds_read_b128) by the candidate stage and by every iteration.
-__device__ __forceinline__ void fs_fused_stage_sweeps(const FsFusedConsts &c, const FsShapesDev &sh, int sub, FsVec4 *sweep) {
-    const int q = threadIdx.x;
-    if (q < c.n_shapes) {
-        float c0, c1, c2, s0, s1, s2;
-        fs_shape_sweep(sh, q, sub, (float)c.substeps, c0, c1, c2, s0, s1, s2);
-        sweep[q] = FsVec4{c0, c1, c2, sh.pos[q].w};
-        sweep[FS_MAX_SHAPES + q] = FsVec4{s0, s1, s2, 0.0f};
-    }
-}
-// collideShapes for one particle (fs_shape_candidates with the sweeps taken from the table: the same numbers)
-__device__ __forceinline__ unsigned fs_fused_shape_candidates(const FsFusedConsts &c, const FsParams &p, const FsVec4 *sweep,
-                                                              float x0, float x1, float x2) {
-    return fs_shape_candidates_core(p, c.n_shapes, x0, x1, x2, [&](int q, float &c0, float &c1, float &c2, float &r) {
-        const FsVec4 s = sweep[q];
-        c0 = s.x; c1 = s.y; c2 = s.z; r = s.w;
-    });
-}
+// planes + spheres for one particle of the fused kernels.  `mask`: the particle's collideShapes candidates of this substep
+// (fs_shape_candidates).  The plane test is per lane (a sheet on the ground lists it for every particle: a wave-level skip would
+// only add instructions there); the sphere block is skipped by every wavefront none of whose lanes lists a sphere -- all of
+// them while the pickers are parked -- and a sphere's sweep and test run only where a lane lists it.
+// (Measured and dropped, EXPERIMENTS R5.1: the substep's sweeps staged in an LDS table instead of recomputed per candidate, and
+// per-row wave-uniform hints -- "every particle of this row lists the plane / none lists a sphere" -- worked out once per
+// substep so that the common cases cost scalar branches only: bit-identical, and 1.5 % / 3.8 % SLOWER on the bench; both lengthen
+// live ranges in a kernel that already spills.)
 __device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedConsts &c, const FsParams &p,
-                                                        const FsVec4 *sweep, unsigned mask, float xi0, float xi1,
+                                                        const FsShapesDev &sh, int sub, unsigned mask, float xi0, float xi1,
                                                         float xi2, float ri0, float ri1, float ri2) {
-    // `mask`: the particle's collideShapes candidates of this substep (fs_shape_candidates).  The plane test is per lane (a
-    // sheet on the ground lists it for every particle: a wave-level skip would only add instructions there); the sphere block
-    // is skipped by every wavefront none of whose lanes lists a sphere -- all of them while the pickers are parked -- and a
-    // sphere's test runs only where a lane lists it.
     if (c.n_planes == 1) {
         if (mask & 1u) fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.pl0, c.pl1, c.pl2, c.pl3, c.cd, c.mu_s, c.mu_k);
     } else {
@@ -554,10 +536,12 @@ __device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedC
                                  p.planes[q][3], c.cd, c.mu_s, c.mu_k);
     }
     if (c.n_shapes == 0 || __builtin_amdgcn_ballot_w64((mask >> 8) != 0u) == 0ull) return;
+    const float S = (float)c.substeps;
     for (int q = 0; q < c.n_shapes; ++q)
         if ((mask >> (8 + q)) & 1u) {
-            const FsVec4 sc = sweep[q], sd = sweep[FS_MAX_SHAPES + q];
-            fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, sc.x, sc.y, sc.z, sc.w, sd.x, sd.y, sd.z, c.cd, c.mu_s, c.mu_k);
+            float c0, c1, c2, s0, s1, s2;
+            fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
+            fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, c.cd, c.mu_s, c.mu_k);
         }
 }
 
@@ -617,7 +601,6 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     float *X0y = X0x + FS_FUSED_MAX_PARTICLES;
     float *X0z = X0y + FS_FUSED_MAX_PARTICLES;
     unsigned short *cursor = (unsigned short *)(smem + FS_FUSED_OFF_CUR);
-    FsVec4 *const sweep = (FsVec4 *)(smem + FS_FUSED_OFF_SWEEP);
     unsigned short *items = (unsigned short *)(smem + FS_FUSED_OFF_ITEMS);
     int *wave_tot = (int *)(smem + FS_FUSED_OFF_SCAN);
 
@@ -723,7 +706,6 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll 1
         for (int sub = 0; sub < c.substeps; ++sub) {
             // ---- predict from (X0, vel) into X; build the spatial hash
-            fs_fused_stage_sweeps(c, sh, sub, sweep);
             for (int q = t; q < FS_FUSED_BUCKETS / 2; q += FS_FUSED_THREADS) ((unsigned *)cursor)[q] = 0u;
             FsVec4 xp[FS_FUSED_PPT];
 #pragma unroll
@@ -748,7 +730,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 const int i = items[qs];
                 const FsVec4 xi = FsVec4{X0x[qs], X0y[qs], X0z[qs], 0.0f};  // = XS[qs], the predicted position of i
                 // collideShapes rides along: the particle's shape candidates go into the upper bits of its count word
-                const int shape_bits = (int)(fs_fused_shape_candidates(c, E.p, sweep, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
+                const int shape_bits = (int)(fs_shape_candidates(E.p, sh, sub, xi.x, xi.y, xi.z) << FS_SHAPE_MASK_SHIFT);
                 if (find_mode == 4) {  // grid cloth: no packed rest-near ids to carry through the search
                     FsNearWords none;
 #pragma unroll
@@ -944,7 +926,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                                                     xj.z - X0z[j], c.restd, c.restd2, c.mu_p);
                             }
                         }
-                        fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0, xi1, xi2, ri0, ri1, ri2);
+                        fs_fused_shape_contacts(a, c, E.p, sh, sub, smask, xi0, xi1, xi2, ri0, ri1, ri2);
                         fs_apply(a, c.relax, nx, ny, nz);
                     }
 #pragma unroll
@@ -991,7 +973,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
 #pragma unroll
                         for (int q = 0; q < FS_FUSED_PREFETCH_CAND; ++q) cjt[q] = cn[q];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sweep, smask2, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, smask2, xi0, xi1, xi2, ri0, ri1, ri2);
                     n2x = xi0; n2y = xi1; n2z = xi2;
                     fs_apply(a, c.relax, n2x, n2y, n2z);
                 }
@@ -1019,7 +1001,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                         j = jn;
                         if (sq + 2 <= more) jn = g_nlist[(unsigned)(sq + 2) * un + (unsigned)i];
                     }
-                    fs_fused_shape_contacts(a, c, E.p, sweep, smask, xi0, xi1, xi2, ri0, ri1, ri2);
+                    fs_fused_shape_contacts(a, c, E.p, sh, sub, smask, xi0, xi1, xi2, ri0, ri1, ri2);
                     fs_apply(a, c.relax, xi0, xi1, xi2);
                     squeue[q] = FsVec4{xi0, xi1, xi2, pa.w};
                 }

@@ -219,6 +219,8 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args(argv)
+    if a.device is not None and (a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        ap.error("--device names ONE HIP device: with --gpus N (or under torch.distributed.run) every rank takes LOCAL_RANK")
     if a.gpus > 1 and os.environ.get("WORLD_SIZE") is None:   # start the ranks ourselves, before this process touches the GPU
         from .launch import launch_local_ranks
         # (`python -m flingbot_amd.evaluate ...` again, once per rank, from the same working directory)
@@ -243,7 +245,14 @@ def main(argv=None):
     if a.weights:
         ckpt = torch.load(a.weights, map_location=dev)
         policy.load_state_dict(ckpt.get("net", ckpt))          # utils.py:116-118 stores the module under 'net'
-    stats = run_tasks(policy, env, mine)
+    if mine:
+        stats = run_tasks(policy, env, mine)
+    else:  # more ranks than task blocks (13 tasks over 8 GPUs: blocks of 2, the last rank has none): nothing to run, still gathers
+        nothing = np.zeros(0, np.float32)
+        stats = {"init_coverage": nothing, "final_coverage": nothing, "simulation_steps": 0,
+                 "action_primitive_counts": {a_: 0 for a_ in env.actions},
+                 "mean": {k: float("nan") for k in ("init_coverage", "final_coverage", "best_coverage", "episode_delta_coverage",
+                                                    "episode_length")}}
     ctx.close()
     out = {"tasks": len(tasks), **stats["mean"], "action_primitive_counts": stats["action_primitive_counts"],
            "simulation_steps": stats["simulation_steps"]}
@@ -257,4 +266,8 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    # `python -m flingbot_amd.evaluate` executes this file a second time as __main__; run the package's own instance of the
+    # module instead, so that there is one copy of its state (and one place for anything that wraps its functions)
+    from flingbot_amd.evaluate import main as _package_main
+
+    _package_main()

@@ -33,13 +33,13 @@ class OracleBatch:
     """The slice of the FlingSim interface FlingPrimitives uses, on N independent CPU oracles + the numpy restatement of
     the reference picker (oracle/picker.py).  The reductions are the reference's own numpy expressions."""
 
-    def __init__(self, n, scene_params, init_pos, pickers=True):
+    def __init__(self, n, scene_params, init_pos, pickers=True, variant=None):
         from oracle import OracleSim
         from oracle.picker import OraclePicker
 
         self.sims, self.tools, self.snap = [], [], {}
         for _ in range(n):
-            o = OracleSim()
+            o = OracleSim(variant)   # variant: a sensitivity build of the oracle (tests/parity_table.py --plausibility)
             o.set_scene(scene_params)
             o.step(1)
             o.set_positions(init_pos.ravel())
@@ -285,10 +285,10 @@ def run_primitives_golden(make_sim, get_positions, get_shapes, scheduled=False):
 class OracleTaskSim:
     """The slice of the FlingSim interface flingbot_amd.tasks uses, on N bare CPU oracles (no scene yet)."""
 
-    def __init__(self, n):
+    def __init__(self, n, variant=None):
         from oracle import OracleSim
 
-        self.sims = [OracleSim() for _ in range(n)]
+        self.sims = [OracleSim(variant) for _ in range(n)]
 
     def set_scene(self, e, scene_params):
         self.sims[e].set_scene(scene_params)

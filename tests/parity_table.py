@@ -181,6 +181,119 @@ def render_fit(res):
     return "\n".join(lines)
 
 
+# ---------------------------------------------------------------------------------------------------------------- plausibility
+# The reference holds a handful of constants that were TUNED ON REAL FleX: the task generator rejects a crumpled cloth whose
+# highest particle ends above 0.4 m ("probably an error", tasks.py:263-265) and lets the hanging cloth swing out for at most 300
+# steps (tasks.py:206-216); wait_until_stable gives up after 300 steps (flex_utils.py:430-441); stretch_cloth pulls the grasp
+# points apart in 2 cm increments until the cloth's midpoint stops following, at most to 0.7 m (simEnv.py:140-184); lift_cloth
+# raises in 5 cm increments until the lowest particle clears 0.02 m, at most to 0.7 m (simEnv.py:186-200).  A reading of the
+# closed solver under which those loops run into their limits (or never engage) is less plausible than one that keeps them in
+# their working range.  This pins nothing; it RANKS readings with the only FleX-tuned numbers the reference contains.
+PLAUSIBILITY_READINGS = (None, "alt_stiffness_iter", "alt_apply_per_type", "alt_friction_post", "alt_count_candidates")
+
+
+def _plausibility_one(job):
+    variant, seed, small = job
+    import random
+
+    from fling_helpers import OracleBatch, OracleTaskSim
+    from flingbot_amd import tasks as ftasks
+    from flingbot_amd.primitives import FlingPrimitives
+
+    random.seed(seed)
+    np.random.seed(seed)
+    params = (ftasks.draw_task_parameters(min_cloth_size=24, strict_min_edge_length=24, max_cloth_size=32) if small
+              else ftasks.draw_task_parameters())                      # the reference's sizes: sides 64 ... 104
+    rec = {"variant": variant, "seed": seed, "cloth_size": [int(v) for v in params["cloth_size"]]}
+
+    class Gen(OracleTaskSim):
+        def __init__(self):
+            super().__init__(1, variant)
+            self.waits, self.stats = [], []
+
+        def wait_until_stable(self, envs, max_steps=300, tolerance=1e-2):
+            ok, steps = super().wait_until_stable(envs, max_steps, tolerance)
+            self.waits.append((bool(ok[0]), int(steps[0])))
+            return ok, steps
+
+        def cloth_stats(self, envs):
+            out = super().cloth_stats(envs)
+            self.stats.append(out[0].copy())
+            return out
+
+    gen = Gen()
+    task = ftasks.generate_tasks(gen, [params])[0]
+    rec["hold_iterations"] = len(gen.stats) - 1                      # tasks.py:206-216: <= 300 (the last call is the height test)
+    rec["generator_wait_steps"], rec["generator_wait_capped"] = gen.waits[0][1], not gen.waits[0][0]
+    rec["final_max_height"] = float(gen.stats[-1][1])
+    rec["accepted"] = task is not None
+    if task is None:
+        return rec
+    rec["initial_coverage"] = float(task["initial_coverage"] / task["flatten_area"])
+
+    class Batch(OracleBatch):
+        def wait_until_stable(self, envs, max_steps=300, tolerance=1e-2):
+            ok, steps = super().wait_until_stable(envs, max_steps, tolerance)
+            self.waits = getattr(self, "waits", []) + [(bool(ok[0]), int(steps[0]))]
+            return ok, steps
+
+    sim = Batch(1, ftasks.task_scene_arguments(task)[0], np.asarray(task["particle_pos"], np.float32).reshape(-1, 4), pickers=False,
+                variant=variant)
+    prim = FlingPrimitives(sim, range(1))
+    prim.setup_pickers()
+    prim.preaction()
+    q = sim.get_positions(0).reshape(-1, 4)
+    p1, p2 = q[np.argmin(q[:, 0]), :3].astype(np.float64), q[np.argmax(q[:, 0]), :3].astype(np.float64)
+    d0 = float(np.linalg.norm((p1 - p2)[[0, 2]]))
+    out = prim.pick_and_fling([p1], [p2], [True], [True])[0]
+    prim.postaction()
+    rec["grasp_dist"] = d0
+    rec["fling_terminated"] = bool(out["terminated"])
+    if out["dist"] is not None:
+        rec["stretch_dist"] = float(out["dist"])
+        rec["stretch_increments"] = int(round((float(out["dist"]) - d0) / 0.02))
+        rec["stretch_at_limit"] = bool(float(out["dist"]) >= 0.7)
+        rec["lift_height"] = float(out["fling_height"])
+        rec["lift_increments"] = int(round((float(out["fling_height"]) - 0.3) / 0.05))
+        rec["lift_at_limit"] = bool(float(out["fling_height"]) >= 0.7)
+    rec["postaction_wait_steps"], rec["postaction_wait_capped"] = sim.waits[-1][1], not sim.waits[-1][0]
+    from oracle.coverage import covered_area
+    rec["final_coverage"] = float(covered_area(sim.get_positions(0)) / task["flatten_area"])
+    return rec
+
+
+def plausibility(n_tasks=8, jobs=7, small=False, readings=PLAUSIBILITY_READINGS):
+    from oracle.flex import _load
+    for v in readings:
+        if v is not None:
+            _load(v)   # build before the pool forks
+    work = [(v, 100 + k, small) for k in range(n_tasks) for v in readings]
+    with Pool(min(jobs, len(work))) as pool:
+        return pool.map(_plausibility_one, work, chunksize=1)
+
+
+def render_plausibility(recs, readings=PLAUSIBILITY_READINGS):
+    def col(rs, key, fmt="%.2f", of=None):
+        vals = [r[key] for r in rs if key in r and (of is None or r.get(of))]
+        return (fmt % float(np.mean(vals))) if vals else "-"
+
+    lines = ["| reading | tasks accepted (max height <= 0.4 m) | hold loop iterations (cap 300) | generator wait_until_stable: steps, capped | "
+             "initial coverage | stretch_cloth: 2 cm increments, at the 0.7 m limit | lift_cloth: 5 cm increments, at the 0.7 m limit | "
+             "postaction wait_until_stable: steps, capped | final coverage |", "|---|" + "---|" * 8]
+    for v in readings:
+        rs = [r for r in recs if r["variant"] == v]
+        acc = [r for r in rs if r["accepted"]]
+        fl = [r for r in acc if "stretch_dist" in r]
+        lines.append(
+            f"| `{v or 'default oracle'}` | {len(acc)} / {len(rs)} | {col(rs, 'hold_iterations', '%.0f')} | "
+            f"{col(rs, 'generator_wait_steps', '%.0f')}, {sum(r['generator_wait_capped'] for r in rs)} / {len(rs)} | "
+            f"{col(acc, 'initial_coverage')} | {col(fl, 'stretch_increments', '%.1f')}, {sum(r['stretch_at_limit'] for r in fl)} / {len(fl)} | "
+            f"{col(fl, 'lift_increments', '%.1f')}, {sum(r['lift_at_limit'] for r in fl)} / {len(fl)} | "
+            f"{col(acc, 'postaction_wait_steps', '%.0f')}, {sum(r.get('postaction_wait_capped', False) for r in acc)} / {len(acc)} | "
+            f"{col(acc, 'final_coverage')} |")
+    return "\n".join(lines)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true", help="24 x 24 cloths, shorter phases (what the CPU test runs)")
@@ -188,8 +301,19 @@ if __name__ == "__main__":
     ap.add_argument("--fixture", default=None, help="a PyFleX fixture (tests/golden/capture_pyflex.py): rank the default oracle and "
                                                     "every alternative reading by their one-interval error against it")
     ap.add_argument("--pairs", action="store_true", help="with --fixture: also every pair of alternatives")
+    ap.add_argument("--plausibility", type=int, default=0, metavar="N",
+                    help="run the reference's FleX-tuned loops (task generator, wait_until_stable, stretch / lift) on N generated hard "
+                         "tasks per reading and report which readings keep them inside their working range")
+    ap.add_argument("--json", default=None, help="with --plausibility: also write the per-task records here")
     a = ap.parse_args()
-    if a.fixture:
+    if a.plausibility:
+        recs = plausibility(a.plausibility, a.jobs, small=a.quick)
+        if a.json:
+            import json
+            with open(a.json, "w") as fh:
+                json.dump(recs, fh, indent=1)
+        print(render_plausibility(recs))
+    elif a.fixture:
         print(render_fit(fit_fixture(a.fixture, a.jobs, a.pairs)))
     else:
         print(render(table(a.quick, a.jobs)))

@@ -4,6 +4,7 @@ import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -433,3 +434,137 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
             assert ev[i + 1:i + 101] == ["step"] * 100 and ev[i + 101:i + 107] == ["timer_stop", "gather", "barrier", "ctx_sync",
                                                                                 "cuda_sync", "max"]
         assert ev[-1] == "barrier" or ev[-2:] == ["close", "barrier"] or "barrier" in ev[-3:]
+
+
+# ---- `python -m flingbot_amd.evaluate --tasks set.npz --gpus 8`, end to end, on a machine without a GPU ----------------------
+# The command itself runs (argument parsing, the launcher, eight fresh `python -m flingbot_amd.evaluate` children, the block
+# split, the coverage gather, rank 0's JSON line); what a child cannot have here -- a HIP device -- is replaced INSIDE the
+# children by a sitecustomize module the test puts on their PYTHONPATH: the process group runs on gloo, the GPU context / env /
+# policy are inert stand-ins, and run_tasks returns statistics computed from the tasks it was handed (or fails, when told to).
+EVAL_SITECUSTOMIZE = r"""
+import os, sys, time
+if os.environ.get("FS_EVAL_STUB") and os.environ.get("WORLD_SIZE"):
+    sys.path.insert(0, os.environ["FS_ROOT"])
+    import numpy as np
+    import torch
+    from flingbot_amd import distributed as fdist, evaluate, nets, sim as fsim
+    import flingbot_amd.env as fenv
+
+    RANK = int(os.environ["RANK"])
+    open(os.path.join(os.environ["FS_OUT"], f"pid{RANK}"), "w").write(str(os.getpid()))
+    torch.cuda.is_available = lambda: False
+    torch.cuda.set_device = lambda d: None
+    _init, _gather = fdist.init_from_env, fdist.gather_rewards
+    fdist.init_from_env = lambda backend=None: _init("gloo")
+    fdist.gather_rewards = lambda r, device=None: _gather(r, None)
+
+    class Ctx:
+        def __init__(self, n_envs=1, device=0, solver=0, **kw):
+            self.n_envs = n_envs
+        def close(self):
+            pass
+    class Env:
+        actions, scale_factors = ["fling"], [1.0]
+        def __init__(self, ctx, episode_length=10, device=None):
+            self.sim = ctx
+    class Policy:
+        def __init__(self, **kw):
+            pass
+    def run_tasks(policy, env, tasks):
+        if str(RANK) == os.environ.get("FS_FAIL_RANK"):
+            time.sleep(1.0)                    # the other ranks are inside the gather by now
+            raise RuntimeError(f"injected failure on rank {RANK}")
+        if str(RANK) == os.environ.get("FS_KILL_RANK"):
+            import signal
+            time.sleep(1.0)
+            os.kill(os.getpid(), signal.SIGKILL)
+        init = np.array([float(t["initial_coverage"]) / float(t["flatten_area"]) for t in tasks], np.float32)
+        final = init + np.float32(0.125)
+        return {"init_coverage": init, "final_coverage": final, "simulation_steps": 10 * len(tasks),
+                "action_primitive_counts": {"fling": 3 * len(tasks)},
+                "mean": {"init_coverage": float(init.mean()), "final_coverage": float(final.mean()), "best_coverage": float(final.mean()),
+                         "episode_delta_coverage": 0.125, "episode_length": 3.0}}
+    fsim.FlingSim, fenv.BatchedFlingEnv, nets.MaximumValuePolicy, evaluate.run_tasks = Ctx, Env, Policy, run_tasks
+"""
+
+
+def _write_task_set(path, n):
+    from flingbot_amd import taskio
+    tasks = []
+    for i in range(n):
+        tasks.append({"particle_pos": np.zeros(16, np.float32), "particle_vel": np.zeros(12, np.float32), "shape_pos": np.zeros(28, np.float32),
+                      "phase": np.zeros(4, np.int32), "cloth_size": np.array([2, 2]), "cloth_stiff": np.array([0.9, 0.9, 0.9]),
+                      "mesh_verts": np.array([]), "mesh_stretch_edges": np.array([]), "mesh_bend_edges": np.array([]),
+                      "mesh_shear_edges": np.array([]), "mesh_faces": np.array([]), "flatten_area": 0.5, "initial_coverage": 0.01 * (i + 1),
+                      "cloth_mass": 0.5, "flip_mesh": 0, "task_difficulty": "hard"})
+    assert taskio.save_tasks(path, tasks) == n
+
+
+def _run_evaluate(tmp_path, extra_env, n_tasks=13, gpus=8):
+    (tmp_path / "site").mkdir(exist_ok=True)
+    (tmp_path / "site" / "sitecustomize.py").write_text(EVAL_SITECUSTOMIZE)
+    tasks = str(tmp_path / "set.npz")
+    _write_task_set(tasks, n_tasks)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(PYTHONPATH=os.pathsep.join([str(tmp_path / "site"), ROOT, env.get("PYTHONPATH", "")]), FS_ROOT=ROOT,
+               FS_OUT=str(tmp_path), FS_EVAL_STUB="1", **extra_env)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-m", "flingbot_amd.evaluate", "--tasks", tasks, "--gpus", str(gpus), "--slots", "4"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    pids = [int(open(tmp_path / f"pid{r}").read()) for r in range(gpus) if (tmp_path / f"pid{r}").exists()]
+    return out, pids, time.time() - t0
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    try:  # a zombie that nobody reaped yet still answers kill(0): look at its state
+        with open(f"/proc/{pid}/stat") as fh:
+            return fh.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_evaluate_command_eight_ranks_end_to_end_uneven_blocks(tmp_path):
+    """13 tasks over 8 ranks: blocks of 2, rank 6 gets one, rank 7 none -- and the summary still covers exactly the 13."""
+    import json
+
+    out, pids, _ = _run_evaluate(tmp_path, {})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(pids) == 8                 # rank 0 prints, once
+    rec = json.loads(lines[0])
+    init = np.array([0.01 * (i + 1) / 0.5 for i in range(13)], np.float32)
+    assert rec["gpus"] == 8 and rec["episodes"] == 13 and rec["tasks"] == 13 and rec["simulation_steps"] == 130
+    assert rec["init_coverage"] == pytest.approx(float(init.mean()), rel=1e-6)
+    assert rec["final_coverage"] == pytest.approx(float((init + np.float32(0.125)).mean()), rel=1e-6)
+    assert rec["episode_delta_coverage"] == pytest.approx(0.125, rel=1e-5)
+    assert not any(_alive(p) for p in pids)
+
+
+@pytest.mark.parametrize("how", ["raises", "killed"])
+def test_evaluate_command_propagates_a_failing_rank_and_leaves_no_children(tmp_path, how):
+    """The failure path of the one-process-per-GPU layout (the reference's counterpart: a Ray worker that dies, utils.py:144-157):
+    rank 5 raises inside its evaluation (or is killed) while the other seven wait in the coverage gather.  The command must end
+    promptly with that rank's status -- 1 for the exception, 128 + 9 for SIGKILL -- print no result line, and leave none of
+    the eight children behind."""
+    out, pids, seconds = _run_evaluate(tmp_path, {"FS_FAIL_RANK" if how == "raises" else "FS_KILL_RANK": "5"})
+    assert out.returncode == (1 if how == "raises" else 137), (out.returncode, out.stderr[-2000:])
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if how == "raises":
+        assert "injected failure on rank 5" in out.stderr
+    assert len(pids) == 8 and seconds < 120
+    deadline = time.time() + 15
+    while time.time() < deadline and any(_alive(p) for p in pids):
+        time.sleep(0.2)
+    assert not any(_alive(p) for p in pids), [p for p in pids if _alive(p)]
+
+
+def test_evaluate_command_rejects_device_with_several_ranks(tmp_path):
+    out = subprocess.run([sys.executable, "-m", "flingbot_amd.evaluate", "--tasks", "x.npz", "--gpus", "2", "--device", "0"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert out.returncode == 2 and "--device names ONE HIP device" in out.stderr

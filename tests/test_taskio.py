@@ -1,6 +1,7 @@
 """Task storage without HDF5: flingbot_amd/taskio.py (.npz interchange, Task, TaskLoader) and the
 evaluation loop running from a stored file."""
 import os
+import sys
 import random
 
 import numpy as np
@@ -76,6 +77,66 @@ def test_converter_script_is_standalone():
               isinstance(t.targets[0], ast.Name) and t.targets[0].id in ("ARRAY_FIELDS", "SCALAR_FIELDS")}
     assert consts["ARRAY_FIELDS"] == taskio.ARRAY_FIELDS and consts["SCALAR_FIELDS"] == taskio.SCALAR_FIELDS
     assert '"flingbot_amd tasks v1"' in src and taskio.FORMAT == "flingbot_amd tasks v1"
+
+
+def test_converter_script_runs_on_the_reference_writers_layout(tmp_path, monkeypatch):
+    """scripts/convert_tasks_hdf5.py EXECUTED (h5py is not in this image, so the two calls it makes -- h5py.File as a context
+    manager, groups that are mappings of datasets with an `attrs` mapping -- are served by an in-memory stand-in laid out the
+    way the reference's writer lays a file out, environment/tasks.py:303-320: floats / ints / np.float64 / str as group
+    attributes, everything else as datasets, group key = sha1 of the running count; h5py hands str attributes back as bytes or
+    str depending on its version, both are covered).  The converted file loads through taskio and equals the source tasks."""
+    import hashlib
+    import importlib.util
+    import types
+
+    from flingbot_amd import taskio
+
+    def ref_task(i):
+        n = 3 + i
+        return {"particle_pos": np.arange(4 * n, dtype=np.float32), "particle_vel": np.zeros(3 * n, np.float32),
+                "shape_pos": np.arange(28, dtype=np.float32), "phase": np.full(n, 7, np.int32), "cloth_size": np.array([n, 1]),
+                "cloth_stiff": np.array([0.9, 0.8, 0.7]), "mesh_verts": np.array([]), "mesh_stretch_edges": np.array([]),
+                "mesh_bend_edges": np.array([]), "mesh_shear_edges": np.array([]), "mesh_faces": np.array([]),
+                "flatten_area": np.float64(0.25 + i), "initial_coverage": 0.1 * (i + 1), "cloth_mass": 0.5 + i, "flip_mesh": 0,
+                "task_difficulty": "hard" if i % 2 else "easy"}
+
+    class Group(dict):
+        def __init__(self):
+            super().__init__()
+            self.attrs = {}
+
+    store = {}
+    for i in range(3):                                            # the reference's writer loop
+        g = store[hashlib.sha1(f"{len(store)}".encode()).hexdigest()] = Group()
+        for key, value in ref_task(i).items():
+            if type(value) in (float, int, np.float64, str):
+                g.attrs[key] = value.encode() if isinstance(value, str) and i == 2 else value   # (old h5py: bytes)
+            else:
+                g[key] = value
+
+    class File:
+        def __init__(self, path, mode):
+            assert path == "tasks.hdf5" and mode == "r"
+        def __enter__(self):
+            return store
+        def __exit__(self, *exc):
+            return False
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=File))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "convert_tasks_hdf5.py")
+    spec = importlib.util.spec_from_file_location("convert_tasks_hdf5", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "set.npz")
+    assert mod.convert("tasks.hdf5", out) == 3
+    tasks = taskio.TaskLoader(out, repeat=False).all_tasks()
+    assert [t.name for t in tasks] == list(store)                  # file order = the order the reference's TaskLoader walks
+    for i, t in enumerate(tasks):
+        want = ref_task(i)
+        for f in taskio.ARRAY_FIELDS:
+            assert np.array_equal(np.asarray(t[f]), want[f]), (i, f)
+        assert float(t.flatten_area) == float(want["flatten_area"]) and float(t.initial_coverage) == want["initial_coverage"]
+        assert float(t.cloth_mass) == want["cloth_mass"] and int(t.flip_mesh) == 0 and str(t.task_difficulty) == want["task_difficulty"]
 
 
 @pytest.mark.gpu
