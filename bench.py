@@ -39,8 +39,16 @@ N_PART = DIM * DIM
 N_SPRINGS = 23938
 SUBSTEPS, ITERS = 4, 30
 # algorithmic bytes per pyflex.step() = S x [112 N + I x (32 N + 16 M)]
-BYTES_PER_STEP = SUBSTEPS * (112 * N_PART + ITERS * (32 * N_PART + 16 * N_SPRINGS))   # 63,524,608
+BYTES_PER_STEP = SUBSTEPS * (112 * N_PART + ITERS * (32 * N_PART + 16 * N_SPRINGS))   # 63,524,608 (= algorithmic_bytes_per_step(64, 64))
 HBM_PEAK_GBS = 8000.0               # /opt/skills/guides/MI355X_MICROARCH.md chip table (spec)
+
+
+def algorithmic_bytes_per_step(dimx, dimz):
+    """SURVEY.md 8(d)'s streaming model for a dimx x dimz grid cloth: S x [112 N + I x (32 N + 16 M)] with the spring count of
+    helpers.h:838-924 (stretch + bend + shear)."""
+    n = dimx * dimz
+    m = (dimx - 1) * dimz + dimx * (dimz - 1) + max(dimx - 2, 0) * dimz + dimx * max(dimz - 2, 0) + 2 * (dimx - 1) * (dimz - 1)
+    return SUBSTEPS * (112 * n + ITERS * (32 * n + 16 * m))
 
 
 def scene_params():
@@ -166,7 +174,7 @@ def traffic_from_profile(episodes):
 def limiter_from_profile():
     """What the committed PMC counters say actually limits the fused kernel (it keeps the iterations in LDS, so the
     contract's algorithmic-bytes `roofline` is an equivalent streamed bandwidth, not HBM traffic)."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
         try:
             with open(path) as fh:
@@ -217,7 +225,7 @@ def stream_limiter_from_profile():
     """What the committed profiles say about the 64-episodes-per-GPU launch shape (streaming back-end, two launch
     chains): per-kernel share and duration of one frame's 129 dependent launches."""
     import csv
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{tag}_stream64_kernel_stats.csv")
         try:
             rows = list(csv.reader(open(path)))[1:]
@@ -248,7 +256,7 @@ def mfma_from_profile():
     SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 flops over the kernel's summed duration = fp32 MFMA flops ISSUED per second (useful work
     + the 12.5 % halo the fused blocks recompute), against the 157.3 TFLOP/s dense fp32-MFMA peak."""
     import re
-    for tag in ("r04", "r01"):
+    for tag in ("r05", "r04", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_cnn_pmc.txt")
         try:
             for line in open(path):
@@ -684,11 +692,24 @@ def run_rank(args):
                          "kernel_ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": BYTES_PER_STEP * E},
             "mean_coverage": float(cov_all.mean().item()),
         }
+        # `roofline` above is the contract's figure (algorithmic bytes of the streaming model / kernel time).  The
+        # LDS-resident kernel does not move those bytes, so the figure saturates: a faster kernel prints a fraction above 1 of
+        # a bandwidth nobody uses.  What physically bounds it is VALU issue: `valu_roofline` is the number to read, and it leads.
+        out["roofline"]["saturated"] = bool(out["roofline"]["frac"] > 1.0)
+        if out["roofline"]["saturated"]:
+            out["roofline"]["note"] = "metric saturated: equivalent bandwidth above the HBM peak -- see valu_roofline"
         if fused:
-            out["limiter"] = limiter_from_profile()
-            out["valu_roofline"] = valu_roofline(out["limiter"], E, kern_ms)
-            if out["valu_roofline"]:
-                out["valu_frac_of_peak"] = out["valu_roofline"]["frac"]
+            limiter = limiter_from_profile()
+            vr = valu_roofline(limiter, E, kern_ms)
+            if vr:   # lead with the physical bound: re-insert it right in front of the contract's `roofline`
+                head = {k: out.pop(k) for k in list(out) if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                                                      "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                                                      "dtype", "data", "config")}
+                out["valu_roofline"] = vr
+                out["valu_frac_of_peak"] = vr["frac"]
+                out["roofline_that_bounds_the_kernel"] = "valu_roofline"
+                out.update(head)
+            out["limiter"] = limiter
         if not args.no_parity:
             parity_main = ParityCheck(ctx, E // 2, E // 2, args.preroll + args.warmup + args.steps)
     ctx.close()
@@ -823,7 +844,13 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream
             sched = stats["scheduler"]
             ctx.close()
             n_tasks = len(tasks)
-            return {"episodes": n_tasks, "slots": n_slots, "max_actions": actions, "cloth_sides": [int(sides.min()), int(sides.max())],
+            mean_bytes = float(np.mean([algorithmic_bytes_per_step(int(a_), int(b_)) for a_, b_ in sides])) if len(sides) else 0.0
+            return {"episodes": n_tasks, "slots": n_slots,
+                    # SURVEY 8(d)'s equivalent bandwidth for configs[4]: the episode-steps of the loop x the mean algorithmic bytes of
+                    # a step over the task set's cloth sizes (every task weighted equally; steps per task are not recorded) / the
+                    # WALL time of the whole loop -- perception, action selection, resets and host scheduling included
+                    "roofline_frac_equivalent": stats["simulation_steps"] * mean_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                    "mean_algorithmic_bytes_per_step": mean_bytes, "max_actions": actions, "cloth_sides": [int(sides.min()), int(sides.max())],
                     "transforms": len(env.transformations), "render_dim": env.render_dim, "image_dim": env.image_dim,
                     "seconds": dt, "task_generation_seconds": t_gen, "flings": flings, "flings_per_s": flings / dt,
                     "episode_steps": int(stats["simulation_steps"]), "episode_steps_per_s": stats["simulation_steps"] / dt,

@@ -189,6 +189,17 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
     }
     if (device < 0 || device >= count) { fs_set_error("device index out of range"); return nullptr; }
     if (!fs_hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+    {   // The library holds gfx950 code objects only, and the solver's reciprocal square root is that chip's v_rsq_f32 as data
+        // (oracle/v_rsq_f32_gfx950.npz): another architecture gets a clear refusal here instead of "no kernel image" later.
+        hipDeviceProp_t prop;
+        if (!fs_hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return nullptr;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            static char msg[160];
+            snprintf(msg, sizeof(msg), "device %d is %s: libflingsim is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+            fs_set_error(msg);
+            return nullptr;
+        }
+    }
     fs_ctx *ctx = new fs_ctx();
     ctx->device = device;
     ctx->n_envs = n_envs;
@@ -284,6 +295,12 @@ static FsEnv *get_env(fs_ctx *ctx, int env, bool need_scene = true) {
     FsEnv *e = &ctx->envs[env];
     if (need_scene && !e->has_scene) { fs_set_error("env has no scene: call fs_set_scene first"); return nullptr; }
     return e;
+}
+
+extern "C" int fs_fused_fits(fs_ctx *ctx, int env) {
+    FsEnv *e = get_env(ctx, env);
+    if (!e) return FS_ERR_ARG;
+    return fs_fused_supported(ctx, *e) ? 1 : 0;
 }
 
 int fs_lane_guard(fs_ctx *ctx, int env) {

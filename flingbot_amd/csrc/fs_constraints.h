@@ -35,6 +35,9 @@ __device__ __forceinline__ float fs_dot3(float ax, float ay, float az, float bx,
 // its input bits, and the CPU oracle reproduces it from a table of this chip's 2^24 (exponent parity, mantissa) results
 // (oracle/v_rsq_f32_gfx950.npz, dumped through fs_eval_rsqrt; the GPU suite re-reads the whole table on the box it runs
 // on), so HIP and oracle still agree bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "fs_rsqrt is gfx950's v_rsq_f32 AS DATA: the goldens and oracle/v_rsq_f32_gfx950.npz hold this chip's results. Another --offload-arch needs its own table (tests/golden/make_rsq_table.py) before it may be added to the build."
+#endif
 __device__ __forceinline__ float fs_rsqrt(float x) {
     return __builtin_amdgcn_rsqf(__builtin_fmaxf(x, 1.17549435e-38f));
 }

@@ -622,6 +622,7 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
     const FsShapesDev &sh = shapes[e];
     const FsFusedConsts c = fs_fused_consts(E, sh);
     const int n = c.n;
+    const int kmax = (n + FS_FUSED_THREADS - 1) / FS_FUSED_THREADS;  // particle slots per thread that hold a particle for some thread
     const unsigned un = (unsigned)n;
     const int t = threadIdx.x;
 
@@ -855,6 +856,11 @@ __global__ __launch_bounds__(FS_FUSED_THREADS) void fs_k_fused_step(const FsEnvD
                 for (int q = 0; q < FS_FUSED_PPT; ++q) { rx[q] = 0.0f; ry[q] = 0.0f; rz[q] = 0.0f; }
 #pragma unroll 1
                 for (int k = 0; k < FS_FUSED_PPT; ++k) {
+                    if (k >= kmax) {  // a particle slot no thread has (cloths of <= 3072 particles): rotate, compute nothing
+#pragma unroll
+                        for (int q = FS_FUSED_PPT - 1; q > 0; --q) { rx[q] = rx[q - 1]; ry[q] = ry[q - 1]; rz[q] = rz[q - 1]; }
+                        continue;
+                    }
                     const int i_raw = t + k * FS_FUSED_THREADS;
                     const int i = i_raw < n ? i_raw : 0;  // lanes past the end recompute particle 0 and discard it
                     uint32_t jw_n[JW], cw_n[JW];

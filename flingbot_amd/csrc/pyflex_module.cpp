@@ -28,7 +28,7 @@ static void fail(const char *what) { throw std::runtime_error(std::string(what) 
 static void ck(int rc, const char *what) {
     if (rc < 0) fail(what);
 }
-static int g_shared_gpu = -1;  // FLINGSIM_SHARED_GPU (see pyflex_step): -1 unread, 0 off, 1 on, 2 on but the scene does not fit
+static bool g_shared_gpu = false;  // FLINGSIM_SHARED_GPU, read once in pyflex.init (see pyflex_set_scene)
 static fs_ctx *ctx() {
     if (!g_ctx) throw std::runtime_error("pyflex.init() has not been called");
     return g_ctx;
@@ -43,6 +43,8 @@ static void pyflex_init(bool headless, bool render, int camera_width, int camera
     if (const char *s = std::getenv("FLINGSIM_DEVICE")) device = std::atoi(s);
     g_ctx = fs_create(device, 1, camera_width, camera_height);
     if (!g_ctx) fail("pyflex.init");
+    const char *shared = std::getenv("FLINGSIM_SHARED_GPU");
+    g_shared_gpu = shared && std::atoi(shared) != 0;
 }
 
 static void pyflex_clean() {
@@ -55,11 +57,13 @@ static void pyflex_set_scene(int scene_idx, farr scene_params, farr vertices, ia
                              iarr shear_edges, iarr faces, int thread_idx) {
     (void)thread_idx;
     if (scene_idx != 0) throw std::runtime_error("pyflex.set_scene: only scene_idx 0 (SoftgymCloth) exists");
-    if (g_shared_gpu == 2) g_shared_gpu = 1;
     ck(fs_set_scene(ctx(), 0, scene_params.data(), (int)scene_params.size(), vertices.data(), (int)vertices.size(),
                     stretch_edges.data(), (int)stretch_edges.size(), bend_edges.data(), (int)bend_edges.size(),
                     shear_edges.data(), (int)shear_edges.size(), faces.data(), (int)faces.size()),
        "pyflex.set_scene");
+    // FLINGSIM_SHARED_GPU (below): chosen here, per scene, so that everything that steps this scene -- pyflex.step, movep / step_n,
+    // wait_until_stable -- runs on the same back-end from the first step on
+    if (g_shared_gpu) ck(fs_set_solver(ctx(), fs_fused_fits(ctx(), 0) > 0 ? FS_SOLVER_FUSED : FS_SOLVER_AUTO), "pyflex.set_scene");
 }
 
 // pyflex.cpp:213-222: update_params / capture / path are ignored by the cloth scene; render only toggles drawing
@@ -67,22 +71,11 @@ static void pyflex_set_scene(int scene_idx, farr scene_params, farr vertices, ia
 // per Ray worker, `--num_processes 16`, README.md:147-148).  A lone cloth steps fastest on the streaming kernels (129 small
 // launches spread over the chip), but the chip dispatches ~250 k such launches per second IN TOTAL, so sixteen processes doing
 // that share one process's rate; the fused kernel is ONE launch per frame on one compute unit, and sixteen of those do run side
-// by side.  With the switch the module prefers the fused kernel whenever the cloth fits it (<= 4096 particles) and falls back to
-// AUTO when it does not.  Results are identical either way.
+// by side.  With the switch (read once, in pyflex.init) set_scene selects the fused kernel for a cloth that fits it (<= 4096
+// particles) and AUTO otherwise.  Results are identical either way.
 static void pyflex_step(py::object update_params, int capture, py::object path, int render) {
     (void)update_params; (void)capture; (void)path; (void)render;
-    if (g_shared_gpu < 0) {
-        const char *s = std::getenv("FLINGSIM_SHARED_GPU");
-        g_shared_gpu = (s && std::atoi(s) != 0) ? 1 : 0;
-    }
-    if (g_shared_gpu == 1 && fs_get_solver(ctx()) != FS_SOLVER_FUSED) fs_set_solver(ctx(), FS_SOLVER_FUSED);
-    int rc = fs_step(ctx(), 0, 1);
-    if (rc == FS_ERR_STATE && g_shared_gpu == 1) {  // the cloth does not fit the LDS-resident kernel
-        fs_set_solver(ctx(), FS_SOLVER_AUTO);
-        g_shared_gpu = 2;                           // (asked for, not applicable to this scene; set_scene re-arms it)
-        rc = fs_step(ctx(), 0, 1);
-    }
-    ck(rc, "pyflex.step");
+    ck(fs_step(ctx(), 0, 1), "pyflex.step");
 }
 
 static std::tuple<py::array_t<unsigned char>, py::array_t<float>> pyflex_render() {

@@ -58,6 +58,7 @@ def load_library(build_if_missing=True):
         "fs_n_envs": (ci, [vp]),
         "fs_set_solver": (ci, [vp, ci]),
         "fs_get_solver": (ci, [vp]),
+        "fs_fused_fits": (ci, [vp, ci]),
         "fs_last_kernel_form": (ci, [vp]),
         "fs_last_boundary_form": (ci, [vp]),
         "fs_set_stream_groups": (ci, [vp, ci]),

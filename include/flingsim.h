@@ -54,6 +54,10 @@ void fs_destroy(fs_ctx *ctx);
 int fs_n_envs(const fs_ctx *ctx);
 int fs_set_solver(fs_ctx *ctx, int solver);
 int fs_get_solver(const fs_ctx *ctx);
+/* 1 when FS_SOLVER_FUSED can step this episode (<= 4096 particles, one collision plane at most), 0 when it cannot (the
+   caller then keeps FS_SOLVER_AUTO): lets a front end choose the back-end when a scene is set instead of finding out from a
+   failed fs_step */
+int fs_fused_fits(fs_ctx *ctx, int env);
 
 /* pyflex.set_scene (pyflex.cpp:229-244 -> main.cpp:613 Init -> softgym_cloth.h:33 Initialize).
    scene_params[19] layout: flex_utils.py:332-342.  Empty `verts` selects the grid path (helpers.h:838). */
