@@ -342,6 +342,8 @@ class StubSim:
     def set_particles(self, envs, pids, pos4, zero_velocity=True): pass
     def step_list(self, envs, n=1): self.steps += n; LOG.append(("step_list", n))
     def movep(self, envs, targets, grasp, speed=0.1, limit=1000, min_steps=None, eps=1e-4):
+        if os.environ.get("FS_C2_FAIL_RANK") == str(RANK) and self.n_envs == 4:
+            raise RuntimeError("movep: step limit reached (injected)")       # one rank's fling script fails in the first C2 leg
         self.last_movep_steps = 3 * len(envs); LOG.append(("movep", len(envs))); return np.full(len(envs), 3, np.int32)
     def add_sphere(self, e, radius, pos, quat): self.shapes = getattr(self, "shapes", {}); self.shapes.setdefault(e, []).append(list(pos))
     def get_shape_states(self, e): return np.zeros(14 * len(self.shapes.get(e, [])), np.float32)
@@ -356,6 +358,8 @@ args = types.SimpleNamespace(episodes=4, steps=3, warmup=1, preroll=2, solver=2,
 bench.run_rank(args)
 seeds_ok = all(np.array_equal(s.first_pos[e], bench.initial_state(RANK * s.n_envs + e, 8192.0).ravel())
                for s in StubSim.instances[:2] for e in range(s.n_envs))
+if os.environ.get("FS_C2_FAIL_RANK"):
+    seeds_ok = True
 with open(os.path.join(os.environ["FS_OUT"], f"rank{RANK}.json"), "w") as fh:
     json.dump({"log": LOG, "seeds_ok": bool(seeds_ok), "sizes": [s.n_envs for s in StubSim.instances]}, fh)
 """
@@ -568,3 +572,31 @@ def test_evaluate_command_rejects_device_with_several_ranks(tmp_path):
     out = subprocess.run([sys.executable, "-m", "flingbot_amd.evaluate", "--tasks", "x.npz", "--gpus", "2", "--device", "0"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
     assert out.returncode == 2 and "--device names ONE HIP device" in out.stderr
+
+
+def test_bench_survives_a_rank_failing_inside_the_c2_leg(tmp_path):
+    """bench.c2_leg: rank 1's fling script raises (a movep that runs into its step limit) while rank 0's succeeds.  Both ranks
+    must agree on the failure before the next collective, so nobody hangs; the headline and the 64-episode entry are printed
+    as usual, the failed entry carries `error`, the second C2 entry (64 episodes, which does not fail) is measured normally."""
+    import json
+
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FS_ROOT=ROOT, FS_OUT=str(tmp_path), FS_C2_FAIL_RANK="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(out)
+    rec = json.loads([l for l in outs[0].splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["configs"][1]["episodes_per_gpu"] == 64
+    by_key = {c.get("key"): c for c in rec["configs"]}
+    assert "error" in by_key["c2_fling_4"] and "value" not in by_key["c2_fling_4"]      # rank 0 itself did not fail: "another rank"
+    assert "another rank failed" in by_key["c2_fling_4"]["error"]
+    assert by_key["c2_fling_64"]["value"] > 0 and "ratio_to_crumpled_sheet" in by_key["c2_fling_64"]
+    assert "fling_phase_ratio" not in rec
