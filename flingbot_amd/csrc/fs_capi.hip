@@ -194,9 +194,8 @@ extern "C" fs_ctx *fs_create(int device, int n_envs, int camera_width, int camer
         hipDeviceProp_t prop;
         if (!fs_hip_ok(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return nullptr;
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-            static char msg[160];
-            snprintf(msg, sizeof(msg), "device %d is %s: libflingsim is built for gfx950 (MI355X) only", device, prop.gcnArchName);
-            fs_set_error(msg);
+            fs_set_error("device " + std::to_string(device) + " is " + prop.gcnArchName +
+                         ": libflingsim is built for gfx950 (MI355X) only");
             return nullptr;
         }
     }
