@@ -314,6 +314,41 @@ def test_collide_shapes_candidates_grid64_fused(gpu_required):
     ctx.close()
 
 
+@pytest.mark.parametrize("dims", [(16, 16), (24, 24), (40, 20), (45, 23), (48, 48), (56, 55)])
+def test_small_cloths_on_the_fused_kernel_bit_exact(gpu_required, dims):
+    """fs_k_fused_step skips the particle slots no thread holds a particle for (kmax = ceil(N / 1024): 1, 1, 1, 2, 3, 4 here;
+    EXPERIMENTS R5.2): crumple + settle of cloths below 4096 particles on the fused back-end -- alone and as a batch of five
+    different seeds in one launch -- equals the oracle bit for bit, neighbour lists included."""
+    from flingbot_amd import sim as fsim
+    from oracle import OracleSim
+
+    ctx = fsim.FlingSim(n_envs=5, solver=2)
+    orcs = [OracleSim() for _ in range(5)]
+    for e in range(5):
+        for s in (ctx.env(e), orcs[e]):
+            s.set_scene(cloth_params(*dims, pos=(0.0, -0.15 - 0.01 * e, 0.0)))
+            r = np.random.RandomState(17 * e + dims[0])
+            p = s.get_positions().reshape(-1, 4).copy()
+            p[:, :3] = (r.rand(p.shape[0], 3) * [0.12, 0.08, 0.12] + [0, 0.03, 0]).astype(np.float32)   # loose heap: contacts at once
+            s.set_positions(p.ravel())
+            s.set_velocities(np.zeros(3 * p.shape[0], np.float32))
+    ctx.step(12)                                    # all five in one launch
+    assert ctx.last_kernel_form() in (fsim.FS_FORM_FUSED_12, fsim.FS_FORM_FUSED_16, fsim.FS_FORM_FUSED_GENERIC)
+    for e in range(5):
+        orcs[e].step(12)
+        _assert_state_equal(ctx.env(e), orcs[e], f"{dims} episode {e}")
+        ch, lh = ctx.get_last_neighbors(e)
+        co, lo = orcs[e].get_last_neighbors()
+        assert np.array_equal(ch, co) and co.max() >= 2
+        mask = np.arange(96)[None, :] < co[:, None]
+        assert np.array_equal(np.where(mask, lh, -1), np.where(mask, lo, -1))
+        assert np.array_equal(ctx.get_last_shape_candidates(e), orcs[e].get_last_shape_candidates())
+    ctx.env(2).step(3)                              # and one of them alone
+    orcs[2].step(3)
+    _assert_state_equal(ctx.env(2), orcs[2], f"{dims} episode 2, stepped alone")
+    ctx.close()
+
+
 def test_crumple_64_fused(gpu_required):
     ctx, orc = _sims(2)
     hip = ctx.env(0)
