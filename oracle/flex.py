@@ -66,6 +66,7 @@ def rsqrt_table():
     global _rsq_table
     if _rsq_table is None:
         with np.load(os.path.join(_HERE, "v_rsq_f32_gfx950.npz")) as z:
+            assert str(z["arch"]) == "gfx950", "the table holds ONE chip's v_rsq_f32: it must be the architecture the kernels are built for"
             _rsq_table = np.ascontiguousarray(z["delta2bit"], np.uint8)
         assert _rsq_table.size == 1 << 22
     return _rsq_table
