@@ -648,6 +648,18 @@ def run_rank(args):
 
     E = args.episodes
     ctx = fsim.FlingSim(n_envs=E, device=local_rank, solver=args.solver)
+    # what the collective saw, not what WORLD_SIZE claims: one all_gather of (rank, LOCAL_RANK, device identity, architecture).
+    # Every rank gets the same table, so every rank takes the same decision: two ranks on one GPU => no figure at all.
+    try:
+        arch = torch.cuda.get_device_properties(local_rank).gcnArchName
+    except Exception:
+        arch = ""
+    census = fdist.rank_census(ctx.device_key(), arch)
+    if census["ranks_seen"] != world or census["distinct_devices"] != world:
+        ctx.close()
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but the process group's all_gather saw {census['ranks_seen']} rank(s) on "
+                         f"{census['distinct_devices']} distinct device(s) ({census['backend']}): one process per GPU is the "
+                         f"contract, refusing to report a {world}-GPU figure")
     for e, g in enumerate(fdist.episode_range(rank, E)):
         setup_episode(ctx.env(e), seed=g)  # global episode id = seed
     ctx.sync()
@@ -667,6 +679,8 @@ def run_rank(args):
             "value": value,
             "unit": "sim steps/s",
             "n_gpus": world,
+            "ranks_seen": census["ranks_seen"], "distinct_devices": census["distinct_devices"], "backend": census["backend"],
+            "collective_library": census["collective_library"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -702,7 +716,8 @@ def run_rank(args):
             limiter = limiter_from_profile()
             vr = valu_roofline(limiter, E, kern_ms)
             if vr:   # lead with the physical bound: re-insert it right in front of the contract's `roofline`
-                head = {k: out.pop(k) for k in list(out) if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                head = {k: out.pop(k) for k in list(out) if k not in ("metric", "value", "unit", "n_gpus", "ranks_seen", "distinct_devices", "backend",
+                                                                      "collective_library", "steps", "warmup",
                                                                       "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                                                                       "dtype", "data", "config")}
                 out["valu_roofline"] = vr

@@ -11,7 +11,9 @@ Workloads:
   picker  the call pattern of Picker.step around every simulation step (environment/flex_utils.py:104-205):
           get_shape_states + get_positions (Picker._get_pos), get_shape_states + set_shape_states + set_positions
           (Picker._set_pos), pyflex.step() -- on a 64 x 64 cloth with the two picker spheres.
-The 16-process case is run twice: as is, and with FLINGSIM_SHARED_GPU=1 (the module's switch for exactly this deployment).
+The 16-process case is run three times: as an unmodified caller gets it (FLINGSIM_SHARED_GPU unset: the module's co-tenant
+table, csrc/fs_tenants.cpp, finds the other workers and picks the back-end), with the detection overridden to "alone"
+(FLINGSIM_SHARED_GPU=0: the streaming kernels, the default of rounds 1-5) and to "shared" (=1).
 Processes: the reference runs one PyFleX per Ray worker (`--num_processes 16`, README.md:147-148, utils.py:144-157); here 16
 fresh interpreters, each with its own pyflex.init, started together and released by a wall-clock start time, share one
 MI355X.  The parent of the workers never touches the GPU.  Reported next to the batched face's numbers in bench.py.
@@ -45,6 +47,7 @@ def worker(mode, steps, start_at):
             pyflex.add_sphere(0.02, np.array(c), np.array([1., 0., 0., 0.]))
     pyflex.step()
     pyflex.get_positions()                       # warm: everything allocated, the device idle
+    tenants0 = pyflex._tenants()
     while time.time() < start_at:
         time.sleep(0.0005)
     t0 = time.time()
@@ -66,14 +69,18 @@ def worker(mode, steps, start_at):
             pyflex.step()
         pyflex.get_positions()
     t1 = time.time()
-    print(json.dumps({"mode": mode, "steps": steps, "t0": t0, "t1": t1}), flush=True)
+    print(json.dumps({"mode": mode, "steps": steps, "t0": t0, "t1": t1, "tenants_at_start": tenants0[0], "backend_at_start": tenants0[1],
+                      "tenants_at_end": pyflex._tenants()[0], "backend_at_end": pyflex._tenants()[1]}), flush=True)
 
 
-def run(mode, n_procs, steps, timeout=300, shared_gpu=False):
+def run(mode, n_procs, steps, timeout=300, shared_gpu=None):
     """n_procs fresh interpreters, released together; returns aggregate steps/s over [first start, last end].
-    shared_gpu: the workers run with FLINGSIM_SHARED_GPU=1 (csrc/pyflex_module.cpp: prefer the one-launch-per-frame kernel)."""
+    shared_gpu: None = FLINGSIM_SHARED_GPU unset, what an unmodified caller gets (csrc/pyflex_module.cpp asks the co-tenant
+    table); False / True = the variable set to 0 / 1 (never / always the one-launch-per-frame kernel for a cloth that fits it)."""
     start_at = time.time() + 6.0 + 0.5 * n_procs          # enough for every child to import, init and warm up
-    env = dict(os.environ, FLINGSIM_SHARED_GPU="1" if shared_gpu else "0")
+    env = {k: v for k, v in os.environ.items() if k != "FLINGSIM_SHARED_GPU"}
+    if shared_gpu is not None:
+        env["FLINGSIM_SHARED_GPU"] = "1" if shared_gpu else "0"
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", mode, "--steps", str(steps),
                                "--start-at", repr(start_at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
              for _ in range(n_procs)]
@@ -93,7 +100,10 @@ def run(mode, n_procs, steps, timeout=300, shared_gpu=False):
         return {"processes": n_procs, "error": str(errs[:2])}
     late = sum(1 for r in recs if r["t0"] > start_at + 0.05)
     span = max(r["t1"] for r in recs) - min(r["t0"] for r in recs)
-    return {"processes": n_procs, "shared_gpu_switch": bool(shared_gpu), "finished": len(recs), "steps_per_process": steps, "seconds": span,
+    return {"processes": n_procs, "shared_gpu_switch": {None: "unset (detected)", False: "0", True: "1"}[shared_gpu],
+            "backends_at_end": sorted({r.get("backend_at_end", "?") for r in recs}),
+            "tenants_seen": [min(r.get("tenants_at_end", 0) for r in recs), max(r.get("tenants_at_end", 0) for r in recs)],
+            "finished": len(recs), "steps_per_process": steps, "seconds": span,
             "steps_per_s": sum(r["steps"] for r in recs) / span,
             "slowest_process_steps_per_s": min(r["steps"] / (r["t1"] - r["t0"]) for r in recs),
             "late_starters": late, "failed": len(errs)}
@@ -104,12 +114,13 @@ def measure(procs=(1, 16)):
            "note": "one cloth per process like the reference (Ray worker = PyFleX instance); every getter / setter is a "
                    "synchronous copy as in pyflex.cpp.  The batched face (FlingSim: all episodes of a process in one launch "
                    "sequence, movep on the device) is the supported throughput path; this is what unmodified callers get."}
-    out["c1_32x32_200_steps"] = [run("c1", n, 200) for n in procs] + [run("c1", max(procs), 200, shared_gpu=True)]
-    out["picker_pattern_64x64"] = [run("picker", n, 200) for n in procs] + [run("picker", max(procs), 200, shared_gpu=True)]
-    out["shared_gpu_switch"] = ("FLINGSIM_SHARED_GPU=1 in the workers' environment: the module steps a cloth that fits it on the fused "
-                                "kernel (one launch per frame on one compute unit) instead of the streaming kernels (129 launches per "
-                                "frame): slower for a lone process, but sixteen of them run side by side where sixteen launch chains "
-                                "share the chip's dispatch rate")
+    for key, mode in (("c1_32x32_200_steps", "c1"), ("picker_pattern_64x64", "picker")):
+        out[key] = [run(mode, n, 200) for n in procs] + [run(mode, max(procs), 200, shared_gpu=False), run(mode, max(procs), 200, shared_gpu=True)]
+    out["shared_gpu_switch"] = ("unset: pyflex.init registers the process in the device's co-tenant table (a per-user file under /dev/shm), "
+                                "set_scene and every 64th step count the live tenants; with two or more the module steps a cloth that fits "
+                                "it on the fused kernel (one launch per frame on one compute unit) instead of the streaming kernels (129 "
+                                "launches per frame): slower for a lone process, but sixteen of them run side by side where sixteen launch "
+                                "chains share the chip's dispatch rate.  FLINGSIM_SHARED_GPU=0 / 1 overrides the detection")
     return out
 
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libflingsim.so")
 ARCH = "gfx950"
 
-LIB_SOURCES = ["fs_capi.hip", "fs_solver.hip", "fs_render.hip", "fs_picker.hip", "fs_loops.hip", "fs_image.hip", "fs_action.hip", "fs_valuenet.hip", "fs_observe.hip", "fs_hostapi.hip", "fs_scene.cpp"]
+LIB_SOURCES = ["fs_capi.hip", "fs_solver.hip", "fs_render.hip", "fs_picker.hip", "fs_loops.hip", "fs_image.hip", "fs_action.hip", "fs_valuenet.hip", "fs_observe.hip", "fs_hostapi.hip", "fs_scene.cpp", "fs_tenants.cpp"]
 # -amdgpu-kernarg-preload-count: the first 16 kernel-argument dwords arrive in SGPRs with the wave instead of behind an
 # s_load -- one scalar round trip less in front of every kernel, which the streaming back-end's ~130 dependent launches per
 # frame feel (measured: 64x64 cloths x 8 / 64 episodes 1.04 / 1.424 -> 0.98 / 1.392 ms per step)

@@ -262,7 +262,7 @@ extern "C" int fs_service_lane(fs_ctx *ctx, int on) {
 extern "C" void fs_destroy(fs_ctx *ctx) { delete ctx; }
 extern "C" int fs_n_envs(const fs_ctx *ctx) { return ctx ? ctx->n_envs : FS_ERR_ARG; }
 extern "C" int fs_set_solver(fs_ctx *ctx, int solver) {
-    if (!ctx || solver < 0 || solver > 8) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
+    if (!ctx || solver < 0 || solver > FS_SOLVER_COTENANT) { fs_set_error("bad solver id"); return FS_ERR_ARG; }
     ctx->force_merged_boundary = (solver == FS_SOLVER_STREAM_MERGED);
     ctx->force_coded_stream = (solver == FS_SOLVER_STREAM_CODED);
     ctx->force_split_boundary = (solver == FS_SOLVER_STREAM_SPLIT);
@@ -294,6 +294,12 @@ static FsEnv *get_env(fs_ctx *ctx, int env, bool need_scene = true) {
     FsEnv *e = &ctx->envs[env];
     if (need_scene && !e->has_scene) { fs_set_error("env has no scene: call fs_set_scene first"); return nullptr; }
     return e;
+}
+
+extern "C" int fs_device_key(fs_ctx *ctx, char *out, int n_chars) {
+    if (!ctx || !out || n_chars < 16) return FS_ERR_ARG;
+    HIP_TRY(hipDeviceGetPCIBusId(out, n_chars, ctx->device));   // e.g. "0000:05:00.0": the same for every process, whatever
+    return FS_OK;                                              // HIP_VISIBLE_DEVICES made of the device's index
 }
 
 extern "C" int fs_fused_fits(fs_ctx *ctx, int env) {
@@ -602,6 +608,12 @@ extern "C" int fs_step_list(fs_ctx *ctx, int n, const int *envs, int n_steps) {
 
 int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int *d_ids) {
     int solver = ctx->solver;
+    if (solver == FS_SOLVER_COTENANT) {
+        // a process that shares the device (include/flingsim.h): the fused kernel whenever the launch fits it, else as AUTO
+        solver = FS_SOLVER_FUSED;
+        for (int id : ids)
+            if (!fs_fused_supported(ctx, ctx->envs[id])) solver = FS_SOLVER_AUTO;
+    }
     if (solver == FS_SOLVER_AUTO) {
         // The fused kernel gives one CU to an episode for the whole frame: unbeatable once the launch fills the chip, but a
         // small launch leaves most CUs idle while the streaming kernels spread every stage over all of them.  Measured

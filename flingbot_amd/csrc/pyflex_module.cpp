@@ -28,10 +28,30 @@ static void fail(const char *what) { throw std::runtime_error(std::string(what) 
 static void ck(int rc, const char *what) {
     if (rc < 0) fail(what);
 }
-static bool g_shared_gpu = false;  // FLINGSIM_SHARED_GPU, read once in pyflex.init (see pyflex_set_scene)
+// How many processes share the device decides the back-end (csrc/fs_tenants.cpp): a lone cloth steps fastest on the streaming
+// kernels (129 small launches per frame spread over the chip), but the chip dispatches such launches at one rate IN TOTAL, so
+// sixteen processes doing that -- the reference's documented deployment, one PyFleX per Ray worker, `--num_processes 16`,
+// README.md:147-148 -- share one process's rate; the fused kernel is ONE launch per frame on one compute unit, and sixteen of
+// those do run side by side.  FS_SOLVER_COTENANT takes the fused kernel for every launch that fits it (<= 4096 particles) and
+// AUTO's choice otherwise; results are identical either way (every back-end equals the oracle bit for bit).
+//   FLINGSIM_SHARED_GPU unset  the module finds out by itself: pyflex.init registers the process in the device's co-tenant
+//                              table, set_scene (and every 64th step) counts the live tenants; two or more => COTENANT
+//   FLINGSIM_SHARED_GPU=1 / 0  the caller's word wins: always / never COTENANT (tenants in other containers or of other users
+//                              are invisible to the table)
+static int g_shared_env = -1;      // -1: unset (detect), 0 / 1: FLINGSIM_SHARED_GPU, read once in pyflex.init
+static bool g_cotenant = false;    // the back-end in force
+static char g_device_key[64] = "";
+static unsigned g_steps_since_check = 0;
 static fs_ctx *ctx() {
     if (!g_ctx) throw std::runtime_error("pyflex.init() has not been called");
     return g_ctx;
+}
+static void choose_backend(bool prune) {
+    bool shared = g_shared_env > 0;
+    if (g_shared_env < 0 && g_device_key[0]) shared = fs_tenants_count(g_device_key, prune ? 1 : 0) >= 2;
+    if (shared != g_cotenant || prune) ck(fs_set_solver(ctx(), shared ? FS_SOLVER_COTENANT : FS_SOLVER_AUTO), "pyflex");
+    g_cotenant = shared;
+    g_steps_since_check = 0;
 }
 
 // pyflex.cpp:15-124.  m.def has no py::arg there either: four required positionals.
@@ -44,11 +64,18 @@ static void pyflex_init(bool headless, bool render, int camera_width, int camera
     g_ctx = fs_create(device, 1, camera_width, camera_height);
     if (!g_ctx) fail("pyflex.init");
     const char *shared = std::getenv("FLINGSIM_SHARED_GPU");
-    g_shared_gpu = shared && std::atoi(shared) != 0;
+    g_shared_env = (shared && *shared) ? (std::atoi(shared) != 0 ? 1 : 0) : -1;
+    // always registered, whatever the switch says about THIS process: the others count us
+    if (fs_device_key(g_ctx, g_device_key, (int)sizeof(g_device_key)) != FS_OK || fs_tenants_register(g_device_key) < 0)
+        g_device_key[0] = 0;   // no table (no writable /dev/shm or /tmp): behave as a lone tenant unless the switch says otherwise
+    choose_backend(true);
 }
 
 static void pyflex_clean() {
-    if (g_ctx) fs_destroy(g_ctx);
+    if (g_ctx) {
+        if (g_device_key[0]) fs_tenants_unregister(g_device_key);
+        fs_destroy(g_ctx);
+    }
     g_ctx = nullptr;
 }
 
@@ -61,20 +88,17 @@ static void pyflex_set_scene(int scene_idx, farr scene_params, farr vertices, ia
                     stretch_edges.data(), (int)stretch_edges.size(), bend_edges.data(), (int)bend_edges.size(),
                     shear_edges.data(), (int)shear_edges.size(), faces.data(), (int)faces.size()),
        "pyflex.set_scene");
-    // FLINGSIM_SHARED_GPU (below): chosen here, per scene, so that everything that steps this scene -- pyflex.step, movep / step_n,
-    // wait_until_stable -- runs on the same back-end from the first step on
-    if (g_shared_gpu) ck(fs_set_solver(ctx(), fs_fused_fits(ctx(), 0) > 0 ? FS_SOLVER_FUSED : FS_SOLVER_AUTO), "pyflex.set_scene");
+    // every episode reset re-reads the co-tenant table (and clears the entries of workers that died): the back-end follows
+    // the deployment without the caller knowing about it
+    choose_backend(true);
 }
 
 // pyflex.cpp:213-222: update_params / capture / path are ignored by the cloth scene; render only toggles drawing
-// FLINGSIM_SHARED_GPU=1: this process is one of many that share the GPU, the way the reference runs its environments (one PyFleX
-// per Ray worker, `--num_processes 16`, README.md:147-148).  A lone cloth steps fastest on the streaming kernels (129 small
-// launches spread over the chip), but the chip dispatches ~250 k such launches per second IN TOTAL, so sixteen processes doing
-// that share one process's rate; the fused kernel is ONE launch per frame on one compute unit, and sixteen of those do run side
-// by side.  With the switch (read once, in pyflex.init) set_scene selects the fused kernel for a cloth that fits it (<= 4096
-// particles) and AUTO otherwise.  Results are identical either way.
 static void pyflex_step(py::object update_params, int capture, py::object path, int render) {
     (void)update_params; (void)capture; (void)path; (void)render;
+    // workers start together: one that reached its first set_scene before its neighbours had called pyflex.init would step the
+    // whole episode as a lone tenant -- so the count is refreshed every 64 steps (an unlocked scan of <= 62 slots)
+    if (g_shared_env < 0 && ++g_steps_since_check >= 64) choose_backend(false);
     ck(fs_step(ctx(), 0, 1), "pyflex.step");
 }
 
@@ -278,4 +302,14 @@ PYBIND11_MODULE(pyflex, m) {
         return py::make_tuple(stable != 0, steps);
     }, py::arg("max_steps") = 300, py::arg("tolerance") = 1e-2,
           "flex_utils.wait_until_stable (flex_utils.py:430-441) looped on the device; returns (stable, steps taken)");
+    // white box for the tests and for bench_dropin.py: (live tenants of this process's device, back-end in force)
+    m.def("_tenants", []() {
+        const int n = g_device_key[0] ? fs_tenants_count(g_device_key, 0) : 0;
+        return py::make_tuple(n, g_cotenant ? "cotenant" : "auto", std::string(g_device_key));
+    }, "co-tenant table of the device (csrc/fs_tenants.cpp): (live processes, back-end in force, device key)");
+    // a worker that ends without pyflex.clean (the reference's never call it) leaves the table by itself; one that is killed is
+    // cleared by the next tenant that prunes
+    py::module_::import("atexit").attr("register")(py::cpp_function([]() {
+        if (g_device_key[0]) fs_tenants_unregister(g_device_key);
+    }));
 }

@@ -60,3 +60,44 @@ def max_over_ranks(value, device=None):
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def _hash63(text):
+    import hashlib
+    return int.from_bytes(hashlib.sha1(str(text).encode()).digest()[:8], "big") >> 1
+
+
+def rank_census(device_identity, arch=""):
+    """What the process group ITSELF saw, as opposed to what the environment variables claim: every rank contributes
+    (rank, LOCAL_RANK, hash of its device's identity -- the PCI bus id, FlingSim.device_key() --, hash of its architecture
+    name) to one all_gather (RCCL when the backend is "nccl", on the rank's own device) and every rank gets the same answer:
+        ranks_seen        distinct rank numbers in the gathered table (== world size when the collective spans the job)
+        distinct_devices  distinct physical devices behind those ranks (one process per GPU <=> == world size)
+        distinct_archs    1 on a homogeneous node
+        backend, collective_library   what carried the gather ("nccl" + RCCL's version on ROCm, "gloo" in the CPU tests)
+    bench.py and evaluate.py refuse to report a multi-GPU figure when distinct_devices != world size (two ranks on one GPU)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = torch.tensor([rank, local_rank, _hash63(device_identity), _hash63(arch)], dtype=torch.int64)
+    out = {"backend": "none (world size 1: no process group)", "collective_library": None}
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        backend = str(dist.get_backend())
+        out["backend"] = backend
+        if backend == "nccl":
+            mine = mine.to(torch.device("cuda", torch.cuda.current_device()))
+            try:
+                out["collective_library"] = "RCCL/NCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                out["collective_library"] = "RCCL (version unavailable)"
+        rows = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+        table = torch.stack(rows).cpu()
+        out["world_size"] = int(dist.get_world_size())
+    else:
+        table = mine.reshape(1, 4)
+        out["world_size"] = 1
+    out["ranks_seen"] = int(torch.unique(table[:, 0]).numel())
+    out["distinct_devices"] = int(torch.unique(table[:, 2]).numel())
+    out["distinct_archs"] = int(torch.unique(table[:, 3]).numel())
+    out["local_ranks"] = [int(v) for v in table[:, 1]]
+    return out

@@ -13,7 +13,7 @@ from . import build as _build
 
 FS_SOLVER_AUTO, FS_SOLVER_STREAM, FS_SOLVER_FUSED = 0, 1, 2
 FS_SOLVER_FUSED_GENERIC, FS_SOLVER_STREAM_ELL, FS_SOLVER_FUSED_CODED, FS_SOLVER_STREAM_CODED = 3, 4, 5, 6  # test / comparison variants (include/flingsim.h)
-FS_SOLVER_STREAM_SPLIT, FS_SOLVER_STREAM_MERGED = 7, 8
+FS_SOLVER_STREAM_SPLIT, FS_SOLVER_STREAM_MERGED, FS_SOLVER_COTENANT = 7, 8, 9
 # fs_last_kernel_form (white box): which kernel form the last solver launch ran
 (FS_FORM_FUSED_12, FS_FORM_FUSED_16, FS_FORM_FUSED_GENERIC, FS_FORM_STREAM_EAGER, FS_FORM_STREAM_CODED, FS_FORM_STREAM_ELL,
  FS_FORM_STREAM_GRID, FS_FORM_FUSED_GRID64, FS_FORM_STREAM_GRIDL) = range(1, 10)
@@ -146,13 +146,24 @@ def load_library(build_if_missing=True):
         "fs_get_last_neighbors": (ci, [vp, ci, ip, ip]),
         "fs_get_last_shape_candidates": (ci, [vp, ci, ip]),
         "fs_device_positions": (vp, [vp, ci]),
+        "fs_device_key": (ci, [vp, C.c_char_p, ci]),
+        "fs_tenants_register": (ci, [C.c_char_p]),
+        "fs_tenants_count": (ci, [C.c_char_p, ci]),
+        "fs_tenants_unregister": (ci, [C.c_char_p]),
     }
+    unbound = []
     for name, (res, args) in proto.items():
         if "FLINGSIM_LIB" in os.environ and not hasattr(lib, name):
-            continue  # development override with an older build of the library (A/B timing): entry points it predates stay unbound
+            unbound.append(name)   # development override with an older build of the library (A/B timing): entry points it
+            continue               # predates stay unbound -- and are named below, so a stale or mistyped override is seen
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if unbound:
+        import warnings
+        warnings.warn(f"FLINGSIM_LIB={os.environ['FLINGSIM_LIB']}: this build lacks {len(unbound)} C-ABI entries of "
+                      f"include/flingsim.h ({', '.join(unbound)}); calls to them will fail, and its results may differ from "
+                      f"this tree's oracle", RuntimeWarning, stacklevel=2)
     lib._fs_symbols = tuple(proto)
     _lib = lib
     return lib
@@ -204,6 +215,12 @@ class FlingSim:
 
     def set_solver(self, solver):
         self._ck(self.lib.fs_set_solver(self.h, int(solver)))
+
+    def device_key(self):
+        """fs_device_key: the PCI bus id of the context's device -- the same string in every process that drives this GPU."""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.fs_device_key(self.h, buf, 64))
+        return buf.value.decode()
 
     def last_kernel_form(self):
         """FS_FORM_* of the most recent solver launch (white box for the parity tests)."""

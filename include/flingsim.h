@@ -42,6 +42,9 @@ typedef struct fs_ctx fs_ctx;
                                      (the form cloths above 16384 particles and launches of fewer than 16 episodes take)
                                      instead of fs_k_boundary */
 #define FS_SOLVER_STREAM_MERGED 8 /* STREAM, with fs_k_boundary at every launch size */
+#define FS_SOLVER_COTENANT 9      /* for a process that SHARES the device with others (fs_tenants_*): every launch whose episodes
+                                     all fit the fused kernel takes it whatever the launch size (one launch per frame on one
+                                     compute unit each -- co-tenants' frames run side by side), every other launch is AUTO's */
 
 const char *fs_last_error(void);
 int fs_version(void);
@@ -58,6 +61,18 @@ int fs_get_solver(const fs_ctx *ctx);
    caller then keeps FS_SOLVER_AUTO): lets a front end choose the back-end when a scene is set instead of finding out from a
    failed fs_step */
 int fs_fused_fits(fs_ctx *ctx, int env);
+
+/* Co-tenant table (csrc/fs_tenants.cpp): the reference runs one PyFleX per Ray worker on one GPU (`--num_processes 16`,
+   README.md:147-148, utils.py:144-157); the processes of one user that drive the same physical device through this library find
+   each other in a small mmap-ed file per (user, device) under /dev/shm (FLINGSIM_TENANT_DIR overrides), so that the `pyflex`
+   module can pick FS_SOLVER_COTENANT by itself.  `device_key` names the physical device: fs_device_key() = its PCI bus id.
+   fs_tenants_register: add this process, returns the number of live tenants including it; fs_tenants_count: live tenants
+   (prune != 0: also clear the entries of processes that died without unregistering); fs_tenants_unregister: remove this process.
+   Host-only (no HIP call): usable, and tested, without a GPU. */
+int fs_device_key(fs_ctx *ctx, char *out, int n_chars);
+int fs_tenants_register(const char *device_key);
+int fs_tenants_count(const char *device_key, int prune);
+int fs_tenants_unregister(const char *device_key);
 
 /* pyflex.set_scene (pyflex.cpp:229-244 -> main.cpp:613 Init -> softgym_cloth.h:33 Initialize).
    scene_params[19] layout: flex_utils.py:332-342.  Empty `verts` selects the grid path (helpers.h:838). */

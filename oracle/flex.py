@@ -37,7 +37,7 @@ VARIANTS = ("exact", "exact_rsqrt", "nofma", "newton", "host")  # host: exact_rs
 # (PARITY.md); they are never the parity oracle either.
 MODEL_ALTERNATIVES = ("friction_post", "neighbors_by_distance", "shape_end_pose", "sleep_velocity_only", "sleep_at_predict",
                       "no_sleep", "apply_per_type", "damping_mult", "stiffness_iter", "shape_every_iteration", "contact_planes",
-                      "count_candidates")
+                      "count_candidates", "no_maxaccel", "maxaccel_per_frame", "maxaccel_position", "kinematic_velocity_kept")
 
 
 def build_oracle(force=False):
@@ -118,6 +118,8 @@ def _load(variant=None):
     lib.orc_max_neighbor_list.argtypes = [vp]
     lib.orc_get_last_shape_candidates.argtypes = [vp, ip]
     lib.orc_missed_shape_contacts.argtypes = [vp]
+    for name in ("orc_accel_clamps", "orc_degenerate_normals"):
+        getattr(lib, name).argtypes, getattr(lib, name).restype = [vp], C.c_long
     _libs[variant] = lib
     return lib
 
@@ -274,3 +276,11 @@ class OracleSim:
     def missed_shape_contacts(self):
         """How often an iteration found a plane / sphere violated that collideShapes had not listed (since set_scene)."""
         return self.lib.orc_missed_shape_contacts(self.h)
+
+    def accel_clamps(self):
+        """Particle-substeps in which finalize's maxAcceleration clamp (NvFlex.h:112-113) changed a velocity (since set_scene)."""
+        return int(self.lib.orc_accel_clamps(self.h))
+
+    def degenerate_normals(self):
+        """Contacts whose normal fell back to (0,1,0) because the pair was coincident (since set_scene)."""
+        return int(self.lib.orc_degenerate_normals(self.h))

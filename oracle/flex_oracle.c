@@ -69,13 +69,16 @@ struct orc_sim {
     float *splane;   /* ORC_ALT_CONTACT_PLANES only: n x ORC_MAX_SHAPES x 4, the frozen tangent plane of each sphere candidate */
     int missed_shape_contacts; /* white box: contacts that violated inside an iteration without being a candidate (since set_scene) */
     float *lam;    /* ORC_ALT_FRICTION_POST only */
+    float *vframe; /* ORC_ALT_MAXACCEL_PER_FRAME only: 3n, the velocities at the start of the NvFlexUpdateSolver call */
+    long accel_clamps;       /* white box: particle-substeps in which the maxAcceleration clamp changed a velocity (since set_scene) */
+    long degenerate_normals; /* white box: contacts whose normal fell back to (0,1,0) because the pair was coincident (since set_scene) */
 };
 
 static void free_scene(orc_sim *s) {
     free(s->pos); free(s->vel); free(s->phase); free(s->rest); free(s->sidx); free(s->slen); free(s->sk);
     free(s->tris); free(s->tnrm); free(s->nrm); free(s->adj_off); free(s->adj_spr);
     free(s->xp); free(s->xn); free(s->x0); free(s->v0); free(s->ncount); free(s->nlist);
-    free(s->cell_key); free(s->cell_order); free(s->lam); free(s->smask); free(s->splane);
+    free(s->cell_key); free(s->cell_order); free(s->lam); free(s->smask); free(s->splane); free(s->vframe);
     memset(s, 0, sizeof(*s));
 }
 
@@ -313,6 +316,11 @@ int orc_set_scene(orc_sim *s, const float *ptr, const float *verts, int n_vert_f
     s->ns = 0;
     s->smask = (unsigned *)calloc(n + 1, sizeof(unsigned));
     s->missed_shape_contacts = 0;
+    s->accel_clamps = 0;
+    s->degenerate_normals = 0;
+#ifdef ORC_ALT_MAXACCEL_PER_FRAME
+    s->vframe = (float *)calloc((size_t)3 * (n + 1), sizeof(float));
+#endif
 #ifdef ORC_ALT_CONTACT_PLANES
     s->splane = (float *)calloc((size_t)ORC_MAX_SHAPES * 4 * (n + 1), sizeof(float));
 #endif
@@ -388,12 +396,26 @@ static int cell_lower_bound(const orc_sim *s, const int *keys, int cx, int cy, i
  *   -DORC_ALT_COUNT_CANDIDATES       the Local-relaxation divisor counts every LISTED contact of the particle (particle
  *                                    candidates and shape candidates), violated or not (NvFlex.h:89 "divided by the
  *                                    particle's constraint count"; default: only the constraints that pushed this iteration)
+ *   -DORC_ALT_NO_MAXACCEL            the maxAcceleration clamp of finalize is skipped (how much the rule matters at all;
+ *                                    NvFlex.h:112-113 "clamped to this value at the end of each step")
+ *   -DORC_ALT_MAXACCEL_PER_FRAME     "each step" read as each NvFlexUpdateSolver call: the velocity change since the START OF
+ *                                    THE FRAME is clamped to maxAcceleration * dt once, after the last substep (default: per
+ *                                    substep, change since the substep's start clamped to maxAcceleration * dt / substeps)
+ *   -DORC_ALT_MAXACCEL_POSITION      a clamped particle's position follows its clamped velocity, x = x0 + h v (default: the
+ *                                    velocity alone is clamped, the position keeps what the iterations produced -- so the
+ *                                    particle moved farther than v h says); combines with either clamp period
+ *   -DORC_ALT_KINEMATIC_VELOCITY_KEPT  finalize leaves the velocity of an invMass-0 particle alone, so a particle the picker
+ *                                    releases resumes with the velocity it had when it was pinned (default: zeroed while
+ *                                    pinned = what v = (x* - x) / h gives for a particle the solver does not move)
  * The static-friction branch has no alternative worth a build: with mu_s <= mu_k (0 <= 0.75 for shapes, 1 = 1 between
  * particles) "full stick below mu_s * depth" and "clamp to mu_k * depth" give the same scale for every input
  * (tests/test_oracle_cpu.py::test_static_friction_branch_is_redundant).
  */
 #if defined(ORC_ALT_SLEEP_VELOCITY_ONLY) + defined(ORC_ALT_SLEEP_AT_PREDICT) + defined(ORC_ALT_NO_SLEEP) > 1
 #error "one sleep alternative at a time"
+#endif
+#if defined(ORC_ALT_NO_MAXACCEL) && (defined(ORC_ALT_MAXACCEL_PER_FRAME) || defined(ORC_ALT_MAXACCEL_POSITION))
+#error "no clamp at all excludes the other clamp alternatives"
 #endif
 #if defined(ORC_ALT_CONTACT_PLANES) && (defined(ORC_ALT_SHAPE_EVERY_ITERATION) || defined(ORC_ALT_FRICTION_POST))
 #error "contact planes need the candidate stage and the in-iteration friction"
@@ -630,7 +652,7 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
             float dist = ORC_LEN(l2, inv);
             float nx, ny, nz;
             if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
-            else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+            else { nx = 0.0f; ny = 1.0f; nz = 0.0f; s->degenerate_normals++; /* (white box only) */ }
             float pen = restd - dist;
             float ratio = wi / (wi + wj);
             float cn = pen * ratio;
@@ -701,7 +723,7 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
             float dist = ORC_LEN(l2, inv);
             float nx, ny, nz;
             if (dist > 0.0f) { nx = ORC_OVER_LEN(ex, dist, inv); ny = ORC_OVER_LEN(ey, dist, inv); nz = ORC_OVER_LEN(ez, dist, inv); }
-            else { nx = 0.0f; ny = 1.0f; nz = 0.0f; }
+            else { nx = 0.0f; ny = 1.0f; nz = 0.0f; s->degenerate_normals++; /* (white box only) */ }
             float pen = lim - dist;
 #endif
             float c0 = nx * pen, c1 = ny * pen, c2 = nz * pen;
@@ -849,6 +871,9 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
     float *xp = s->xp, *xn = s->xn, *x0 = s->x0, *v0 = s->v0;
     const float S = (float)p->numSubsteps;
 
+#ifdef ORC_ALT_MAXACCEL_PER_FRAME
+    if (sub == 0) memcpy(s->vframe, s->vel, sizeof(float) * 3 * n);
+#endif
     /* 1. predict (NvFlex.h:99 gravity, :117 damping [form I], :545 invMass 0 = kinematic) */
     for (int i = 0; i < n; ++i) {
         const float w = s->pos[4 * i + 3];
@@ -930,34 +955,62 @@ static void substep(orc_sim *s, int sub, float h, float inv_h) {
     /* 5. finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping
           (NvFlex.h:110 "velocity magnitude < threshold => considered fixed"; Macklin 2014 section 4.5 freezes the
           position when the particle moved less than the threshold; we also zero the velocity [I]) */
+    /* [I] "at the end of each step" (NvFlex.h:112-113): the default reads a step as a substep -- the velocity change since the
+       substep's start is clamped to maxAcceleration * h, and only the VELOCITY is clamped (the position keeps what the
+       iterations produced).  ORC_ALT_MAXACCEL_PER_FRAME / _POSITION / ORC_ALT_NO_MAXACCEL are the other readings. */
+#if defined(ORC_ALT_MAXACCEL_PER_FRAME)
+    const float maxdv = p->maxAcceleration * p->dt;
+    const int clamp_now = (sub == p->numSubsteps - 1);
+#elif defined(ORC_ALT_NO_MAXACCEL)
+    const float maxdv = FLT_MAX;
+    const int clamp_now = 0;
+#else
     const float maxdv = p->maxAcceleration * h;
+    const int clamp_now = 1;
+#endif
     const float thr2 = p->sleepThreshold * p->sleepThreshold;
     for (int i = 0; i < n; ++i) {
         const float w = s->pos[4 * i + 3];
+#ifdef ORC_ALT_KINEMATIC_VELOCITY_KEPT
+        if (!(w > 0.0f)) continue;
+#else
         if (!(w > 0.0f)) { for (int k = 0; k < 3; ++k) s->vel[3 * i + k] = 0.0f; continue; }
-        float v[3], dv[3];
-        for (int k = 0; k < 3; ++k) { v[k] = (xp[4 * i + k] - x0[4 * i + k]) * inv_h; dv[k] = v[k] - v0[3 * i + k]; }
+#endif
+#ifdef ORC_ALT_MAXACCEL_PER_FRAME
+        const float *vref = s->vframe + 3 * i;
+#else
+        const float *vref = v0 + 3 * i;
+#endif
+        float v[3], dv[3], xe[3];
+        for (int k = 0; k < 3; ++k) { xe[k] = xp[4 * i + k]; v[k] = (xe[k] - x0[4 * i + k]) * inv_h; dv[k] = v[k] - vref[k]; }
         float dv2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
-        if (dv2 > maxdv * maxdv) {
+        if (clamp_now && dv2 > maxdv * maxdv) {
             float sc_ = maxdv / sqrtf(dv2);
-            for (int k = 0; k < 3; ++k) v[k] = v0[3 * i + k] + dv[k] * sc_;
+            for (int k = 0; k < 3; ++k) v[k] = vref[k] + dv[k] * sc_;
+            s->accel_clamps++; /* (white box only) */
+#ifdef ORC_ALT_MAXACCEL_POSITION
+            for (int k = 0; k < 3; ++k) xe[k] = x0[4 * i + k] + h * v[k];
+#endif
         }
         float v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
         if (p->maxSpeed < FLT_MAX && v2 > p->maxSpeed * p->maxSpeed) {
             float sc_ = p->maxSpeed / sqrtf(v2);
             for (int k = 0; k < 3; ++k) v[k] = v[k] * sc_;
             v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+#ifdef ORC_ALT_MAXACCEL_POSITION
+            for (int k = 0; k < 3; ++k) xe[k] = x0[4 * i + k] + h * v[k];
+#endif
         }
 #if defined(ORC_ALT_NO_SLEEP) || defined(ORC_ALT_SLEEP_AT_PREDICT)
         (void)thr2;
-        for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
+        for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xe[k]; }
 #elif defined(ORC_ALT_SLEEP_VELOCITY_ONLY)
-        for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = (v2 < thr2) ? 0.0f : v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
+        for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = (v2 < thr2) ? 0.0f : v[k]; s->pos[4 * i + k] = xe[k]; }
 #else
         if (v2 < thr2) { /* asleep: "considered fixed" -> keeps its position, zero velocity [I] */
             for (int k = 0; k < 3; ++k) s->vel[3 * i + k] = 0.0f;
         } else {
-            for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xp[4 * i + k]; }
+            for (int k = 0; k < 3; ++k) { s->vel[3 * i + k] = v[k]; s->pos[4 * i + k] = xe[k]; }
         }
 #endif
     }
@@ -1049,6 +1102,8 @@ int orc_set_shape_states(orc_sim *s, const float *in) {
 int orc_max_neighbor_list(const orc_sim *s) { return s->max_list; }
 int orc_get_last_shape_candidates(const orc_sim *s, unsigned *masks) { memcpy(masks, s->smask, sizeof(unsigned) * s->n); return 0; }
 int orc_missed_shape_contacts(const orc_sim *s) { return s->missed_shape_contacts; }
+long orc_accel_clamps(const orc_sim *s) { return s->accel_clamps; }
+long orc_degenerate_normals(const orc_sim *s) { return s->degenerate_normals; }
 
 int orc_get_last_neighbors(const orc_sim *s, int *counts, int *lists) {
     memcpy(counts, s->ncount, sizeof(int) * s->n);

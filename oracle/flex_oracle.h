@@ -77,6 +77,10 @@ int orc_get_last_neighbors(const orc_sim *s, int *out_counts, int *out_lists);
    stage never changed a result) */
 int orc_get_last_shape_candidates(const orc_sim *s, unsigned *out_masks);
 int orc_missed_shape_contacts(const orc_sim *s);
+/* white box (PARITY.md): how often the maxAcceleration clamp of finalize changed a velocity / a contact normal fell back to
+   (0,1,0) for a coincident pair, in particle-substeps / contacts since set_scene */
+long orc_accel_clamps(const orc_sim *s);
+long orc_degenerate_normals(const orc_sim *s);
 
 #ifdef __cplusplus
 }

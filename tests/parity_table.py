@@ -37,6 +37,10 @@ ROWS = [  # (variant, what it changes)
     ("alt_shape_every_iteration", "no collideShapes stage: every plane / sphere tested for every particle in every iteration (rounds 1-4)"),
     ("alt_contact_planes", "a sphere candidate frozen at collideShapes into its tangent plane (the data model of NvFlexGetContacts, NvFlex.h:1074-1080)"),
     ("alt_count_candidates", "Local-relaxation divisor counts every listed contact (particle and shape candidates), violated or not"),
+    ("alt_no_maxaccel", "the maxAcceleration clamp of finalize skipped (how much the rule matters at all; NvFlex.h:112-113)"),
+    ("alt_maxaccel_per_frame", "'at the end of each step' = each NvFlexUpdateSolver call: velocity change since the start of the FRAME clamped to maxAcceleration * dt, once after the last substep (default: per substep)"),
+    ("alt_maxaccel_position", "a clamped particle's position follows its clamped velocity, x = x0 + h v (default: velocity clamped, position kept)"),
+    ("alt_kinematic_velocity_kept", "finalize leaves the velocity of an invMass-0 (picked) particle alone: a released particle resumes with its pre-grasp velocity (default: zeroed)"),
 ]
 
 
@@ -59,7 +63,8 @@ def _run(job):
         sc.scenario_c2_fling(sim, dim=24 if quick else 64, settle_steps=30 if quick else 300, record=rec)
     rec.close()
     states = list(zip(rec.pos, rec.vel, rec.shapes)) if variant is None else None
-    return name, variant, rec.frames, rec.pos, covered_area(sim.get_positions()), sim.max_neighbor_list(), states
+    white = (sim.accel_clamps(), sim.degenerate_normals(), sim.n * sim.get_params()[1] * rec.frames[-1])
+    return name, variant, rec.frames, rec.pos, covered_area(sim.get_positions()), (sim.max_neighbor_list(),) + white, states
 
 
 def _scene(name, quick):
@@ -116,7 +121,8 @@ def table(quick=False, jobs=8, scenarios=("c1", "c2", "fling")):
             for a, b in zip(pos0, pos):
                 a3, b3 = a.reshape(-1, 4)[:, :3], b.reshape(-1, 4)[:, :3]
                 div.append(float(np.abs(a3 - b3).max() / max(1.0, float(np.abs(a3).max()))))
-            out[(s, v)] = {"frames": fr, "divergence": div, "local": loc[(s, v)], "coverage": (cov0, cov), "max_list": (ml0, ml)}
+            out[(s, v)] = {"frames": fr, "divergence": div, "local": loc[(s, v)], "coverage": (cov0, cov), "max_list": (ml0[0], ml[0]),
+                           "white": ml0[1:]}   # default oracle: (clamp events, degenerate normals, particle-substeps)
     return out
 
 
@@ -125,8 +131,10 @@ def render(out, scenarios=("c1", "c2", "fling")):
     lines = []
     for s in scenarios:
         fr = out[(s, ROWS[0][0])]["frames"]
+        ml, (clamps, degen, psub) = out[(s, ROWS[0][0])]["max_list"][0], out[(s, ROWS[0][0])]["white"]
         lines.append(f"\n**{names[s]}** -- frames {', '.join(str(f) for f in fr)} (last = end of the scenario); longest candidate "
-                     f"list of the default oracle: {out[(s, ROWS[0][0])]['max_list'][0]} (cap 96)\n")
+                     f"list of the default oracle: {ml} (cap 96); the maxAcceleration clamp changed a velocity in {clamps} of "
+                     f"{int(psub)} particle-substeps; contact normals that fell back to (0,1,0) for a coincident pair: {degen}\n")
         lines.append("| alternative | " + " | ".join(f"trajectory @{f}" for f in fr) + " | " +
                      " | ".join(f"one step from @{f}" for f in fr) + " | coverage at the end (default -> alternative) |")
         lines.append("|---|" + "---|" * (2 * len(fr) + 1))
@@ -162,7 +170,9 @@ def fit_fixture(path, jobs=8, pairs=False, only=None):
     if pairs:
         excl = {"alt_sleep_velocity_only", "alt_sleep_at_predict", "alt_no_sleep"}
         # (frozen contact planes need the candidate stage and the in-iteration friction: flex_oracle.c refuses those builds)
-        clash = {frozenset(("alt_contact_planes", "alt_shape_every_iteration")), frozenset(("alt_contact_planes", "alt_friction_post"))}
+        clash = {frozenset(("alt_contact_planes", "alt_shape_every_iteration")), frozenset(("alt_contact_planes", "alt_friction_post")),
+                 # (no clamp at all leaves nothing for the clamp's period or its position rule to act on)
+                 frozenset(("alt_no_maxaccel", "alt_maxaccel_per_frame")), frozenset(("alt_no_maxaccel", "alt_maxaccel_position"))}
         variants += ["alt_" + a[4:] + "+" + b[4:] for a, b in itertools.combinations(alts, 2)
                      if not (a in excl and b in excl) and frozenset((a, b)) not in clash]
     for v in variants:   # build the libraries before the pool forks (make is not re-entrant on one target)
@@ -192,7 +202,8 @@ def render_fit(res):
 # raises in 5 cm increments until the lowest particle clears 0.02 m, at most to 0.7 m (simEnv.py:186-200).  A reading of the
 # closed solver under which those loops run into their limits (or never engage) is less plausible than one that keeps them in
 # their working range.  This pins nothing; it RANKS readings with the only FleX-tuned numbers the reference contains.
-PLAUSIBILITY_READINGS = (None, "alt_stiffness_iter", "alt_apply_per_type", "alt_friction_post", "alt_count_candidates")
+PLAUSIBILITY_READINGS = (None, "alt_stiffness_iter", "alt_apply_per_type", "alt_friction_post", "alt_count_candidates",
+                         "alt_no_maxaccel", "alt_maxaccel_per_frame", "alt_maxaccel_position")
 
 
 def _plausibility_one(job):

@@ -326,6 +326,8 @@ class StubSim:
             def set_velocities(self, v): pass
         return View()
     def sync(self): LOG.append(("ctx_sync", None))
+    def device_key(self):   # the device's PCI bus id; FS_SAME_DEVICE: two ranks were (wrongly) started on one GPU
+        return "0000:%02x:00.0" % (5 if os.environ.get("FS_SAME_DEVICE") and RANK < 2 else 5 + RANK)
     def step(self, n=1):
         self.steps += n; LOG.append(("step", n)); time.sleep(0.001 * (1 + 2 * (RANK == 1)))      # rank 1 is the slow one
     def timer_start(self): LOG.append(("timer_start", None)); self._t = time.perf_counter()
@@ -396,6 +398,8 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
     assert len(lines0) == 1 and not [l for o in outs[1:] for l in o.splitlines() if l.startswith("{")]   # rank 0 prints, the others are silent
     rec = json.loads(lines0[0])
     assert rec["n_gpus"] == world and rec["steps"] == 3 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    # ... and what the process group's own all_gather saw (not WORLD_SIZE): as many ranks, on as many distinct devices
+    assert rec["ranks_seen"] == world and rec["distinct_devices"] == world and rec["backend"] == "gloo"
     assert rec["config"]["episodes_per_gpu"] == 4 and rec["config"]["parallelism"] == f"episodes x{world}"
     assert rec["unit"] == "sim steps/s" and rec["higher_is_better"] is True and rec["vs_baseline"] is None
     # whole-job value = all ranks' episode-steps / the SLOWEST rank's time: rank 1 sleeps 3 ms per step, rank 0 1 ms
@@ -438,6 +442,32 @@ def test_bench_run_rank_control_flow_two_ranks(tmp_path, world):
             assert ev[i + 1:i + 101] == ["step"] * 100 and ev[i + 101:i + 107] == ["timer_stop", "gather", "barrier", "ctx_sync",
                                                                                 "cuda_sync", "max"]
         assert ev[-1] == "barrier" or ev[-2:] == ["close", "barrier"] or "barrier" in ev[-3:]
+
+
+def test_bench_refuses_two_ranks_on_one_device(tmp_path):
+    """The day a multi-GPU run happens the first question is "did RCCL really see N ranks on N GPUs?".  bench.run_rank answers
+    from a collective (distributed.rank_census: all_gather of rank / LOCAL_RANK / device identity), and when two ranks report the
+    same physical device every rank ends non-zero and NO JSON line is printed."""
+    script = tmp_path / "bench_worker.py"
+    script.write_text(BENCH_WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FS_ROOT=ROOT, FS_OUT=str(tmp_path), FS_SAME_DEVICE="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode not in (0, None) and "saw 2 rank(s) on 1 distinct device(s)" in err, (p.returncode, err[-2000:])
+        assert not [l for l in out.splitlines() if l.startswith("{")]
+
+
+def test_rank_census_single_process():
+    """World size 1 needs no process group: the census reports itself."""
+    sys.path.insert(0, ROOT)
+    from flingbot_amd import distributed as fdist
+    c = fdist.rank_census("0000:05:00.0", "gfx950")
+    assert c["ranks_seen"] == 1 and c["distinct_devices"] == 1 and c["world_size"] == 1 and c["backend"].startswith("none")
 
 
 # ---- `python -m flingbot_amd.evaluate --tasks set.npz --gpus 8`, end to end, on a machine without a GPU ----------------------

@@ -132,24 +132,33 @@ def test_a_fixture_identifies_the_reading_that_made_it(tmp_path):
     """tests/parity_table.py --fixture: the tool that tells, the day a PyFleX fixture exists, WHICH reading of the closed solver it
     agrees with.  Proved on fixtures whose answer is known: one recorded from the default oracle ranks the default first with
     zero error, one recorded from an oracle with two model choices changed (friction after the solve + applyDeltas per
-    constraint type) ranks exactly that pair first with zero error, above either single change."""
+    constraint type) ranks exactly that pair first with zero error, above either single change, and so does one recorded with
+    two readings of the finalize clamp changed (clamp per frame + position following the clamped velocity)."""
     import parity_table as pt
     from oracle import OracleSim
 
     kit = _kit("capture_pyflex")
-    for maker, expect in ((None, None), ("alt_friction_post+apply_per_type", "alt_friction_post+apply_per_type")):
+    model = ("alt_friction_post", "alt_apply_per_type", "alt_stiffness_iter", "alt_damping_mult", "alt_shape_end_pose",
+             "alt_neighbors_by_distance")
+    # the finalize clamp's readings (NvFlex.h:112-113; PARITY.md): period per frame + position following the clamped velocity
+    clamp = ("alt_maxaccel_per_frame", "alt_maxaccel_position", "alt_no_maxaccel", "alt_friction_post", "alt_damping_mult")
+    for maker, only in ((None, model), ("alt_friction_post+apply_per_type", model), ("alt_maxaccel_per_frame+maxaccel_position", clamp)):
+        expect = maker
         path = str(tmp_path / f"fix_{expect}.npz")
         kit.capture(lambda: OracleSim(maker), path, names=("fling",), every=1, dim=12, quick=True, backend="oracle")
-        ranked = pt.fit_fixture(path, jobs=8, pairs=True, only=("alt_friction_post", "alt_apply_per_type", "alt_stiffness_iter",
-                                                                "alt_damping_mult", "alt_shape_end_pose", "alt_neighbors_by_distance"))
+        ranked = pt.fit_fixture(path, jobs=8, pairs=True, only=only)
         best, per = ranked[0]
         assert best == expect and max(mx for _, mx, _ in per.values()) == 0.0, (best, per)
         worst = {v: max(mx for _, mx, _ in p.values()) for v, p in ranked}
         # every reading that really differs from the maker is off; the list-truncation alternative is a no-op here and ties
-        for v in ("alt_friction_post", "alt_apply_per_type", "alt_stiffness_iter", "alt_damping_mult", "alt_shape_end_pose"):
-            assert worst[v] > 0.0, v
+        for v in only:
+            if v != "alt_neighbors_by_distance":
+                assert worst[v] > 0.0, v
         assert worst[None] == (0.0 if expect is None else worst[None]) and (expect is None or worst[None] > 0.0)
-        assert worst["alt_neighbors_by_distance"] == worst[None]
+        if "alt_neighbors_by_distance" in only:
+            assert worst["alt_neighbors_by_distance"] == worst[None]
+        if only is clamp:   # (the search never builds "no clamp" together with a rule about the clamp)
+            assert not any(v and "no_maxaccel" in v and ("maxaccel_per_frame" in v or "maxaccel_position" in v) for v in worst)
 
 
 @pytest.mark.gpu

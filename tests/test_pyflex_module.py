@@ -33,7 +33,7 @@ def test_module_exports_the_reference_surface():
     assert len(REFERENCE_NAMES) == 40
     for name in REFERENCE_NAMES:
         assert callable(getattr(pyflex, name, None)), f"pyflex.{name} missing"
-    for name in ("picker_reset", "movep", "step_n", "wait_until_stable"):  # additive device-side loops
+    for name in ("picker_reset", "movep", "step_n", "wait_until_stable", "_tenants"):  # additive device-side loops
         assert callable(getattr(pyflex, name, None)), f"pyflex.{name} missing"
     # init takes four REQUIRED positionals like the reference (m.def without py::arg, pyflex.cpp:1138)
     with pytest.raises(TypeError):
@@ -41,6 +41,155 @@ def test_module_exports_the_reference_surface():
     # calls before init raise instead of dereferencing a null solver
     with pytest.raises(RuntimeError):
         pyflex.get_positions()
+
+
+_TENANT_CHILD = r"""
+import ctypes, os, sys, time
+lib = ctypes.CDLL(sys.argv[1])
+lib.fs_tenants_register.argtypes = [ctypes.c_char_p]
+lib.fs_tenants_count.argtypes = [ctypes.c_char_p, ctypes.c_int]
+lib.fs_tenants_unregister.argtypes = [ctypes.c_char_p]
+key = sys.argv[2].encode()
+print(lib.fs_tenants_register(key), flush=True)       # live tenants including this one
+line = sys.stdin.readline()                            # parent: "count" / "leave"
+while line:
+    if line.strip() == "count":
+        print(lib.fs_tenants_count(key, 1), flush=True)
+    elif line.strip() == "leave":
+        lib.fs_tenants_unregister(key)
+        print("left", flush=True)
+        break
+    line = sys.stdin.readline()
+"""
+
+
+def test_tenant_table_counts_live_processes_and_forgets_dead_ones(tmp_path, monkeypatch):
+    """csrc/fs_tenants.cpp: the table through which the processes that share a GPU find each other (the reference's
+    `--num_processes 16`, README.md:147-148).  Real processes: two children register next to the parent (1 -> 2 -> 3), one
+    unregisters (2), the other is KILLED without a goodbye -- the next pruning count forgets it (1).  Different device keys do
+    not see each other; registering twice does not count twice."""
+    import ctypes
+    import signal
+    import subprocess
+
+    from flingbot_amd import build
+
+    lib_path = build.build_lib()
+    monkeypatch.setenv("FLINGSIM_TENANT_DIR", str(tmp_path))
+    lib = ctypes.CDLL(lib_path)
+    lib.fs_tenants_register.argtypes = [ctypes.c_char_p]
+    lib.fs_tenants_count.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.fs_tenants_unregister.argtypes = [ctypes.c_char_p]
+    key, other = b"0000:05:00.0", b"0000:06:00.0"
+    assert lib.fs_tenants_count(key, 1) == 0
+    assert lib.fs_tenants_register(key) == 1 and lib.fs_tenants_register(key) == 1     # idempotent per process
+    assert lib.fs_tenants_count(other, 1) == 0                                          # another device: another table
+    env = dict(os.environ, FLINGSIM_TENANT_DIR=str(tmp_path))
+
+    def child():
+        p = subprocess.Popen([sys.executable, "-c", _TENANT_CHILD, lib_path, key.decode()], stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, text=True, env=env)
+        return p, int(p.stdout.readline())
+
+    a, seen_a = child()
+    assert seen_a == 2 and lib.fs_tenants_count(key, 0) == 2
+    b, seen_b = child()
+    assert seen_b == 3 and lib.fs_tenants_count(key, 1) == 3
+    a.stdin.write("count\n"); a.stdin.flush()
+    assert int(a.stdout.readline()) == 3                                                # every tenant sees the same table
+    a.stdin.write("leave\n"); a.stdin.flush()
+    assert a.stdout.readline().strip() == "left" and a.wait(timeout=10) == 0
+    assert lib.fs_tenants_count(key, 0) == 2
+    b.send_signal(signal.SIGKILL)                                                       # no goodbye
+    b.wait(timeout=10)
+    assert lib.fs_tenants_count(key, 1) == 1                                            # pruned: the pid is gone
+    assert lib.fs_tenants_count(key, 0) == 1
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("flingsim-tenants-"))
+    assert len(files) == 2 and all(os.stat(os.path.join(tmp_path, f)).st_mode & 0o077 == 0 for f in files)   # per user, private
+    assert lib.fs_tenants_unregister(key) == 0 and lib.fs_tenants_count(key, 1) == 0
+
+
+def test_tenant_table_drops_a_reused_pid(tmp_path, monkeypatch):
+    """A slot whose pid is alive but belongs to ANOTHER process now (start time differs from the registrant's) is dead: written
+    by hand into the table file -- this test process's pid with a wrong start time -- and gone after the next pruning count."""
+    import ctypes
+    import struct
+
+    from flingbot_amd import build
+
+    monkeypatch.setenv("FLINGSIM_TENANT_DIR", str(tmp_path))
+    lib = ctypes.CDLL(build.build_lib())
+    lib.fs_tenants_count.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    key = b"reused"
+    assert lib.fs_tenants_count(key, 1) == 0             # creates and maps the table
+    path = [os.path.join(tmp_path, f) for f in os.listdir(tmp_path) if f.endswith("-reused")][0]
+    with open(path, "r+b") as fh:                        # header 16 B, then slots of (int pid, int, uint64 start)
+        fh.seek(16)
+        fh.write(struct.pack("<iiQ", os.getpid(), 0, 12345))
+    assert lib.fs_tenants_count(key, 0) == 1             # alive by pid alone ...
+    assert lib.fs_tenants_count(key, 1) == 0             # ... but not the process that registered
+
+
+_COTENANT_CHILD = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import numpy as np
+import pyflex, scenarios as sc
+pyflex.init(True, False, 720, 720)
+e_f, e_i = np.zeros(0, np.float32), np.zeros(0, np.int32)
+pyflex.set_scene(0, sc.survey_params(16), e_f, e_i, e_i, e_i, e_i, 0)
+print("ready", pyflex._tenants()[0], pyflex._tenants()[1], flush=True)
+sys.stdin.readline()
+for _ in range(70):
+    pyflex.step()
+print("stepped", pyflex._tenants()[0], pyflex._tenants()[1], flush=True)
+print(np.asarray(pyflex.get_positions()).view(np.uint32).sum(dtype=np.uint64), flush=True)
+sys.stdin.readline()
+"""
+
+
+@pytest.mark.gpu
+def test_module_selects_the_cotenant_backend_by_itself(gpu_required, tmp_path):
+    """Two unmodified `pyflex` processes on one GPU, FLINGSIM_SHARED_GPU unset: the first starts as a lone tenant (AUTO), the
+    second sees two and takes the co-tenant back-end at its first set_scene, the first follows within 64 steps -- and both
+    produce the same bits (the back-ends are interchangeable).  FLINGSIM_SHARED_GPU=0 / 1 overrides the detection."""
+    import subprocess
+
+    from flingbot_amd import build
+
+    mod_dir = os.path.dirname(build.build_pyflex())
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def child(**extra):
+        env = {k: v for k, v in os.environ.items() if k != "FLINGSIM_SHARED_GPU"}
+        env.update(FLINGSIM_TENANT_DIR=str(tmp_path), **extra)
+        p = subprocess.Popen([sys.executable, "-c", _COTENANT_CHILD, mod_dir, here], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                             text=True, env=env)
+        return p, p.stdout.readline().split()
+
+    a, ra = child()
+    assert ra == ["ready", "1", "auto"], ra
+    b, rb = child()
+    assert rb == ["ready", "2", "cotenant"], rb
+    c, rc = child(FLINGSIM_SHARED_GPU="0")
+    assert rc == ["ready", "3", "auto"], rc                         # the caller's word wins
+    sums = []
+    for p in (a, b, c):
+        p.stdin.write("go\n"); p.stdin.flush()
+    for p, want in ((a, "cotenant"), (b, "cotenant"), (c, "auto")):
+        assert p.stdout.readline().split() == ["stepped", "3", want]   # a lone starter follows at its 64th step
+        sums.append(int(p.stdout.readline()))
+    assert sums[0] == sums[1] == sums[2]
+    for p in (a, b, c):
+        p.stdin.write("bye\n"); p.stdin.flush()
+        assert p.wait(timeout=30) == 0
+    d, rd = child(FLINGSIM_SHARED_GPU="1")
+    assert rd == ["ready", "1", "cotenant"], rd                     # (and the three above have left the table)
+    d.stdin.write("go\n"); d.stdin.flush()
+    assert d.stdout.readline().split() == ["stepped", "1", "cotenant"]
+    assert int(d.stdout.readline()) == sums[0]
+    d.stdin.write("bye\n"); d.stdin.flush()
+    assert d.wait(timeout=30) == 0
 
 
 @pytest.mark.gpu
