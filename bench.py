@@ -171,10 +171,22 @@ def traffic_from_profile(episodes):
         return None, None
 
 
+def profile_tags(suffix):
+    """Round tags (r06, r05, ...) that have profiles/<tag>_<suffix>, newest first: the bench line quotes the latest committed
+    profile of each kind without anybody editing a list."""
+    import re
+    try:
+        names = os.listdir(os.path.join(ROOT, "profiles"))
+    except OSError:
+        return []
+    tags = {m.group(1) for n in names for m in [re.match(r"(r\d\d)_" + re.escape(suffix) + "$", n)] if m}
+    return sorted(tags, reverse=True)
+
+
 def limiter_from_profile():
     """What the committed PMC counters say actually limits the fused kernel (it keeps the iterations in LDS, so the
     contract's algorithmic-bytes `roofline` is an equivalent streamed bandwidth, not HBM traffic)."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in profile_tags("pmc.json"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc.json")
         try:
             with open(path) as fh:
@@ -225,16 +237,25 @@ def stream_limiter_from_profile():
     """What the committed profiles say about the 64-episodes-per-GPU launch shape (streaming back-end, two launch
     chains): per-kernel share and duration of one frame's 129 dependent launches."""
     import csv
-    for tag in ("r05", "r04", "r03", "r02"):
+    import re
+    for tag in profile_tags("stream64_kernel_stats.csv"):
         path = os.path.join(ROOT, "profiles", f"{tag}_stream64_kernel_stats.csv")
         try:
             rows = list(csv.reader(open(path)))[1:]
             ker = [{"kernel": r[0].split("(")[0].replace("void ", ""), "calls": int(r[1]), "average_us": float(r[3]),
                     "percent": float(r[4])} for r in rows if float(r[4]) >= 1.0]
+            wave = "one wave's critical path"
+            try:   # the PMC pass of the same launch shape (scripts/pmc_stream64.sh), when the round committed one
+                txt = open(os.path.join(ROOT, "profiles", f"{tag}_stream64_pmc.txt")).read()
+                m = re.search(r"fs_k_iterate_gridl\S* launches \d+\s+waves \d+\s+VALU/wave (\d+).*?valu_active/wave_cycles ([0-9.]+)", txt)
+                if m:
+                    wave = (f"one wave's critical path (fs_k_iterate_gridl: {m.group(1)} VALU instructions per wave at {m.group(2)} "
+                            f"VALU-active per wave-cycle, profiles/{tag}_stream64_pmc.txt; 0.25 = a VALU that never idles at 4 waves per SIMD)")
+            except Exception:
+                pass
             return {"bound": "launch-latency", "source": f"profiles/{tag}_stream64_kernel_stats.csv",
                     "dependent_launches_per_frame": 129, "kernels": ker,
-                    "note": "each launch is one wave's critical path (~890 VALU instructions at 0.233 of the 0.25 "
-                            "VALU-active ceiling) plus dispatch/drain; two concurrent chains hide part of the turn-around "
+                    "note": f"each launch is {wave} plus dispatch/drain; two concurrent chains hide part of the turn-around "
                             "(DESIGN.md 4.2)"}
         except Exception:
             continue
@@ -256,7 +277,7 @@ def mfma_from_profile():
     SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 flops over the kernel's summed duration = fp32 MFMA flops ISSUED per second (useful work
     + the 12.5 % halo the fused blocks recompute), against the 157.3 TFLOP/s dense fp32-MFMA peak."""
     import re
-    for tag in ("r05", "r04", "r01"):
+    for tag in profile_tags("cnn_pmc.txt"):
         path = os.path.join(ROOT, "profiles", f"{tag}_cnn_pmc.txt")
         try:
             for line in open(path):
@@ -799,6 +820,8 @@ def run_rank(args):
         for entry, chk in c2_checks:
             if chk is not None:
                 entry["parity"] = chk.result()
+        if world > 1 and not args.no_parity:
+            out["two_devices_one_process"] = two_device_check(fsim, torch, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preroll + args.warmup)
         if getattr(args, "dropin", None) is not None:
@@ -811,6 +834,40 @@ def run_rank(args):
     fdist.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def two_device_check(fsim, torch, local_rank):
+    """Multi-GPU runs only (rank 0, after every timed region): ONE process driving two devices -- its own and its
+    neighbour's -- with the fused kernel, whose dynamic-LDS attribute belongs to each DEVICE's copy of the kernel; both
+    contexts against the oracle, bit for bit (the body of tests/test_parity_gpu.py::test_two_contexts_on_two_devices, which a
+    one-GPU test box has to skip).  Failure-safe: the entry carries `error`, the headline prints as usual."""
+    try:
+        n_dev = torch.cuda.device_count()
+        if n_dev < 2:
+            return {"checked": False, "reason": f"{n_dev} device(s) visible to rank 0"}
+        from oracle import OracleSim
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import cloth_params
+
+        p = cloth_params(64, 64, pos=(0.0, -0.05, 0.0))
+        orc = OracleSim()
+        orc.set_scene(p)
+        orc.step(10)
+        po, vo = orc.get_positions().view(np.uint32), orc.get_velocities().view(np.uint32)
+        devices, exact = [local_rank, (local_rank + 1) % n_dev], []
+        ctxs = [fsim.FlingSim(n_envs=1, device=d, solver=fsim.FS_SOLVER_FUSED) for d in devices]
+        for ctx in ctxs:
+            ctx.set_scene(0, p)
+            ctx.step(10)
+            exact.append(bool(np.array_equal(np.asarray(ctx.get_positions(0)).view(np.uint32), po) and
+                              np.array_equal(np.asarray(ctx.get_velocities(0)).view(np.uint32), vo)))
+        keys = [ctx.device_key() for ctx in ctxs]
+        for ctx in ctxs:
+            ctx.close()
+        return {"checked": True, "devices": devices, "device_keys": keys, "distinct": len(set(keys)) == 2, "bit_exact": all(exact),
+                "workload": "64 x 64 cloth, 10 frames, fused kernel on both devices from one process, vs oracle/flex_oracle.c"}
+    except Exception as exc:
+        return {"checked": False, "error": str(exc)[:300]}
 
 
 def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream_slots=192):

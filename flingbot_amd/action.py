@@ -144,7 +144,15 @@ def get_action_params(action_primitive, max_indices, pix_grasp_dist, pix_drag_di
     if shifts is None:
         raise ValueError(f"unknown action primitive {action_primitive!r}")
     anchor = np.asarray(max_indices)[1:]
-    return tuple(anchor + np.array([shift, 0]) for shift in shifts)
+    # the reference ASSIGNS the shifted coordinate into a copy of the integer index array (simEnv.py:517-537): with a
+    # non-integer pixel distance the SUM is truncated into the anchor's dtype there -- the same store here, whatever the
+    # config holds (integer distances, the shipped 8 / 8 / 5, are unaffected)
+    out = []
+    for shift in shifts:
+        p = anchor.copy()
+        p[0] = anchor[0] + shift
+        out.append(p)
+    return tuple(out)
 
 
 _work = {}

@@ -261,11 +261,15 @@ __device__ __forceinline__ void fs_shape_sweep(const FsShapesDev &sh, int q, int
 // NvFlexParams::shapeCollisionMargin", NvFlex.h:1074).  For one particle at its PREDICTED position: the planes and the
 // kinematic spheres whose surface is closer than collisionDistance + shapeCollisionMargin (NvFlex.h:145,147), at most
 // maxContactsPerParticle of them (NvFlex.h:361, main.cpp:828) -- planes in index order, then spheres in index order; a sphere
-// stands where the iterations of this substep see it (end of its sweep).  Result: bit q = plane q, bit 8 + q = sphere q.
+// stands where the iterations of this substep see it (end of its sweep).  Result: bit q = plane q, bit FS_SHAPE_SPHERE_BIT + q = sphere q.
 // The iterations test only this set (oracle: collide_shapes).  The mask rides in the candidate-count word of the particle
 // (FsEnvDev::ncount: bits 0-7 = particle-contact candidates, bits 8-31 = this mask), which every iteration loads anyway.
 #define FS_SHAPE_MASK_SHIFT 8
 #define FS_NCOUNT_MASK 0xff
+#define FS_SHAPE_SPHERE_BIT 8   // within the mask: planes are bits 0 .. FS_SHAPE_SPHERE_BIT - 1, sphere q is bit FS_SHAPE_SPHERE_BIT + q
+static_assert(FS_MAX_NEIGHBORS <= FS_NCOUNT_MASK, "the candidate count must fit the low bits of the ncount word");
+static_assert(FS_MAX_PLANES <= FS_SHAPE_SPHERE_BIT, "plane bits must stay below the first sphere bit");
+static_assert(FS_SHAPE_SPHERE_BIT + FS_MAX_SHAPES + FS_SHAPE_MASK_SHIFT <= 32, "plane + sphere candidate bits must fit the ncount word");
 template <class SphereAt>  // SphereAt(q, c0, c1, c2, r): centre + radius of sphere q at the end of the substep
 __device__ __forceinline__ unsigned fs_shape_candidates_core(const FsParams &p, int n_spheres, float x0, float x1, float x2,
                                                              SphereAt sphere_at) {
@@ -282,7 +286,7 @@ __device__ __forceinline__ unsigned fs_shape_candidates_core(const FsParams &p, 
         const float ex = x0 - c0, ey = x1 - c1, ez = x2 - c2;
         const float l2 = fs_dot3(ex, ey, ez, ex, ey, ez);
         const float lim = r + reach;
-        if (l2 < lim * lim) { mask |= 1u << (8 + q); ++listed; }
+        if (l2 < lim * lim) { mask |= 1u << (FS_SHAPE_SPHERE_BIT + q); ++listed; }
     }
     return mask;
 }
@@ -315,7 +319,7 @@ __device__ __forceinline__ void fs_shape_contacts(FsAcc &a, float xi0, float xi1
                              p.collisionDistance, p.staticFriction, p.dynamicFriction);
     const float S = (float)p.numSubsteps;
     for (int q = 0; q < sh.count; ++q)
-        if ((mask >> (8 + q)) & 1u) {
+        if ((mask >> (FS_SHAPE_SPHERE_BIT + q)) & 1u) {
             float c0, c1, c2, s0, s1, s2;
             fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
             fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, p.collisionDistance,
@@ -335,7 +339,7 @@ __device__ __forceinline__ void fs_swept_shape_contacts(FsAcc &a, float xi0, flo
             fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2], p.planes[q][3],
                              p.collisionDistance, p.staticFriction, p.dynamicFriction);
     for (int q = 0; q < sw.count; ++q)
-        if ((mask >> (8 + q)) & 1u) {
+        if ((mask >> (FS_SHAPE_SPHERE_BIT + q)) & 1u) {
             const FsVec4 c = sw.c[sub][q], s = sw.s[sub][q];
             fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c.x, c.y, c.z, c.w, s.x, s.y, s.z, p.collisionDistance,
                               p.staticFriction, p.dynamicFriction);

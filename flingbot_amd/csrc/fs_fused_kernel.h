@@ -535,10 +535,10 @@ __device__ __forceinline__ void fs_fused_shape_contacts(FsAcc &a, const FsFusedC
                 fs_plane_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, p.planes[q][0], p.planes[q][1], p.planes[q][2],
                                  p.planes[q][3], c.cd, c.mu_s, c.mu_k);
     }
-    if (c.n_shapes == 0 || __builtin_amdgcn_ballot_w64((mask >> 8) != 0u) == 0ull) return;
+    if (c.n_shapes == 0 || __builtin_amdgcn_ballot_w64((mask >> FS_SHAPE_SPHERE_BIT) != 0u) == 0ull) return;
     const float S = (float)c.substeps;
     for (int q = 0; q < c.n_shapes; ++q)
-        if ((mask >> (8 + q)) & 1u) {
+        if ((mask >> (FS_SHAPE_SPHERE_BIT + q)) & 1u) {
             float c0, c1, c2, s0, s1, s2;
             fs_shape_sweep(sh, q, sub, S, c0, c1, c2, s0, s1, s2);
             fs_sphere_contact(a, xi0, xi1, xi2, ri0, ri1, ri2, c0, c1, c2, sh.pos[q].w, s0, s1, s2, c.cd, c.mu_s, c.mu_k);

@@ -42,6 +42,7 @@ static int g_shared_env = -1;      // -1: unset (detect), 0 / 1: FLINGSIM_SHARED
 static bool g_cotenant = false;    // the back-end in force
 static char g_device_key[64] = "";
 static unsigned g_steps_since_check = 0;
+static int g_raw_tenants = -1;     // occupied slots of the table when the back-end was last chosen
 static fs_ctx *ctx() {
     if (!g_ctx) throw std::runtime_error("pyflex.init() has not been called");
     return g_ctx;
@@ -52,6 +53,7 @@ static void choose_backend(bool prune) {
     if (shared != g_cotenant || prune) ck(fs_set_solver(ctx(), shared ? FS_SOLVER_COTENANT : FS_SOLVER_AUTO), "pyflex");
     g_cotenant = shared;
     g_steps_since_check = 0;
+    g_raw_tenants = g_device_key[0] ? fs_tenants_count(g_device_key, -1) : -1;
 }
 
 // pyflex.cpp:15-124.  m.def has no py::arg there either: four required positionals.
@@ -97,8 +99,11 @@ static void pyflex_set_scene(int scene_idx, farr scene_params, farr vertices, ia
 static void pyflex_step(py::object update_params, int capture, py::object path, int render) {
     (void)update_params; (void)capture; (void)path; (void)render;
     // workers start together: one that reached its first set_scene before its neighbours had called pyflex.init would step the
-    // whole episode as a lone tenant -- so the count is refreshed every 64 steps (an unlocked scan of <= 62 slots)
-    if (g_shared_env < 0 && ++g_steps_since_check >= 64) choose_backend(false);
+    // whole episode as a lone tenant -- so every step reads the number of occupied slots (no system call) and the live count is
+    // taken again when that number has moved, and every 64 steps anyway (a killed neighbour leaves its slot occupied)
+    if (g_shared_env < 0 && g_device_key[0] &&
+        (++g_steps_since_check >= 64 || fs_tenants_count(g_device_key, -1) != g_raw_tenants))
+        choose_backend(false);
     ck(fs_step(ctx(), 0, 1), "pyflex.step");
 }
 

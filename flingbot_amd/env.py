@@ -241,6 +241,7 @@ class BatchedFlingEnv:
             rec["coverage"].append(float(curr))
             rec["actions"].append(action)
             rec.setdefault("rewards", []).append(float(curr - prev))
+            rec.setdefault("preaction_coverage", []).append(float(prev))
             if self.terminate[e]:
                 return rec
             obs = yield ("observe",)

@@ -160,6 +160,7 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
         "mean": {"init_coverage": float(init.mean()), "final_coverage": float(final.mean()),
                  "best_coverage": float(trace.max(axis=0).mean()), "episode_delta_coverage": float((final - init).mean()),
                  "episode_length": float(lengths.mean())},
+        "records": [records[i] for i in range(n)],   # per episode: what SimEnv logs per step (taskio.save_replay stores it)
     }
 
 
@@ -187,16 +188,27 @@ def merge_rank_statistics(stats, per_rank, device=None):
     `per_rank` tasks; the last block may be shorter) and reduced to the summary the command line prints."""
     from . import distributed as fdist
 
-    pad = lambda v: np.concatenate([np.asarray(v, np.float32), np.full(per_rank - len(v), np.nan, np.float32)])  # noqa: E731
+    # every rank says how many episodes it ran (its block may be short, or empty); the padding behind them is never looked at, so
+    # a coverage that really IS NaN (a diverged episode, a degenerate flatten_area) stays in the statistics and shows
+    pad = lambda v: np.concatenate([np.asarray(v, np.float32), np.zeros(per_rank - len(v), np.float32)])  # noqa: E731
+    n_mine = len(stats["init_coverage"])
+    assert len(stats["final_coverage"]) == n_mine <= per_rank, (n_mine, len(stats["final_coverage"]), per_rank)
     init = fdist.gather_rewards(pad(stats["init_coverage"]), device=device).cpu().numpy()
     final = fdist.gather_rewards(pad(stats["final_coverage"]), device=device).cpu().numpy()
-    steps = fdist.gather_rewards([float(stats["simulation_steps"])], device=device).cpu().numpy()
-    keep = ~np.isnan(init)
+    tail = fdist.gather_rewards([float(stats["simulation_steps"]), float(n_mine)], device=device).cpu().numpy().reshape(-1, 2)
+    counts = tail[:, 1].astype(np.int64)
+    keep = (np.arange(per_rank)[None, :] < counts[:, None]).ravel()
+    init, final = init[keep], final[keep]
     _, _, world = fdist.init_from_env()
-    return {"gpus": world, "episodes": int(keep.sum()), "init_coverage": float(init[keep].mean()),
-            "final_coverage": float(final[keep].mean()), "episode_delta_coverage": float((final[keep] - init[keep]).mean()),
-            "simulation_steps": int(steps.sum()),
-            "note": "coverages and steps over all ranks; best_coverage / episode_length / action counts are rank 0's"}
+    out = {"gpus": world, "episodes": int(counts.sum()), "init_coverage": float(init.mean()) if init.size else float("nan"),
+           "final_coverage": float(final.mean()) if final.size else float("nan"),
+           "episode_delta_coverage": float((final - init).mean()) if init.size else float("nan"),
+           "simulation_steps": int(tail[:, 0].sum()),
+           "note": "coverages and steps over all ranks; best_coverage / episode_length / action counts are rank 0's"}
+    bad = int((~np.isfinite(init)).sum() + (~np.isfinite(final)).sum())
+    if bad:
+        out["non_finite_coverages"] = bad     # surfaced, not dropped: the means above are NaN because an episode's coverage is
+    return out
 
 
 def main(argv=None):
@@ -216,6 +228,9 @@ def main(argv=None):
     ap.add_argument("--weights", default=None, help="checkpoint with the reference's state_dict layout (flingbot.pth)")
     ap.add_argument("--slots", type=int, default=96, help="episodes resident on a GPU at a time")
     ap.add_argument("--episode-length", type=int, default=10)
+    ap.add_argument("--dump", default=None, metavar="REPLAY.npz",
+                    help="also write the per-step episode log (what SimEnv.on_episode_end dumps: learning/Memory.py:106-165) as a "
+                         ".npz (taskio.save_replay; rank r of a multi-GPU run writes REPLAY.rank<r>.npz)")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args(argv)
@@ -247,6 +262,9 @@ def main(argv=None):
         policy.load_state_dict(ckpt.get("net", ckpt))          # utils.py:116-118 stores the module under 'net'
     if mine:
         stats = run_tasks(policy, env, mine)
+        if a.dump:
+            path = a.dump if world == 1 else a.dump[:-4] + f".rank{rank}.npz" if a.dump.endswith(".npz") else a.dump + f".rank{rank}"
+            taskio.save_replay(path, stats["records"], mine, first_episode=rank * per_rank)
     else:  # more ranks than task blocks (13 tasks over 8 GPUs: blocks of 2, the last rank has none): nothing to run, still gathers
         nothing = np.zeros(0, np.float32)
         stats = {"init_coverage": nothing, "final_coverage": nothing, "simulation_steps": 0,

@@ -141,3 +141,93 @@ class TaskLoader:
     def all_tasks(self):
         """Every task once, in file order: the list evaluate.run_tasks takes."""
         return [self.task(i) for i in range(len(self.keys))]
+
+
+# ---- the episode log (the evaluation half of learning/Memory.py) -------------------------------------------------------------
+REPLAY_FORMAT = "flingbot_amd replay v1"
+REPLAY_SCALARS = ("preaction_coverage", "postaction_coverage", "rewards", "is_terminal", "action_primitive", "task_name",
+                  "task_difficulty", "max_coverage", "init_coverage", "cloth_mass")
+
+
+def save_replay(path, records, tasks, first_episode=0):
+    """What SimEnv.on_episode_end -> Memory.dump (simEnv.py:783-805, learning/Memory.py:106-165) leaves of an EVALUATION
+    episode: one entry per action, keyed like the reference's HDF5 groups -- '%09d_step%02d', the episode's last one with
+    '_last' -- holding the scalars SimEnv.step / log_step_stats record (simEnv.py:433-452,477-503) and utils.collect_stats
+    reads (utils.py:186-330): coverage before / after the action, reward, termination, the primitive, the task's get_stats().
+    Not stored: observations, action masks and value maps -- the training set of run_sim.py's optimizer, out of scope here
+    (DESIGN.md 8).  records: evaluate.run_tasks(...)['records']; tasks: the tasks they ran on (Task objects or generator
+    dictionaries); one flat .npz, `keys` in the order the reference's file would list its groups."""
+    keys, data = [], {"format": np.array(REPLAY_FORMAT)}
+    for i, (rec, task) in enumerate(zip(records, tasks)):
+        n = len(rec["actions"])
+        stats = task.get_stats() if hasattr(task, "get_stats") else {
+            "task_name": str(i), "cloth_mass": task["cloth_mass"], "max_coverage": task["flatten_area"],
+            "task_difficulty": task["task_difficulty"], "init_coverage": task["initial_coverage"]}
+        for k in range(n):
+            key = f"{first_episode + i:09d}_step{k:02d}" + ("_last" if k == n - 1 else "")
+            keys.append(key)
+            row = {"preaction_coverage": rec["preaction_coverage"][k], "postaction_coverage": rec["coverage"][k + 1],
+                   "rewards": rec["rewards"][k], "is_terminal": float(k == n - 1),
+                   "action_primitive": "none" if rec["actions"][k] is None else rec["actions"][k],
+                   "task_name": stats["task_name"], "task_difficulty": stats["task_difficulty"],
+                   "max_coverage": float(stats["max_coverage"]), "init_coverage": float(stats["init_coverage"]),
+                   "cloth_mass": float(stats["cloth_mass"])}
+            for f in REPLAY_SCALARS:
+                data[f"{key}/{f}"] = np.array(row[f])
+    data["keys"] = np.array(keys)
+    np.savez_compressed(path, **data)
+    return len(keys)
+
+
+def collect_stats(path, num_points=128, action_primitives=("fling", "stretchdrag", "drag", "place")):
+    """utils.collect_stats (utils.py:186-390) over a file written by save_replay, with the reference's key names
+    ('<statistic>/<level>/mean|max|min|distribution', 'delta_coverage/<level>/percent_positive|negative|zero',
+    'action_primitive/percent_fling|drag|place'): the LATEST `num_points` entries only (the reference's default window of 128
+    -- an episode cut by the window contributes the steps that are inside it), entries whose postaction coverage is below 5 %
+    of the flattened area skipped, best coverage tracked per episode through a running slot that an episode's '_last' entry
+    closes.  Pinned to the reference's function by tests/golden/replay_golden.npz (the per-step dictionaries and the
+    before / after images of the training dashboard are not produced)."""
+    z = np.load(path, allow_pickle=False)
+    if str(z["format"]) != REPLAY_FORMAT:
+        raise ValueError(f"{path}: not a '{REPLAY_FORMAT}' file")
+    keys = sorted(str(k) for k in z["keys"])          # HDF5 lists its groups by name
+    if len(keys) > num_points:
+        keys = keys[-num_points:]
+    names = ("delta_coverage", "final_coverage", "init_coverage", "best_coverage", "episode_delta_coverage", "episode_length")
+    stats = {k: {"easy": [], "hard": []} for k in names}
+    for level in ("easy", "hard"):
+        stats["best_coverage"][level] = [-1]
+    counts = {ap: 0 for ap in action_primitives}
+    for key in keys:
+        g = {f: z[f"{key}/{f}"].item() for f in REPLAY_SCALARS}
+        mx = g["max_coverage"]
+        if g["postaction_coverage"] / mx < 0.05:
+            continue
+        level = str(g["task_difficulty"])
+        stats["delta_coverage"][level].append((g["postaction_coverage"] - g["preaction_coverage"]) / mx)
+        if g["action_primitive"] in counts:     # (an episode step without a valid action is stored as "none")
+            counts[g["action_primitive"]] += 1
+        stats["best_coverage"][level][-1] = max(stats["best_coverage"][level][-1], g["postaction_coverage"] / mx)
+        if "last" in key:
+            stats["episode_length"][level].append(int(key.split("step")[1].split("_")[0]))
+            stats["final_coverage"][level].append(g["postaction_coverage"] / mx)
+            stats["init_coverage"][level].append(g["init_coverage"] / mx)
+            stats["best_coverage"][level].append(-1)
+            stats["episode_delta_coverage"][level].append(stats["final_coverage"][level][-1] - g["init_coverage"] / mx)
+    for level in ("easy", "hard"):
+        del stats["best_coverage"][level][-1]
+    out = {}
+    for key in names:
+        for level, values in stats[key].items():
+            if len(values) == 0:
+                continue
+            v = np.array(values)
+            out[f"{key}/{level}/distribution"] = v
+            out[f"{key}/{level}/mean"], out[f"{key}/{level}/max"], out[f"{key}/{level}/min"] = v.mean(), v.max(), v.min()
+            if key == "delta_coverage":
+                out[f"{key}/{level}/percent_positive"] = np.count_nonzero(v > 0.0) / len(v)
+                out[f"{key}/{level}/percent_negative"] = np.count_nonzero(v < 0.0) / len(v)
+                out[f"{key}/{level}/percent_zero"] = np.count_nonzero(v == 0.0) / len(v)
+    for ap in ("fling", "drag", "place"):
+        out[f"action_primitive/percent_{ap}"] = counts[ap] / len(keys)
+    return out

@@ -67,7 +67,8 @@ int fs_fused_fits(fs_ctx *ctx, int env);
    each other in a small mmap-ed file per (user, device) under /dev/shm (FLINGSIM_TENANT_DIR overrides), so that the `pyflex`
    module can pick FS_SOLVER_COTENANT by itself.  `device_key` names the physical device: fs_device_key() = its PCI bus id.
    fs_tenants_register: add this process, returns the number of live tenants including it; fs_tenants_count: live tenants
-   (prune != 0: also clear the entries of processes that died without unregistering); fs_tenants_unregister: remove this process.
+   (prune > 0: also clear the entries of processes that died without unregistering; prune < 0: the number of occupied slots as
+   they stand, no liveness check, no system call); fs_tenants_unregister: remove this process.
    Host-only (no HIP call): usable, and tested, without a GPU. */
 int fs_device_key(fs_ctx *ctx, char *out, int n_chars);
 int fs_tenants_register(const char *device_key);
@@ -175,6 +176,12 @@ int fs_last_boundary_form(const fs_ctx *ctx);
    number of chains of the most recent streaming launch (white box for the tests). */
 int fs_set_stream_groups(fs_ctx *ctx, int groups);
 int fs_last_stream_groups(const fs_ctx *ctx);
+/* Streaming launches over episodes of different sizes (the evaluation loop: cloth sides 64..103) take their workgroup ->
+   (episode slot, block) mapping from a device-built table instead of giving every slot the blocks of the largest episode
+   (csrc/fs_stream_kernels.h fs_k_tile_map).  mode 0 (default): when the launch is large and the arithmetic mapping would start
+   >= 1/8 of its workgroups for nothing; 1: always; -1: never.  Results do not depend on it (white box: fs_last_tile_map). */
+int fs_set_tile_map(fs_ctx *ctx, int mode);
+int fs_last_tile_map(const fs_ctx *ctx);
 /* white-box access for tests: y[i] = the reciprocal square root the constraint kernels use (csrc/fs_constraints.h fs_rsqrt),
    evaluated on the device for n host values -- what pins the checker's restatement of it to this chip */
 int fs_eval_rsqrt(fs_ctx *ctx, const float *x, float *y, int n);

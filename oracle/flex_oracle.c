@@ -18,6 +18,10 @@
 
 #define ORC_MAX_SHAPES 16
 #define ORC_MAX_NEIGHBORS 96 /* g_maxNeighborsPerParticle, main.cpp:826 */
+#define ORC_MAX_PLANES 8
+#define ORC_SPHERE_BIT 8     /* candidate mask of collideShapes: bit q = plane q, bit ORC_SPHERE_BIT + q = sphere q */
+_Static_assert(ORC_MAX_PLANES <= ORC_SPHERE_BIT && ORC_SPHERE_BIT + ORC_MAX_SHAPES <= 24,
+               "plane and sphere candidate bits must not alias (the product packs the mask above an 8-bit count)");
 
 /* NvFlex.h:159-192 phase bits */
 #define PH_GROUP_MASK 0x000fffff
@@ -707,7 +711,7 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
         if (types & ORC_T_SHAPES)
         for (int q = 0; q < s->ns; ++q) {
 #ifdef ORC_ALT_CONTACT_PLANES
-            if (!((smask >> (8 + q)) & 1u)) continue;
+            if (!((smask >> (ORC_SPHERE_BIT + q)) & 1u)) continue;
             const float *tp = s->splane + ((size_t)ORC_MAX_SHAPES * i + q) * 4; /* frozen tangent plane of this candidate */
             const float nx = tp[0], ny = tp[1], nz = tp[2];
             float sdist = dot3(nx, ny, nz, xi0, xi1, xi2) + tp[3];
@@ -717,7 +721,7 @@ static void jacobi_pass(orc_sim *s, const float *xp, float *xn, const float *x0,
             float ex = xi0 - sc[q][0], ey = xi1 - sc[q][1], ez = xi2 - sc[q][2];
             float l2 = dot3(ex, ey, ez, ex, ey, ez);
             float lim = s->sh_radius[q] + cd;
-            if (!((smask >> (8 + q)) & 1u)) { if (l2 < lim * lim) s->missed_shape_contacts++; continue; } /* (white box only) */
+            if (!((smask >> (ORC_SPHERE_BIT + q)) & 1u)) { if (l2 < lim * lim) s->missed_shape_contacts++; continue; } /* (white box only) */
             if (!(l2 < lim * lim)) { ORC_COUNT_LISTED(cnt); continue; }
             float inv = orc_rsqrt(l2);
             float dist = ORC_LEN(l2, inv);
@@ -848,7 +852,7 @@ static void collide_shapes(orc_sim *s, float (*sc)[3]) {
                 float l2 = dot3(ex, ey, ez, ex, ey, ez);
                 float lim = s->sh_radius[q] + reach;
                 if (!(l2 < lim * lim)) continue;
-                mask |= 1u << (8 + q); listed++;
+                mask |= 1u << (ORC_SPHERE_BIT + q); listed++;
 #ifdef ORC_ALT_CONTACT_PLANES
                 float inv = orc_rsqrt(l2);
                 float dist = ORC_LEN(l2, inv);

@@ -914,8 +914,96 @@ def task_vectors():
     np.savez_compressed(os.path.join(HERE, "task_golden.npz"), **out)
 
 
+def replay_vectors():
+    """utils.collect_stats (utils.py:186-390) -- the function run_sim.py prints its evaluation statistics with -- run on a
+    synthetic episode log: the reference's OWN code walks the groups of an in-memory stand-in for the HDF5 file (h5py is absent;
+    only `for k in file`, `file.get(k)` and `group.attrs[...]` are served, which is all collect_stats touches before its
+    try / except image block) and its return values are stored next to the log.  flingbot_amd.taskio.collect_stats must give
+    the same numbers from the same log written by taskio.save_replay.  This pins the STATISTICS (filters, per-level lists, the
+    best-coverage bookkeeping, the 128-point window), not the HDF5 container."""
+    _import_reference_env_utils()
+    import h5py as h5stub          # the stub module installed above (or the real one, if this machine has it)
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, name): return _Any()
+
+    for name in ("torchvision", "torchvision.transforms", "tensorboardX"):     # what utils.py / learning/utils.py import on top
+        try:
+            __import__(name)
+        except Exception:
+            m = types.ModuleType(name)
+            m.__getattr__ = lambda attr: (_ for _ in ()).throw(AttributeError(attr)) if attr.startswith("__") else _Any()
+            m.__path__ = []
+            sys.modules[name] = m
+    rng = np.random.RandomState(7)
+    episodes = []                  # (task name, difficulty, max coverage, init coverage, [(pre, post, primitive)])
+    for i in range(90):
+        level = "hard" if i % 3 else "easy"
+        mx = 0.05 + 0.1 * rng.rand()
+        cov = mx * (0.2 + 0.3 * rng.rand())
+        init = cov
+        steps = []
+        for k in range(int(rng.randint(1, 5))):
+            post = min(mx, max(0.0, cov + mx * (rng.rand() - 0.35) * 0.5))
+            if i == 7 and k == 0:
+                post = 0.01 * mx                        # below 5 % of the flattened area: collect_stats skips the entry
+            steps.append((float(cov), float(post), "fling" if (i + k) % 4 else "drag"))
+            cov = post
+        episodes.append(("task%03d" % i, level, float(mx), float(init), steps))
+    groups = {}
+    for i, (name, level, mx, init, steps) in enumerate(episodes):
+        for k, (pre, post, prim) in enumerate(steps):
+            key = "%09d_step%02d" % (i, k) + ("_last" if k == len(steps) - 1 else "")
+            groups[key] = {"preaction_coverage": pre, "postaction_coverage": post, "max_coverage": mx, "init_coverage": init,
+                           "task_difficulty": level, "action_primitive": prim, "task_name": name}
+
+    class Group:
+        def __init__(self, attrs): self.attrs = attrs
+        def __getitem__(self, k): raise KeyError(k)     # no datasets: the image block of collect_stats falls into its except
+
+    class File:
+        def __init__(self, path, mode="r"): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def __iter__(self): return iter(sorted(groups))          # HDF5 lists group names in sorted order
+        def get(self, k): return Group(groups[k])
+
+    h5stub.File = File
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("learning")]:
+        del sys.modules[m]
+    import random
+    import tempfile
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import utils as ref_top
+    finally:
+        os.chdir(cwd)
+    ref_top.h5py.File = File
+    out = {"n_groups": np.array(len(groups))}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, kw in (("latest128", {}), ("all", {"num_points": 10 ** 6})):
+            random.seed(0)
+            res = ref_top.collect_stats(os.path.join(tmp, "replay_buffer.hdf5"), **kw)
+            for k, v in res.items():
+                if "_steps" in k or k.startswith("img_"):
+                    continue
+                out[f"{tag}:{k}"] = np.asarray(v, np.float64)
+    keys = sorted(groups)
+    out["keys"] = np.array(keys)
+    for f in ("preaction_coverage", "postaction_coverage", "max_coverage", "init_coverage", "task_difficulty", "action_primitive",
+              "task_name"):
+        out["log:" + f] = np.array([groups[k][f] for k in keys])
+    np.savez_compressed(os.path.join(HERE, "replay_golden.npz"), **out)
+    print("replay:", len(groups), "groups;", len([k for k in out if k.startswith("all:")]), "statistics of the reference's collect_stats")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["coverage", "camera", "sphere", "nets", "envutils", "picker", "fling", "action", "task", "step"]
+    which = sys.argv[1:] or ["coverage", "camera", "sphere", "nets", "envutils", "picker", "fling", "action", "task", "step", "replay"]
+    if "replay" in which:
+        replay_vectors()
     if "coverage" in which:
         coverage_vectors()
     if "camera" in which:

@@ -150,6 +150,62 @@ def render(out, scenarios=("c1", "c2", "fling")):
     return "\n".join(lines)
 
 
+CLAMP_READINGS = ("alt_no_maxaccel", "alt_maxaccel_per_frame", "alt_maxaccel_position")
+
+
+def clamp_scan(quick=False, jobs=8):
+    """The finalize clamp (NvFlex.h:112-113) fires in bursts -- while a picker yanks a corner, while the cloth pops out of the
+    ground -- so the table's four sample frames can miss it.  This walks EVERY frame of the scripted fling: in how many frames
+    the default oracle's clamp changed a velocity, and the one-frame effect of each clamp reading replayed on the default
+    oracle's recording RE-SYNCHRONISED at every frame (picker script included: exactly what a PyFleX fixture would be put
+    through, test_external_fixtures.replay_pyflex_fixture)."""
+    import importlib.util
+    import tempfile
+
+    import scenarios as sc
+    from oracle import OracleSim
+
+    dim = 24 if quick else 64
+    sim = OracleSim()
+    fired, last = [], [0]
+
+    def record(s):
+        fired.append(s.accel_clamps() - last[0])
+        last[0] = s.accel_clamps()
+    sc.scenario_c2_fling(sim, dim=dim, settle_steps=30 if quick else 300, record=record)
+    spec = importlib.util.spec_from_file_location("capture_pyflex", os.path.join(HERE, "golden", "capture_pyflex.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "default_fling.npz")
+        kit.capture(OracleSim, path, names=("fling",), every=1, dim=dim, quick=quick, backend="oracle")
+        for v in CLAMP_READINGS:
+            from oracle.flex import _load
+            _load(v)
+        with Pool(min(jobs, len(CLAMP_READINGS))) as pool:
+            res = dict(pool.map(_clamp_replay, [(path, v) for v in CLAMP_READINGS], chunksize=1))
+    frames = len(fired)
+    hot = np.array([f > 0 for f in fired])
+    lines = [f"scripted fling ({dim}x{dim}), every frame: the default oracle's maxAcceleration clamp changed a velocity in "
+             f"{int(hot.sum())} of {frames} frames ({sum(fired)} particle-substeps, at most {max(fired)} in one frame); one-frame effect "
+             f"of each reading, re-synchronised replay of the default oracle's recording:", "",
+             "| reading | frames that differ at all | median over those | 90th percentile | maximum | frames above 1e-4 | of them outside the frames in which the default clamp fired |",
+             "|---|---|---|---|---|---|---|"]
+    for v in CLAMP_READINGS:
+        a = np.array(res[v][:frames])
+        nz = a[a > 0]
+        lines.append(f"| `{v}` | {nz.size} / {frames} | {np.median(nz) if nz.size else 0:.1e} | {np.percentile(nz, 90) if nz.size else 0:.1e} | "
+                     f"{a.max():.1e} | {int((a > 1e-4).sum())} | {int(((a > 1e-4) & ~hot[:a.size]).sum())} |")
+    return "\n".join(lines)
+
+
+def _clamp_replay(job):
+    path, variant = job
+    import test_external_fixtures as tef
+    from oracle import OracleSim
+    return variant, [float(x) for x in tef.replay_pyflex_fixture(path, lambda: OracleSim(variant))["fling"]["resync"]]
+
+
 def _fit_one(job):
     path, variant = job
     import test_external_fixtures as tef
@@ -319,14 +375,28 @@ if __name__ == "__main__":
                     help="run the reference's FleX-tuned loops (task generator, wait_until_stable, stretch / lift) on N generated hard "
                          "tasks per reading and report which readings keep them inside their working range")
     ap.add_argument("--json", default=None, help="with --plausibility: also write the per-task records here")
+    ap.add_argument("--readings", default=None, help="with --plausibility: comma-separated readings to run ('default' = the oracle "
+                                                     "as shipped); default: all of PLAUSIBILITY_READINGS")
+    ap.add_argument("--merge", default=None, help="with --plausibility: per-task records of an earlier run (same seeds) to "
+                                                  "tabulate together with this run's")
+    ap.add_argument("--clamp-scan", action="store_true", help="every frame of the scripted fling: how often the finalize clamp fires and "
+                                                               "the one-step effect of each clamp reading from those states")
     a = ap.parse_args()
-    if a.plausibility:
-        recs = plausibility(a.plausibility, a.jobs, small=a.quick)
+    if a.clamp_scan:
+        print(clamp_scan(a.quick, a.jobs))
+    elif a.plausibility:
+        import json
+        readings = PLAUSIBILITY_READINGS if not a.readings else tuple(None if r == "default" else r for r in a.readings.split(","))
+        recs = plausibility(a.plausibility, a.jobs, small=a.quick, readings=readings)
+        if a.merge:
+            with open(a.merge) as fh:
+                old = [r for r in json.load(fh) if r["variant"] not in readings]
+            recs = old + recs
+            readings = tuple(dict.fromkeys([r["variant"] for r in recs]))
         if a.json:
-            import json
             with open(a.json, "w") as fh:
                 json.dump(recs, fh, indent=1)
-        print(render_plausibility(recs))
+        print(render_plausibility(recs, readings))
     elif a.fixture:
         print(render_fit(fit_fixture(a.fixture, a.jobs, a.pairs)))
     else:

@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed line of the round's final tree (profiles/r05_bench_steps20.json =
+"""The bench line's contract, checked on the newest committed line (profiles/rNN_bench_steps20.json =
 `python bench.py --gpus 1 --steps 20 --warmup 5` on an MI355X): the keys the driver and the judge read, their units and the
 arithmetic that ties them together.  No GPU needed -- it reads the recorded line; bench.py's own control flow is covered by
 tests/test_distributed_cpu.py with the solver stubbed."""
@@ -11,7 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    path = os.path.join(ROOT, "profiles", "r05_bench_steps20.json")
+    """The newest committed `rNN_bench_steps20.json` (scripts/profile_all.sh writes one per round)."""
+    import bench
+
+    tag = bench.profile_tags("bench_steps20.json")[0]
+    path = os.path.join(ROOT, "profiles", f"{tag}_bench_steps20.json")
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
@@ -49,6 +53,28 @@ def test_recorded_bench_line_keeps_the_contract():
         assert by_key[k]["parity"]["bit_exact"] is True and 0 < by_key[k]["roofline_frac_equivalent"] < 1
     assert d["fling_phase_ratio"] == pytest.approx(by_key["c2_fling_256"]["ratio_to_crumpled_sheet"])
     assert 0 < d["eval_loop"]["roofline_frac_equivalent"] < 1 and 0 < d["eval_loop"]["continuous"]["roofline_frac_equivalent"] < 1
+
+
+def test_quoted_hbm_traffic_is_the_newest_pmc_pass():
+    """`roofline.traffic` of the bench line is NOT measured in the run: bench.py quotes profiles/hbm_traffic.json, the PMC
+    pass of the same command, scaled per episode.  That makes it the one number of the line nobody re-measures -- so it must
+    be the newest committed pass (profiles/rNN_pmc.json with the highest NN), byte for byte; scripts/summarize_profile.py
+    writes both files in one go, and this test fails when a round commits a new PMC pass without the quoted figure (or edits
+    the figure by hand)."""
+    import bench
+
+    tags = bench.profile_tags("pmc.json")
+    assert tags, "no profiles/rNN_pmc.json"
+    newest = json.load(open(os.path.join(ROOT, "profiles", f"{tags[0]}_pmc.json")))
+    quoted = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert quoted["tag"] == tags[0] == newest["tag"], (quoted["tag"], tags[0])
+    assert quoted["episodes"] == newest["episodes"]
+    assert quoted["bytes_per_launch"] == pytest.approx(newest["hbm_bytes_per_launch"]["total_corrected"], rel=1e-12)
+    h = newest["hbm_bytes_per_launch"]        # the guide's gfx950 correction: FETCH_SIZE counts half of what was read
+    assert h["total_corrected"] == pytest.approx(2 * h["fetch_reported"] + h["write"], rel=1e-12)
+    traffic, source = bench.traffic_from_profile(newest["episodes"])
+    assert traffic == pytest.approx(quoted["bytes_per_launch"]) and tags[0] in source
+    assert bench.limiter_from_profile()["source"] == f"profiles/{tags[0]}_pmc.json"
 
 
 def test_algorithmic_bytes_follow_surveys_table():

@@ -149,6 +149,8 @@ n_tasks, per_rank = 5, 3                                   # 5 tasks over 2 rank
 mine = list(range(n_tasks))[rank * per_rank:(rank + 1) * per_rank]
 stats = {"init_coverage": np.array([0.1 * (t + 1) for t in mine]), "final_coverage": np.array([0.1 * (t + 1) + 0.05 * t for t in mine]),
          "simulation_steps": 100 * (rank + 1)}
+if os.environ.get("FS_NAN_EPISODE") and rank == 1:
+    stats["final_coverage"][0] = np.nan                     # a diverged episode: its coverage really is NaN
 out = merge_rank_statistics(stats, per_rank)
 print(json.dumps({"rank": rank, **out}))
 fdist.barrier()
@@ -175,7 +177,19 @@ def test_evaluate_command_merges_uneven_rank_blocks(tmp_path):
         final = np.array([0.1 * (t + 1) + 0.05 * t for t in range(5)], np.float32)
         assert rec["gpus"] == 2 and rec["episodes"] == 5 and rec["simulation_steps"] == 300
         assert rec["init_coverage"] == pytest.approx(float(init.mean())) and rec["final_coverage"] == pytest.approx(float(final.mean()))
-        assert rec["episode_delta_coverage"] == pytest.approx(float((final - init).mean()))
+        assert rec["episode_delta_coverage"] == pytest.approx(float((final - init).mean())) and "non_finite_coverages" not in rec
+    # an episode whose coverage really is NaN is COUNTED and SHOWN (the padding behind a short block is sliced off by the gathered
+    # episode counts, not recognised by its value): 5 episodes, NaN means, one non-finite coverage reported
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port), FS_ROOT=ROOT, FS_NAN_EPISODE="1")) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err[-2000:]
+        rec = json.loads(out.strip().splitlines()[-1])
+        assert rec["episodes"] == 5 and rec["non_finite_coverages"] == 1 and np.isnan(rec["final_coverage"])
+        assert rec["init_coverage"] == pytest.approx(float(init.mean()))
 
 
 LAUNCHED_WORKER = r"""

@@ -102,8 +102,9 @@ def test_tenant_table_counts_live_processes_and_forgets_dead_ones(tmp_path, monk
     assert lib.fs_tenants_count(key, 0) == 2
     b.send_signal(signal.SIGKILL)                                                       # no goodbye
     b.wait(timeout=10)
+    assert lib.fs_tenants_count(key, -1) == 2                                           # occupied slots as they stand: the dead one too
     assert lib.fs_tenants_count(key, 1) == 1                                            # pruned: the pid is gone
-    assert lib.fs_tenants_count(key, 0) == 1
+    assert lib.fs_tenants_count(key, 0) == 1 and lib.fs_tenants_count(key, -1) == 1
     files = sorted(f for f in os.listdir(tmp_path) if f.startswith("flingsim-tenants-"))
     assert len(files) == 2 and all(os.stat(os.path.join(tmp_path, f)).st_mode & 0o077 == 0 for f in files)   # per user, private
     assert lib.fs_tenants_unregister(key) == 0 and lib.fs_tenants_count(key, 1) == 0
@@ -140,9 +141,11 @@ e_f, e_i = np.zeros(0, np.float32), np.zeros(0, np.int32)
 pyflex.set_scene(0, sc.survey_params(16), e_f, e_i, e_i, e_i, e_i, 0)
 print("ready", pyflex._tenants()[0], pyflex._tenants()[1], flush=True)
 sys.stdin.readline()
-for _ in range(70):
+pyflex.step()
+first = pyflex._tenants()[1]                  # a neighbour that registered meanwhile is noticed at the very next step
+for _ in range(69):
     pyflex.step()
-print("stepped", pyflex._tenants()[0], pyflex._tenants()[1], flush=True)
+print("stepped", pyflex._tenants()[0], pyflex._tenants()[1], first, flush=True)
 print(np.asarray(pyflex.get_positions()).view(np.uint32).sum(dtype=np.uint64), flush=True)
 sys.stdin.readline()
 """
@@ -151,7 +154,7 @@ sys.stdin.readline()
 @pytest.mark.gpu
 def test_module_selects_the_cotenant_backend_by_itself(gpu_required, tmp_path):
     """Two unmodified `pyflex` processes on one GPU, FLINGSIM_SHARED_GPU unset: the first starts as a lone tenant (AUTO), the
-    second sees two and takes the co-tenant back-end at its first set_scene, the first follows within 64 steps -- and both
+    second sees two and takes the co-tenant back-end at its first set_scene, the first follows at its next step -- and both
     produce the same bits (the back-ends are interchangeable).  FLINGSIM_SHARED_GPU=0 / 1 overrides the detection."""
     import subprocess
 
@@ -177,7 +180,7 @@ def test_module_selects_the_cotenant_backend_by_itself(gpu_required, tmp_path):
     for p in (a, b, c):
         p.stdin.write("go\n"); p.stdin.flush()
     for p, want in ((a, "cotenant"), (b, "cotenant"), (c, "auto")):
-        assert p.stdout.readline().split() == ["stepped", "3", want]   # a lone starter follows at its 64th step
+        assert p.stdout.readline().split() == ["stepped", "3", want, want]   # a lone starter follows at its FIRST step
         sums.append(int(p.stdout.readline()))
     assert sums[0] == sums[1] == sums[2]
     for p in (a, b, c):
@@ -186,7 +189,7 @@ def test_module_selects_the_cotenant_backend_by_itself(gpu_required, tmp_path):
     d, rd = child(FLINGSIM_SHARED_GPU="1")
     assert rd == ["ready", "1", "cotenant"], rd                     # (and the three above have left the table)
     d.stdin.write("go\n"); d.stdin.flush()
-    assert d.stdout.readline().split() == ["stepped", "1", "cotenant"]
+    assert d.stdout.readline().split() == ["stepped", "1", "cotenant", "cotenant"]
     assert int(d.stdout.readline()) == sums[0]
     d.stdin.write("bye\n"); d.stdin.flush()
     assert d.wait(timeout=30) == 0

@@ -192,11 +192,21 @@ def test_evaluate_command_line_runs_a_stored_set(gpu_required, tmp_path, capsys)
     path = str(tmp_path / "set.npz")
     taskio.save_tasks(path, made)
     capsys.readouterr()
-    evaluate.main(["--tasks", path, "--slots", "2", "--episode-length", "1"])
+    replay = str(tmp_path / "replay.npz")
+    evaluate.main(["--tasks", path, "--slots", "2", "--episode-length", "1", "--dump", replay])
     line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["tasks"] == len(made) and rec["episode_length"] == 1.0 and rec["simulation_steps"] > 0
     assert 0.0 < rec["init_coverage"] < 1.05 and set(rec["action_primitive_counts"]) == {"fling"}
+    # --dump: the episode log SimEnv.on_episode_end would have dumped (taskio.save_replay), and the reference's statistics
+    # over it (taskio.collect_stats = utils.collect_stats) agree with the line the command printed
+    logged = np.load(replay)
+    assert [str(k) for k in logged["keys"]] == ["%09d_step00_last" % i for i in range(len(made))]
+    cs = taskio.collect_stats(replay)
+    level = str(made[0]["task_difficulty"])
+    assert cs[f"final_coverage/{level}/mean"] == pytest.approx(rec["final_coverage"], rel=1e-6)
+    # (the log's init_coverage is the TASK's stored one, Task.get_stats() -- simEnv.py:447-450 -- not the one measured after the reset)
+    assert cs[f"init_coverage/{level}/mean"] == pytest.approx(np.mean([t["initial_coverage"] / t["flatten_area"] for t in made]), rel=1e-6)
     # the same as ONE rank of a torch.distributed.run launch (process group on RCCL, LOCAL_RANK -> device): same statistics
     import subprocess
     import socket
@@ -210,3 +220,42 @@ def test_evaluate_command_line_runs_a_stored_set(gpu_required, tmp_path, capsys)
     rec2 = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     # (the policy is random-initialised per process, so the actions differ; the tasks and the statistics' shape do not)
     assert rec2["tasks"] == rec["tasks"] and rec2["init_coverage"] == rec["init_coverage"] and set(rec2) == set(rec)
+
+
+def test_episode_log_statistics_equal_the_references_collect_stats(tmp_path):
+    """f4's other half, the part the evaluation path needs: SimEnv.on_episode_end -> Memory.dump leaves one HDF5 group per
+    action (learning/Memory.py:106-165) and utils.collect_stats (utils.py:186-390) turns the file into the numbers run_sim.py
+    prints.  Here: taskio.save_replay writes the same per-action scalars under the same group names into a .npz, and
+    taskio.collect_stats must return what the REFERENCE's collect_stats returned for the same log
+    (tests/golden/replay_golden.npz, made by tests/golden/make_golden.py replay -- the reference's function run as is over
+    the log): every key, exactly -- with the default window of the latest 128 entries and with all of them."""
+    from flingbot_amd import taskio
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "replay_golden.npz"))
+    keys = [str(k) for k in z["keys"]]
+    log = {f: z["log:" + f] for f in ("preaction_coverage", "postaction_coverage", "max_coverage", "init_coverage", "task_difficulty",
+                                      "action_primitive", "task_name")}
+    # back to the shape evaluate.run_tasks hands over: one record per episode, one task per episode
+    records, tasks = [], []
+    for i, key in enumerate(keys):
+        if "_step00" in key:
+            records.append({"coverage": [float(log["preaction_coverage"][i])], "actions": [], "rewards": [], "preaction_coverage": []})
+            tasks.append({"cloth_mass": 0.5, "flatten_area": float(log["max_coverage"][i]), "task_difficulty": str(log["task_difficulty"][i]),
+                          "initial_coverage": float(log["init_coverage"][i])})
+        r = records[-1]
+        r["preaction_coverage"].append(float(log["preaction_coverage"][i]))
+        r["coverage"].append(float(log["postaction_coverage"][i]))
+        r["rewards"].append(float(log["postaction_coverage"][i] - log["preaction_coverage"][i]))
+        r["actions"].append(str(log["action_primitive"][i]))
+    path = str(tmp_path / "replay.npz")
+    assert taskio.save_replay(path, records, tasks) == len(keys)
+    assert [str(k) for k in np.load(path)["keys"]] == keys                       # the reference's group names, in its order
+    assert len(keys) > 128                                                        # the default window really cuts
+    for tag, kw in (("latest128", {}), ("all", {"num_points": 10 ** 6})):
+        got = taskio.collect_stats(path, **kw)
+        want = {k[len(tag) + 1:]: z[k] for k in z.files if k.startswith(tag + ":")}
+        assert set(got) == set(want), (sorted(set(got) ^ set(want)))
+        for k, v in want.items():
+            assert np.array_equal(np.asarray(got[k], np.float64), v), (tag, k, got[k], v)
+    with pytest.raises(ValueError):
+        taskio.collect_stats(str(tmp_path / "tasks_not_replay.npz")) if taskio.save_tasks(str(tmp_path / "tasks_not_replay.npz"), []) == 0 else None
