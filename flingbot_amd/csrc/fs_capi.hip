@@ -123,7 +123,6 @@ fs_ctx::~fs_ctx() {
     if (d_ids) (void)hipFree(d_ids);
     if (d_slot_envs) (void)hipFree(d_slot_envs);
     if (d_slot_sweeps) (void)hipFree(d_slot_sweeps);
-    if (d_tile_map) (void)hipFree(d_tile_map);
     if (h_ids) (void)hipHostFree(h_ids);
     if (h_stage) (void)hipHostFree(h_stage);
     if (render_scratch) (void)hipFree(render_scratch);
@@ -284,12 +283,6 @@ extern "C" int fs_set_stream_groups(fs_ctx *ctx, int groups) {
     return FS_OK;
 }
 extern "C" int fs_last_stream_groups(const fs_ctx *ctx) { return ctx ? ctx->last_stream_groups : FS_ERR_ARG; }
-extern "C" int fs_set_tile_map(fs_ctx *ctx, int mode) {
-    if (!ctx || mode < -1 || mode > 1) { fs_set_error("fs_set_tile_map: -1 never, 0 automatic, 1 always"); return FS_ERR_ARG; }
-    ctx->tile_map_mode = mode;
-    return FS_OK;
-}
-extern "C" int fs_last_tile_map(const fs_ctx *ctx) { return ctx ? ctx->last_tile_map : FS_ERR_ARG; }
 extern "C" int fs_get_solver(const fs_ctx *ctx) { return ctx ? ctx->solver : FS_ERR_ARG; }
 extern "C" int fs_last_kernel_form(const fs_ctx *ctx) { return ctx ? ctx->last_form : FS_ERR_ARG; }
 extern "C" int fs_last_boundary_form(const fs_ctx *ctx) { return ctx ? ctx->last_boundary : FS_ERR_ARG; }

@@ -128,10 +128,6 @@ struct fs_ctx {
     FsShapesDev *d_shapes = nullptr;  // [n_envs]
     FsEnvDev *d_slot_envs = nullptr;  // [n_envs] launch table of the streaming kernels (fs_k_slot_table)
     FsSlotSweeps *d_slot_sweeps = nullptr;  // [n_envs] the slots' sphere sweeps per substep, built with the table
-    int *d_tile_map = nullptr;        // workgroup -> (slot, block) of launch lists with mixed cloth sizes (fs_k_tile_map), grow-only
-    size_t tile_map_ints = 0;
-    int last_tile_map = 0;            // 1 when the most recent streaming launch used the tile map (fs_last_tile_map)
-    int tile_map_mode = 0;            // fs_set_tile_map: 0 automatic, 1 always, -1 never
     int *d_ids = nullptr;             // [n_envs] launch list
     int *h_ids = nullptr;             // pinned
     std::vector<int> uploaded_ids;    // what d_ids holds (upload_ids skips an identical list)

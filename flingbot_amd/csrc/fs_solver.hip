@@ -128,7 +128,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     if (groups > FS_MAX_STREAM_GROUPS) groups = FS_MAX_STREAM_GROUPS;
     if (groups > (ne + 7) / 8) groups = (ne + 7) / 8;
     if (groups < 1) groups = 1;
-    struct Chain { int first, count, gx; dim3 grid; hipStream_t st; const int *tmap; };
+    struct Chain { int first, count, gx; dim3 grid; hipStream_t st; };
     Chain chain[FS_MAX_STREAM_GROUPS];
     {
         const int blocks8 = (ne + 7) / 8;
@@ -144,55 +144,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             c.gx = (mx + FS_TILE - 1) / FS_TILE;
             c.grid = dim3((unsigned)(((c.count + 7) / 8) * 8) * (unsigned)c.gx);
             c.st = st;
-            c.tmap = nullptr;
         }
-    }
-    // Tile map (fs_stream_kernels.h): a launch list of mixed cloth sizes gets exactly the workgroups its episodes need.  Taken
-    // when the launch is in the throughput regime (the table costs one more scalar load in front of every kernel) and the
-    // arithmetic mapping would start at least an eighth of its workgroups for nothing.  Built on the device, on the context's
-    // stream, after the slot table it reads and before the chains fork.
-    {
-        size_t need = 0, arithmetic = 0, rows_total = 0;
-        FsTileChains tc = {};
-        for (int g = 0; g < groups; ++g) {
-            const Chain &c = chain[g];
-            int lane_rows[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int k = 0; k < c.count; ++k) {
-                const int blocks = (ctx->envs[ids[c.first + k]].host.n + FS_TILE - 1) / FS_TILE;
-                lane_rows[k & 7] += blocks;
-                need += (size_t)blocks;
-            }
-            tc.first[g] = c.first;
-            tc.count[g] = c.count;
-            tc.kmax[g] = std::max(1, *std::max_element(lane_rows, lane_rows + 8));  // (at least one row: the grid is never empty)
-            tc.offset[g] = (int)(rows_total * 8);
-            rows_total += (size_t)tc.kmax[g];
-            arithmetic += (size_t)c.grid.x;
-        }
-        bool use_map = ctx->tile_map_mode > 0 ||
-                       (ctx->tile_map_mode == 0 && launch_particles >= (size_t)64 * 4096 && rows_total * 8 * 8 <= arithmetic * 7);
-        if (max_n > 0xffff * FS_TILE || ne > 0x7fff) use_map = false;  // (block / slot fields of a table entry)
-        (void)need;
-        if (use_map && rows_total * 8 > ctx->tile_map_ints) {
-            // grow: rare (a larger list than ever before); nothing may still be reading the old table
-            if (ctx->d_tile_map) {
-                fs_sync_all_streams(ctx);
-                (void)hipFree(ctx->d_tile_map);
-                ctx->d_tile_map = nullptr;
-                ctx->tile_map_ints = 0;
-            }
-            const size_t ints = rows_total * 8 * 2;
-            HIP_TRY(hipMalloc((void **)&ctx->d_tile_map, ints * sizeof(int)));
-            ctx->tile_map_ints = ints;
-        }
-        if (use_map) {
-            hipLaunchKernelGGL(fs_k_tile_map, dim3((unsigned)groups), dim3(256), 0, st, ctx->d_slot_envs, tc, ctx->d_tile_map);
-            for (int g = 0; g < groups; ++g) {
-                chain[g].tmap = ctx->d_tile_map + tc.offset[g];
-                chain[g].grid = dim3((unsigned)tc.kmax[g] * 8u);
-            }
-        }
-        ctx->last_tile_map = use_map ? 1 : 0;
     }
     // From the fork to the join an early return would leave chains running on the episodes' slabs while the caller believes
     // the context's stream is all there is to wait for: every error in between waits for ALL streams before it returns.
@@ -227,21 +179,20 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
             const Chain &c = chain[g];
             const FsEnvDev *tab = ctx->d_slot_envs + c.first;
             const int *cids = d_ids + c.first;
-            const int *tmap = c.tmap;   // what the tile kernels take in the place of the (unused) id list
             const dim3 bgrid((unsigned)c.count), bblock(FS_BOUND_THREADS);
             switch (kind) {
                 case K_BOUND_FIRST: hipLaunchKernelGGL((fs_k_boundary<false, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, 0); break;
                 case K_BOUND_MID: hipLaunchKernelGGL((fs_k_boundary<true, true>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip); break;
                 case K_BOUND_LAST: hipLaunchKernelGGL((fs_k_boundary<true, false>), bgrid, bblock, FS_BOUND_LDS_BYTES, c.st, tab, cids, flip); break;
-                case K_PREDICT: hipLaunchKernelGGL(fs_k_predict, c.grid, block, 0, c.st, tab, tmap, c.gx, c.count); break;
+                case K_PREDICT: hipLaunchKernelGGL(fs_k_predict, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
                 case K_SCAN: hipLaunchKernelGGL(fs_k_grid_scan, bgrid, dim3(1024), 0, c.st, tab, cids); break;
-                case K_SCATTER: hipLaunchKernelGGL(fs_k_grid_scatter, c.grid, block, 0, c.st, tab, tmap, c.gx, c.count); break;
+                case K_SCATTER: hipLaunchKernelGGL(fs_k_grid_scatter, c.grid, block, 0, c.st, tab, cids, c.gx, c.count); break;
                 case K_FIND:
-                    if (find_stencil) hipLaunchKernelGGL(fs_k_find_neighbors<true>, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, tmap, sub, c.gx, c.count);
-                    else hipLaunchKernelGGL(fs_k_find_neighbors<false>, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, tmap, sub, c.gx, c.count);
+                    if (find_stencil) hipLaunchKernelGGL(fs_k_find_neighbors<true>, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, c.gx, c.count);
+                    else hipLaunchKernelGGL(fs_k_find_neighbors<false>, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, c.gx, c.count);
                     break;
-                case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, tmap, sub, flip, c.gx, c.count); break;
-                default: hipLaunchKernelGGL(fs_k_finalize, c.grid, block, 0, c.st, tab, tmap, flip, c.gx, c.count); break;
+                case K_ITER: hipLaunchKernelGGL(iter_kernel, c.grid, block, 0, c.st, tab, ctx->d_slot_sweeps + c.first, cids, sub, flip, c.gx, c.count); break;
+                default: hipLaunchKernelGGL(fs_k_finalize, c.grid, block, 0, c.st, tab, cids, flip, c.gx, c.count); break;
             }
         }
     };

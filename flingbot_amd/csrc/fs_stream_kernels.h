@@ -25,45 +25,11 @@ __device__ __forceinline__ int fs_stream_bucket(int cx, int cy, int cz) {
 // step (fs_k_grid_scan's one workgroup per episode lands there too).  The per-XCD L2 keeps what the previous kernel wrote,
 // so an episode's positions and lists are L2 hits in the next kernel instead of round trips to the memory side (measured:
 // 104x104 x 16 episodes 1.18 -> 0.97 ms/step, crumpled 64x64 x 64 episodes 1.89 -> 1.64).
-// TILE MAP (round 6).  The arithmetic mapping gives every slot of a launch the workgroups of its LARGEST episode; a launch
-// list of mixed cloth sizes -- the evaluation loop's: sides 64..103, 4096..10609 particles -- then starts a third of its
-// workgroups only to see them return (132 stored tasks, flat: 2.54 ms per frame against 2.05 for the same particle total in one
-// size; scripts/eval_shape_timing.py).  For such lists the host asks fs_k_tile_map for a table, one int per workgroup:
-// (slot << 16) | block, laid out [k][xcd lane] so that workgroup n = 8 k + lane still lands on XCD lane = slot % 8, each
-// lane's slots listed one after the other with exactly their own blocks, -1 where a lane has run out (lanes differ by the few
-// per cent their slots' totals differ).  `tmap` arrives in SGPRs with the wave (kernarg preload); null = the arithmetic mapping.
-__device__ __forceinline__ bool fs_stream_tile(const int *tmap, int gx, int ne, int &bx, int &by) {
-    const int n = blockIdx.x;
-    if (tmap) {
-        const int w = tmap[n];   // uniform address: a scalar load
-        by = w >> 16;
-        bx = w & 0xffff;
-        return w >= 0;
-    }
-    const int k = n >> 3;
+__device__ __forceinline__ bool fs_stream_tile(int gx, int ne, int &bx, int &by) {
+    const int n = blockIdx.x, k = n >> 3;
     by = (k / gx) * 8 + (n & 7);
     bx = k - (k / gx) * gx;
     return by < ne;
-}
-
-// one workgroup (256 threads) per launch chain: lane x = t & 7 walks its slots x, x + 8, ... of the chain, 32 threads per lane
-// write a slot's blocks side by side; a slot a device-side loop has retired (slot_env < 0) gets no workgroup at all.  `kmax`
-// (host: the largest lane total over ALL listed slots, retired or not -- the launch's grid is 8 * kmax) is never exceeded.
-struct FsTileChains {
-    int first[4], count[4], kmax[4], offset[4];   // FS_MAX_STREAM_GROUPS chains: slot range, rows of the map, start within `map`
-};
-__global__ __launch_bounds__(256) void fs_k_tile_map(const FsEnvDev *table, FsTileChains ch, int *map) {
-    const int g = blockIdx.x, x = threadIdx.x & 7, r = threadIdx.x >> 3;
-    const FsEnvDev *tab = table + ch.first[g];
-    int *m = map + ch.offset[g];
-    int k = 0;
-    for (int s = x; s < ch.count[g]; s += 8) {
-        const int blocks = tab[s].slot_env < 0 ? 0 : (tab[s].n + FS_TILE - 1) / FS_TILE;
-        for (int b = r; b < blocks; b += 32)
-            if (k + b < ch.kmax[g]) m[(k + b) * 8 + x] = (s << 16) | b;
-        k += blocks;
-    }
-    for (int q = k + r; q < ch.kmax[g]; q += 32) m[q * 8 + x] = -1;
 }
 
 // ---- launch table.  The kernels of a step reach their episode through the launch list: ids[slot] -> envs[episode] -> arrays,
@@ -99,9 +65,9 @@ __global__ __launch_bounds__(64) void fs_k_slot_table(const FsEnvDev *envs, cons
     if (threadIdx.x == 0) table[slot].slot_env = e;
 }
 
-__global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *tmap, int gx, int ne) {
+__global__ __launch_bounds__(FS_TILE) void fs_k_predict(const FsEnvDev *envs, const int *ids, int gx, int ne) {
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
     if (E.slot_env < 0) return;    // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
@@ -161,9 +127,9 @@ __global__ __launch_bounds__(1024) void fs_k_grid_scan(const FsEnvDev *envs, con
 }
 
 // ---- scatter particle ids into buckets.  After this kernel cell_fill[b] == end of bucket b.
-__global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *envs, const int *tmap, int gx, int ne) {
+__global__ __launch_bounds__(FS_TILE) void fs_k_grid_scatter(const FsEnvDev *envs, const int *ids, int gx, int ne) {
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
     if (E.slot_env < 0) return;    // retired slot
     const int i = bx * FS_TILE + threadIdx.x;
@@ -381,10 +347,10 @@ __global__ __launch_bounds__(FS_BOUND_THREADS) void fs_k_boundary(const FsEnvDev
 // STENCIL: every episode of the launch is a grid cloth in find mode 4 (the host checks the launch list): the packed rest-near
 // ids are never loaded and the kernel fits 5 waves per SIMD instead of 4.
 template <bool STENCIL>
-__global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *tmap,
+__global__ __launch_bounds__(FS_TILE) void fs_k_find_neighbors(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                                int sub, int gx, int ne) {
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
     if (E.slot_env < 0) return;    // retired slot
     __shared__ uint32_t queue_s[FS_STREAM_FINDQ][FS_TILE];
@@ -691,11 +657,11 @@ __device__ __forceinline__ void fs_iterate_particle_grid(const FsEnvDev &E, cons
     dst[i] = xi;
 }
 
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *tmap,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_grid(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                              int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[256];
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];
     const int e = E.slot_env;
     if (e < 0) return;  // retired slot
@@ -789,10 +755,10 @@ __device__ __forceinline__ void fs_iterate_particle_gridl(const FsEnvDev &E, con
 // beyond 4 buys nothing: 64x64 cloths x 1 / 8 / 32 / 64 episodes 0.913 / 1.054 / 1.133 / 1.484 -> 0.880 / 1.026 / 1.099 / 1.454 ms
 // per step; larger launches measured slower with it and keep the general form.
 template <bool POSK>
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *tmap,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                               int sub, int flip, int gx, int ne) {
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];
     const int e = E.slot_env;
     if (e < 0) return;  // retired slot
@@ -838,11 +804,11 @@ __device__ __forceinline__ void fs_stage_sdict(const FsEnvDev &E, FsVec4 *sdict)
 
 // throughput form (big launches): six springs in flight, later loads issued when needed (fewer live registers)
 template <bool CODED>
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *tmap,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                         int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];
     const int e = E.slot_env;
     if (e < 0) return;  // retired slot
@@ -853,11 +819,11 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate(const FsEnvDev *envs, co
 }
 // latency form (small launches)
 template <bool CODED>
-__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *tmap,
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
                                                               int sub, int flip, int gx, int ne) {
     __shared__ FsVec4 sdict[CODED ? 256 : 1];
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];
     const int e = E.slot_env;
     if (e < 0) return;  // retired slot
@@ -868,9 +834,9 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_eager(const FsEnvDev *en
 }
 
 // ---- finalize: velocity from displacement, maxAcceleration / maxSpeed clamps (NvFlex.h:112-113), sleeping (:110)
-__global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, const int *tmap, int flip, int gx, int ne) {
+__global__ __launch_bounds__(FS_TILE) void fs_k_finalize(const FsEnvDev *envs, const int *ids, int flip, int gx, int ne) {
     int bx, by;
-    if (!fs_stream_tile(tmap, gx, ne, bx, by)) return;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
     const FsEnvDev &E = envs[by];  // the slot's own copy of its episode's descriptor (fs_k_slot_table)
     if (E.slot_env < 0) return;    // retired slot
     const int i = bx * FS_TILE + threadIdx.x;

@@ -147,8 +147,6 @@ def load_library(build_if_missing=True):
         "fs_get_last_shape_candidates": (ci, [vp, ci, ip]),
         "fs_device_positions": (vp, [vp, ci]),
         "fs_device_key": (ci, [vp, C.c_char_p, ci]),
-        "fs_set_tile_map": (ci, [vp, ci]),
-        "fs_last_tile_map": (ci, [vp]),
         "fs_tenants_register": (ci, [C.c_char_p]),
         "fs_tenants_count": (ci, [C.c_char_p, ci]),
         "fs_tenants_unregister": (ci, [C.c_char_p]),
@@ -235,13 +233,6 @@ class FlingSim:
     def set_stream_groups(self, groups):
         """Concurrent launch chains of the streaming back-end: 0 = measured default, 1..4 = forced (fs_set_stream_groups)."""
         self._ck(self.lib.fs_set_stream_groups(self.h, int(groups)))
-
-    def set_tile_map(self, mode):
-        """fs_set_tile_map: -1 never, 0 automatic (default), 1 always -- the workgroup table of mixed-size streaming launches."""
-        self._ck(self.lib.fs_set_tile_map(self.h, int(mode)))
-
-    def last_tile_map(self):
-        return self._ck(self.lib.fs_last_tile_map(self.h))
 
     def last_stream_groups(self):
         return self._ck(self.lib.fs_last_stream_groups(self.h))

@@ -176,12 +176,6 @@ int fs_last_boundary_form(const fs_ctx *ctx);
    number of chains of the most recent streaming launch (white box for the tests). */
 int fs_set_stream_groups(fs_ctx *ctx, int groups);
 int fs_last_stream_groups(const fs_ctx *ctx);
-/* Streaming launches over episodes of different sizes (the evaluation loop: cloth sides 64..103) take their workgroup ->
-   (episode slot, block) mapping from a device-built table instead of giving every slot the blocks of the largest episode
-   (csrc/fs_stream_kernels.h fs_k_tile_map).  mode 0 (default): when the launch is large and the arithmetic mapping would start
-   >= 1/8 of its workgroups for nothing; 1: always; -1: never.  Results do not depend on it (white box: fs_last_tile_map). */
-int fs_set_tile_map(fs_ctx *ctx, int mode);
-int fs_last_tile_map(const fs_ctx *ctx);
 /* white-box access for tests: y[i] = the reciprocal square root the constraint kernels use (csrc/fs_constraints.h fs_rsqrt),
    evaluated on the device for n host values -- what pins the checker's restatement of it to this chip */
 int fs_eval_rsqrt(fs_ctx *ctx, const float *x, float *y, int n);

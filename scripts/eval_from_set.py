@@ -3,7 +3,6 @@ the process, so that rocprofv3's kernel trace / PMC passes see nothing of the ta
 usage: eval_from_set.py tasks.npz [slots] [actions]
 EVAL_CONTACTS=k   every k-th closed chunk, download the contact-candidate counts of 8 slots (perturbs the timing: own run)
 EVAL_SOLVER=n     back-end of the context (0 AUTO)
-EVAL_TILE_MAP=m   fs_set_tile_map (-1 never, 0 automatic, 1 always)
 EVAL_CAP_MIN / EVAL_CAP   chunk bounds of the pipelined scheduler (default 2 / 4)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +19,6 @@ actions = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 tasks = taskio.TaskLoader(path, repeat=False).all_tasks()
 torch.manual_seed(1)
 ctx = fsim.FlingSim(n_envs=S, solver=int(os.environ.get("EVAL_SOLVER", "0")))
-ctx.set_tile_map(int(os.environ.get("EVAL_TILE_MAP", "0")))
 env = BatchedFlingEnv(ctx, episode_length=actions)
 policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
                                  obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
@@ -53,7 +51,7 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t0
 flings = sum(stats["action_primitive_counts"].values())
 st = stats["scheduler"]
 seq = max(st.get("sequences", 1), 1)
-print("tile map %s, chunk bounds %s / %s: " % (os.environ.get("EVAL_TILE_MAP", "0"), cap_min or "default", cap or "default"), end="")
+print("chunk bounds %s / %s: " % (cap_min or "default", cap or "default"), end="")
 print("eval loop %d tasks / %d slots / %d actions: %.2f s  %d flings (%.1f /s)  %d episode-steps (%.0f /s)" % (
     len(tasks), S, actions, dt, flings, flings / dt, stats["simulation_steps"], stats["simulation_steps"] / dt), flush=True)
 print("    fs_advance calls %d, launch sequences (frames) %d, mean active episodes %.1f, wall per frame %.3f ms" % (

@@ -17,7 +17,6 @@ path = sys.argv[1]
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 132
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 only = os.environ.get("SHAPE_ONLY", "ABCD")
-tile_map = int(os.environ.get("SHAPE_TILE_MAP", "0"))   # fs_set_tile_map: -1 never, 0 automatic, 1 always
 tasks = taskio.TaskLoader(path, repeat=False).all_tasks()[:E]
 E = len(tasks)
 if os.environ.get("SHAPE_BALANCE"):
@@ -44,14 +43,13 @@ else:
 
 
 def timed(ctx, label, particles):
-    ctx.set_tile_map(tile_map)
     ctx.step(3); ctx.sync()
     ms = []
     for _ in range(3):
         ctx.timer_start(); ctx.step(frames); ms.append(ctx.timer_stop() / frames)
     m = float(np.median(ms))
-    print("%-72s %7.3f ms/frame  (%.3f .. %.3f)  %9d particles  %5.1f G particle-iterations/s  kernel form %d, %d chain(s), tile map %d" % (
-        label, m, min(ms), max(ms), particles, particles * 120 / m / 1e6, ctx.last_kernel_form(), ctx.last_stream_groups(), ctx.last_tile_map()), flush=True)
+    print("%-72s %7.3f ms/frame  (%.3f .. %.3f)  %9d particles  %5.1f G particle-iterations/s  kernel form %d, %d chain(s)" % (
+        label, m, min(ms), max(ms), particles, particles * 120 / m / 1e6, ctx.last_kernel_form(), ctx.last_stream_groups()), flush=True)
     return m
 
 

@@ -130,18 +130,14 @@ def test_async_task_loop_equals_lockstep_loop(gpu_required, actions):
                                         for _ in range(n)])
     gen.close()
     results = []
-    for mode, slots in (("lockstep", n), ("async", n), ("async", 2), ("async-blocking", n), ("async-blocking", 2), ("async-deep", 2),
-                        ("async-tilemap", n)):
+    for mode, slots in (("lockstep", n), ("async", n), ("async", 2), ("async-blocking", n), ("async-blocking", 2), ("async-deep", 2)):
         ctx = fsim.FlingSim(n_envs=slots, solver=0)
-        if mode == "async-tilemap":      # the workgroup table of mixed-size launches (automatic only for large launches) forced on:
-            ctx.set_tile_map(1)          # slots retire on the device inside the wait loops, the table is rebuilt for every chunk
         env = BatchedFlingEnv(ctx, action_primitives=actions, image_dim=128, episode_length=3)
         policy = _policy(env)
         if mode == "lockstep":
             stats = run_episodes(policy, env, tasks)
-        elif mode in ("async", "async-tilemap"):   # the default: chunks queued ahead, services on the service lane, scenes prebuilt
+        elif mode == "async":            # the default: chunks queued ahead, services on the service lane, scenes prebuilt
             stats = run_tasks(policy, env, tasks)
-            assert ctx.last_tile_map() == (1 if mode == "async-tilemap" else 0)
         elif mode == "async-deep":       # one-sequence chunks, three of them open
             stats = run_tasks(policy, env, tasks, cap_min=1, cap=1)
         else:                            # the blocking scheduler, scenes built in place

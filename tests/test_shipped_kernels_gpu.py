@@ -372,61 +372,3 @@ def test_boundary_on_mixed_cloth_sizes_bit_exact(gpu_required):
     for s, o in zip(sample, orcs):
         _assert_bits(ctx, s, o, f"episode {s} ({dims[s]} x {dims[s]})")
     ctx.close()
-
-
-@pytest.mark.parametrize("groups", [1, 2])
-def test_tile_map_of_mixed_size_launches_bit_exact(gpu_required, groups):
-    """Round 6: a streaming launch over episodes of different sizes takes its workgroup -> (slot, block) mapping from a
-    device-built table (fs_k_tile_map) instead of giving every slot the workgroups of the largest episode.  Forced on for a
-    list of 18 cloths of three sizes (automatic only from 64 x 4096 particles on), one and two launch chains, two fs_step calls,
-    plus a launch of a SUBSET of the episodes (fs_step_list: another table): the oracle's bits, and the same bits as the
-    arithmetic mapping."""
-    from flingbot_amd import sim as fsim
-
-    dims = [64, 72, 96, 72, 64, 96, 72, 64, 96, 72, 64, 96, 72, 64, 96, 72, 64, 96]
-    steps = 6
-
-    def setup(sim, k):
-        sim.set_scene(cloth_params(dims[k], dims[k], pos=(0.0, -0.12, 0.0)))
-        rng = np.random.RandomState(7 + k)
-        pos = sim.get_positions().reshape(-1, 4).copy()
-        pos[:, :3] += (rng.randn(pos.shape[0], 3) * 0.004).astype(np.float32)
-        pos[:1500, :3] = (rng.rand(1500, 3) * [0.1, 0.04, 0.1] + [0.0, 0.02, 0.0]).astype(np.float32)
-        sim.set_positions(pos.ravel())
-
-    sample = [0, 1, 2, 9, 17]
-    subset = [1, 2, 5, 9, 10, 13, 17]
-    orcs = _oracle_runs([lambda o, s=s: setup(o, s) for s in sample], steps)
-    states = {}
-    for mode in (1, -1):
-        ctx = fsim.FlingSim(n_envs=len(dims), solver=fsim.FS_SOLVER_AUTO)
-        ctx.set_tile_map(mode)
-        ctx.set_stream_groups(groups)
-        for e in range(len(dims)):
-            setup(ctx.env(e), e)
-        ctx.step(steps // 2)
-        assert ctx.last_tile_map() == (1 if mode == 1 else 0) and ctx.last_kernel_form() == fsim.FS_FORM_STREAM_GRIDL
-        ctx.step(steps - steps // 2)
-        for s, o in zip(sample, orcs):
-            _assert_bits(ctx, s, o, f"tile map {mode}: episode {s} ({dims[s]} x {dims[s]})")
-        ctx.step_list(subset, 2)                      # a shorter list: the table is rebuilt for it
-        assert ctx.last_tile_map() == (1 if mode == 1 else 0)
-        states[mode] = [np.array(ctx.get_positions(e)).view(np.uint32).copy() for e in range(len(dims))]
-        ctx.close()
-    for e in range(len(dims)):
-        assert np.array_equal(states[1][e], states[-1][e]), e
-
-
-def test_tile_map_is_automatic_for_large_mixed_launches(gpu_required):
-    """The automatic rule: a launch of at least 64 x 4096 particles whose arithmetic mapping would start an eighth or more of
-    its workgroups for nothing takes the table; a launch of one size, or a small one, keeps the arithmetic mapping."""
-    from flingbot_amd import sim as fsim
-
-    for dims, want in (([64] * 24 + [104] * 40, 1), ([80] * 64, 0), ([64, 104] * 6, 0)):
-        ctx = fsim.FlingSim(n_envs=len(dims), solver=fsim.FS_SOLVER_AUTO)
-        for e, d in enumerate(dims):
-            ctx.set_scene(e, cloth_params(d, d, pos=(0.0, -0.12, 0.0)))
-        ctx.step(2)
-        assert ctx.last_tile_map() == want, (dims[:3], len(dims), ctx.last_tile_map())
-        assert np.isfinite(ctx.get_positions(len(dims) - 1)).all()
-        ctx.close()
