@@ -18,6 +18,7 @@
 // FLINGSIM_SHARED_GPU=1 themselves.
 //
 // Host-only code, no HIP: the CPU suite exercises it with real child processes (tests/test_pyflex_module.py).
+#include <cctype>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>

@@ -349,6 +349,23 @@ def test_model_alternatives_are_live_and_bounded(capsys):
             assert max(out[(s, v)]["divergence"]) > 0, (s, v)
     assert max(out[("c2", "alt_shape_end_pose")]["divergence"]) == 0.0       # no spheres in the crumple
     assert max(out[("fling", "alt_shape_end_pose")]["divergence"]) > 1e-6    # pickers move in the fling
+    # the finalize clamp's readings (NvFlex.h:112-113; round 6): the clamp DOES fire in both workloads (white-box counter), every
+    # reading of it moves the trajectory, dropping it altogether sends the sheet flying at the pop-out of flex_utils.set_scene's
+    # step (metres after one frame of the crumple), and no contact normal ever falls back to (0,1,0)
+    for s in ("c2", "fling"):
+        clamps, degenerate, particle_substeps = out[(s, "exact")]["white"]
+        assert 0 < clamps < particle_substeps and degenerate == 0, (s, out[(s, "exact")]["white"])
+        for v in ("alt_no_maxaccel", "alt_maxaccel_per_frame", "alt_maxaccel_position"):
+            assert max(out[(s, v)]["divergence"]) > 1e-4, (s, v)
+        # a picked particle's velocity at finalize cannot matter: the reference grasps a settled cloth and never writes velocities
+        assert out[(s, "alt_kinematic_velocity_kept")]["divergence"] == [0.0] * len(out[(s, "exact")]["frames"])
+    assert out[("c2", "alt_no_maxaccel")]["divergence"][0] > 1.0
+    # every switch of the oracle has its row in the table and its paragraph in PARITY.md
+    from oracle.flex import MODEL_ALTERNATIVES
+    rows = {v for v, _ in pt.ROWS}
+    parity_md = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "PARITY.md")).read()
+    for name in MODEL_ALTERNATIVES:
+        assert "alt_" + name in rows and "`alt_" + name + "`" in parity_md, name
     with capsys.disabled():
         print("\n" + pt.render(out, scenarios=("c2", "fling")))
 

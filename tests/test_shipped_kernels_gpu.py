@@ -372,3 +372,33 @@ def test_boundary_on_mixed_cloth_sizes_bit_exact(gpu_required):
     for s, o in zip(sample, orcs):
         _assert_bits(ctx, s, o, f"episode {s} ({dims[s]} x {dims[s]})")
     ctx.close()
+
+
+def test_cotenant_solver_mode_chooses_per_launch(gpu_required):
+    """FS_SOLVER_COTENANT (what the `pyflex` module runs on when the co-tenant table shows a shared device): every launch whose
+    episodes all fit the fused kernel takes it, whatever the launch size -- one launch per frame on one compute unit each, so that
+    co-tenants' frames run side by side -- and any other launch is AUTO's; no launch can fail because of the mode.  Same bits."""
+    from flingbot_amd import sim as fsim
+
+    dims = [32, 104, 48]
+
+    def setup(sim, k):
+        sim.set_scene(cloth_params(dims[k], dims[k], pos=(0.0, -0.1, 0.0)))
+
+    orcs = _oracle_runs([lambda o, k=k: setup(o, k) for k in range(3)], 6)
+    ctx = fsim.FlingSim(n_envs=3, solver=fsim.FS_SOLVER_COTENANT)
+    for k in range(3):
+        setup(ctx.env(k), k)
+    fused = (fsim.FS_FORM_FUSED_12, fsim.FS_FORM_FUSED_16, fsim.FS_FORM_FUSED_GENERIC, fsim.FS_FORM_FUSED_GRID64)
+    ctx.step_list([0, 2], 3)                       # both fit the fused kernel: taken although two episodes are a "small launch"
+    assert ctx.last_kernel_form() in fused
+    ctx.step_list([1], 3)                          # 10 816 particles: AUTO's choice, the streaming kernels
+    assert ctx.last_kernel_form() not in fused
+    ctx.step_list([0, 2], 3)
+    ctx.step(3, env=1)
+    assert ctx.last_kernel_form() not in fused
+    for k in range(3):
+        _assert_bits(ctx, k, orcs[k], f"cotenant mode, episode {k} ({dims[k]} x {dims[k]})")
+    ctx.step(1)                                    # a mixed list: falls back to AUTO as a whole, never an error
+    assert ctx.last_kernel_form() not in fused
+    ctx.close()
