@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include <fcntl.h>
@@ -59,6 +60,7 @@ struct Mapping {
     Table *tab = nullptr;
 };
 Mapping g_map[4];  // a process rarely drives more than one device through the module; four is plenty
+std::mutex g_map_mutex;  // (ctypes callers may come from several threads; the table itself is guarded by flock)
 
 unsigned long long proc_start_time(int pid) {
     char path[64], buf[1024];
@@ -105,6 +107,7 @@ Mapping *open_table(const char *device_key) {
         fs_set_error("tenant table: empty device key");
         return nullptr;
     }
+    std::lock_guard<std::mutex> guard(g_map_mutex);
     Mapping *free_entry = nullptr;
     for (Mapping &m : g_map) {
         if (m.tab && m.key == device_key) return &m;

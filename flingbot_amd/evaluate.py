@@ -252,6 +252,20 @@ def main(argv=None):
     dev = f"cuda:{device}"
     torch.cuda.set_device(device)
     ctx = fsim.FlingSim(n_envs=max(1, min(a.slots, len(mine))), device=device, solver=0)
+    census = None
+    if world > 1:
+        # what the process group itself saw (one all_gather of rank / LOCAL_RANK / device identity): one process per GPU is the
+        # contract of the sharded run -- two ranks on one device would report N GPUs' worth of throughput from fewer
+        try:
+            arch = torch.cuda.get_device_properties(device).gcnArchName
+        except Exception:
+            arch = ""
+        census = fdist.rank_census(ctx.device_key(), arch)
+        if census["ranks_seen"] != world or census["distinct_devices"] != world:
+            ctx.close()
+            raise SystemExit(f"evaluate: WORLD_SIZE={world} but the process group's all_gather saw {census['ranks_seen']} rank(s) on "
+                             f"{census['distinct_devices']} distinct device(s) ({census['backend']}): one process per GPU, or use "
+                             f"--device with a single process")
     env = BatchedFlingEnv(ctx, episode_length=a.episode_length, device=dev)
     policy = nets.MaximumValuePolicy(action_primitives=["fling"], num_rotations=12, scale_factors=list(env.scale_factors),
                                      obs_dim=64, pix_grasp_dist=8, pix_drag_dist=8, pix_place_dist=5, rgb_only=True,
@@ -276,6 +290,7 @@ def main(argv=None):
            "simulation_steps": stats["simulation_steps"]}
     if world > 1:
         out.update(merge_rank_statistics(stats, per_rank, device=dev))
+        out.update({k: census[k] for k in ("ranks_seen", "distinct_devices", "backend", "collective_library")})
         fdist.barrier()
     if rank == 0:
         print(json.dumps(out))

@@ -229,5 +229,5 @@ def collect_stats(path, num_points=128, action_primitives=("fling", "stretchdrag
                 out[f"{key}/{level}/percent_negative"] = np.count_nonzero(v < 0.0) / len(v)
                 out[f"{key}/{level}/percent_zero"] = np.count_nonzero(v == 0.0) / len(v)
     for ap in ("fling", "drag", "place"):
-        out[f"action_primitive/percent_{ap}"] = counts[ap] / len(keys)
+        out[f"action_primitive/percent_{ap}"] = counts[ap] / len(keys) if keys else float("nan")
     return out

@@ -509,6 +509,8 @@ if os.environ.get("FS_EVAL_STUB") and os.environ.get("WORLD_SIZE"):
     class Ctx:
         def __init__(self, n_envs=1, device=0, solver=0, **kw):
             self.n_envs = n_envs
+        def device_key(self):      # PCI bus id of the rank's device; FS_SAME_DEVICE: ranks 0 and 1 were started on ONE GPU
+            return "0000:%02x:00.0" % (5 if os.environ.get("FS_SAME_DEVICE") and RANK < 2 else 5 + RANK)
         def close(self):
             pass
     class Env:
@@ -588,9 +590,19 @@ def test_evaluate_command_eight_ranks_end_to_end_uneven_blocks(tmp_path):
     rec = json.loads(lines[0])
     init = np.array([0.01 * (i + 1) / 0.5 for i in range(13)], np.float32)
     assert rec["gpus"] == 8 and rec["episodes"] == 13 and rec["tasks"] == 13 and rec["simulation_steps"] == 130
+    assert rec["ranks_seen"] == 8 and rec["distinct_devices"] == 8 and rec["backend"] == "gloo"     # from the collective, not from WORLD_SIZE
     assert rec["init_coverage"] == pytest.approx(float(init.mean()), rel=1e-6)
     assert rec["final_coverage"] == pytest.approx(float((init + np.float32(0.125)).mean()), rel=1e-6)
     assert rec["episode_delta_coverage"] == pytest.approx(0.125, rel=1e-5)
+    assert not any(_alive(p) for p in pids)
+
+
+def test_evaluate_command_refuses_two_ranks_on_one_device(tmp_path):
+    """`evaluate --gpus 8` with ranks 0 and 1 on ONE physical device (their device keys agree): the census all_gather shows 8 ranks
+    on 7 devices, every rank ends non-zero, no result line, no child left behind."""
+    out, pids, _ = _run_evaluate(tmp_path, {"FS_SAME_DEVICE": "1"})
+    assert out.returncode != 0 and "saw 8 rank(s) on 7 distinct device(s)" in out.stderr, out.stderr[-2000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert not any(_alive(p) for p in pids)
 
 
