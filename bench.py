@@ -262,6 +262,35 @@ def stream_limiter_from_profile():
     return None
 
 
+def eval_limiter_from_profile():
+    """What the committed counters say bounds the evaluation loop's launches: the PMC pass over the loop-less
+    reconstruction of its launch shape -- 132 stored hard tasks in their crumpled states, scripts/profile_shapes.sh case A (a PMC
+    pass over the loop itself is impractical: counter collection serialises its ~2 M dispatches)."""
+    import re
+    for tag in profile_tags("eval_shapes.txt"):
+        try:
+            txt = open(os.path.join(ROOT, "profiles", f"{tag}_eval_shapes.txt")).read()
+            block = txt.split("# PMC pass, case A", 1)[1].split("# PMC pass, case B", 1)[0]
+            ker = {}
+            for m in re.finditer(r"^(?:void )?(fs_k_\w+).*?\s+launches\s+(\d+)\s+waves/launch\s+(\d+)\s+VALU/wave\s+(\d+)\s+"
+                                 r"valu_active/wave_cycles ([0-9.]+)", block, re.M):
+                ker[m.group(1)] = {"waves_per_launch": int(m.group(3)), "valu_per_wave": int(m.group(4)),
+                                   "valu_active_per_wave_cycle": float(m.group(5))}
+            if "fs_k_iterate_gridl" not in ker:
+                continue
+            it = ker["fs_k_iterate_gridl"]
+            return {"bound": "valu-issue", "source": f"profiles/{tag}_eval_shapes.txt (case A: 132 stored tasks, crumpled, plain fs_step)",
+                    "kernels": ker, "iterate_valu_busy_fraction": it["valu_active_per_wave_cycle"] / 0.2,
+                    "note": "fs_k_iterate_gridl (79 % of the loop's kernel time) runs 5 waves per SIMD, so VALU-active per wave-cycle "
+                            "tops out at 0.2: at this launch size the kernel is VALU-bound on instructions that are ~40 % contact "
+                            "evaluation -- not the one-wave critical path of the 64-episode launch (DESIGN.md 6 has the frame's "
+                            "accounting: uniform benchmark 2.05 ms, + 0.5 ground contact and size mix, + 1.1 particle contacts, "
+                            "+ 0.5 the loop itself)"}
+        except Exception:
+            continue
+    return None
+
+
 def oracle_trajectory(seed, steps):
     """The checker: one episode of the workload on the C oracle, `steps` frames from the initial state."""
     from oracle import OracleSim
@@ -938,6 +967,9 @@ def eval_loop_leg(device_index, episodes=32, actions=3, stream_tasks=384, stream
                     "policy": "random-init fling value net (seeded)"})
         if stream_tasks > 0:
             out["continuous"] = one(stream_tasks, stream_slots, 1)
+            lim = eval_limiter_from_profile()
+            if lim:
+                out["continuous"]["limiter"] = lim
         return out
     except Exception as exc:  # the headline number must not depend on this leg
         import traceback

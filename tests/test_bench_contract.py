@@ -86,3 +86,16 @@ def test_algorithmic_bytes_follow_surveys_table():
     for dim, m in ((64, 23938), (32, 5826)):
         n = dim * dim
         assert bench.algorithmic_bytes_per_step(dim, dim) == 4 * (112 * n + 30 * (32 * n + 16 * m))
+
+
+def test_eval_loop_limiter_reads_the_committed_counters():
+    """The evaluation-loop entry of the bench line names what bounds its launches from the committed PMC pass of the loop-less
+    reconstruction (profiles/rNN_eval_shapes.txt, case A): VALU per wave of the iterate / search / boundary kernels and the
+    iterate kernel's VALU-busy fraction against the 0.2 ceiling of five waves per SIMD."""
+    import bench
+
+    lim = bench.eval_limiter_from_profile()
+    assert lim and lim["bound"] == "valu-issue" and lim["source"].startswith("profiles/r")
+    k = lim["kernels"]
+    assert {"fs_k_iterate_gridl", "fs_k_find_neighbors", "fs_k_boundary"} <= set(k)
+    assert 300 < k["fs_k_iterate_gridl"]["valu_per_wave"] < 1500 and 0.5 < lim["iterate_valu_busy_fraction"] <= 1.05
