@@ -37,7 +37,7 @@ VARIANTS = ("exact", "exact_rsqrt", "nofma", "newton", "host")  # host: exact_rs
 # (PARITY.md); they are never the parity oracle either.
 MODEL_ALTERNATIVES = ("friction_post", "neighbors_by_distance", "shape_end_pose", "sleep_velocity_only", "sleep_at_predict",
                       "no_sleep", "apply_per_type", "damping_mult", "stiffness_iter", "shape_every_iteration", "contact_planes",
-                      "count_candidates", "no_maxaccel", "maxaccel_per_frame", "maxaccel_position", "kinematic_velocity_kept")
+                      "count_candidates", "neighbors_at_start", "no_maxaccel", "maxaccel_per_frame", "maxaccel_position", "kinematic_velocity_kept")
 
 
 def build_oracle(force=False):

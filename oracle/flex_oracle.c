@@ -400,6 +400,8 @@ static int cell_lower_bound(const orc_sim *s, const int *keys, int cx, int cy, i
  *   -DORC_ALT_COUNT_CANDIDATES       the Local-relaxation divisor counts every LISTED contact of the particle (particle
  *                                    candidates and shape candidates), violated or not (NvFlex.h:89 "divided by the
  *                                    particle's constraint count"; default: only the constraints that pushed this iteration)
+ *   -DORC_ALT_NEIGHBORS_AT_START     particle-contact candidates are searched on the positions at the START of the substep
+ *                                    (default: on the predicted positions, Macklin 2014 Algorithm 1 "N_i(x*_i)")
  *   -DORC_ALT_NO_MAXACCEL            the maxAcceleration clamp of finalize is skipped (how much the rule matters at all;
  *                                    NvFlex.h:112-113 "clamped to this value at the end of each step")
  *   -DORC_ALT_MAXACCEL_PER_FRAME     "each step" read as each NvFlexUpdateSolver call: the velocity change since the START OF
@@ -438,7 +440,16 @@ static int cell_lower_bound(const orc_sim *s, const int *keys, int cx, int cy, i
  *  eNvFlexPhaseSelfCollideFilter on either drops pairs with |rest_i - rest_j|^2 < radius^2 (NvFlex.h:166,564-565),
  *  list = ascending j, truncated to the 96 smallest (maxNeighborsPerParticle, main.cpp:826)   [I: ordering/truncation]
  */
-static void find_neighbors(orc_sim *s) {
+static void find_neighbors(orc_sim *s_) {
+    /* [I] WHICH positions the search looks at: the predicted ones (Macklin 2014, Algorithm 1: "find neighboring particles
+       N_i(x*_i)" after the prediction); ORC_ALT_NEIGHBORS_AT_START searches the positions at the start of the substep. */
+#ifdef ORC_ALT_NEIGHBORS_AT_START
+    orc_sim view = *s_;
+    view.xp = s_->x0;
+    orc_sim *s = &view;
+#else
+    orc_sim *s = s_;
+#endif
     const int n = s->n;
     const float r = s->p.radius + s->p.particleCollisionMargin;
     const float r2 = r * r;
@@ -482,7 +493,7 @@ static void find_neighbors(orc_sim *s) {
                     if (cnt < total_cap) tmp[cnt++] = j;
                 }
             }
-        if (cnt > s->max_list) s->max_list = cnt; /* before truncation */
+        if (cnt > s_->max_list) s_->max_list = cnt; /* before truncation */
 #ifdef ORC_ALT_NEIGHBORS_BY_DISTANCE
         if (cnt > s->p.maxNeighbors) { /* keep the nearest: selection by (distance^2, id), then back to ascending id */
             for (int a = 0; a < s->p.maxNeighbors; ++a) {

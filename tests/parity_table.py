@@ -37,6 +37,7 @@ ROWS = [  # (variant, what it changes)
     ("alt_shape_every_iteration", "no collideShapes stage: every plane / sphere tested for every particle in every iteration (rounds 1-4)"),
     ("alt_contact_planes", "a sphere candidate frozen at collideShapes into its tangent plane (the data model of NvFlexGetContacts, NvFlex.h:1074-1080)"),
     ("alt_count_candidates", "Local-relaxation divisor counts every listed contact (particle and shape candidates), violated or not"),
+    ("alt_neighbors_at_start", "particle-contact candidates searched on the positions at the START of the substep (default: on the predicted positions, Macklin 2014 Algorithm 1)"),
     ("alt_no_maxaccel", "the maxAcceleration clamp of finalize skipped (how much the rule matters at all; NvFlex.h:112-113)"),
     ("alt_maxaccel_per_frame", "'at the end of each step' = each NvFlexUpdateSolver call: velocity change since the start of the FRAME clamped to maxAcceleration * dt, once after the last substep (default: per substep)"),
     ("alt_maxaccel_position", "a clamped particle's position follows its clamped velocity, x = x0 + h v (default: velocity clamped, position kept)"),
