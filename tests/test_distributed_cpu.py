@@ -476,6 +476,42 @@ def test_bench_refuses_two_ranks_on_one_device(tmp_path):
         assert not [l for l in out.splitlines() if l.startswith("{")]
 
 
+def test_bench_two_device_check_control_flow():
+    """bench.two_device_check (rank 0 of a multi-GPU run: its own and its neighbour's device driven from ONE process against the
+    oracle) with the GPU context replaced by an oracle-backed stand-in: skipped with a reason on a one-device box, `bit_exact` and
+    `distinct` on two devices, and a context that answers wrongly is reported, not raised."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import OracleSim
+
+    class Sim:
+        FS_SOLVER_FUSED = 2
+        wrong = False
+
+        class FlingSim:
+            def __init__(self, n_envs=1, device=0, solver=0):
+                self.device, self.o = device, OracleSim()
+            def set_scene(self, e, p): self.o.set_scene(p)
+            def step(self, n=1): self.o.step(n)
+            def get_positions(self, e=0):
+                p = self.o.get_positions()
+                if Sim.wrong and self.device == 1:
+                    p = p.copy(); p[5] += 1e-6
+                return p
+            def get_velocities(self, e=0): return self.o.get_velocities()
+            def device_key(self): return "0000:%02x:00.0" % (5 + self.device)
+            def close(self): pass
+
+    cuda = lambda n: types.SimpleNamespace(cuda=types.SimpleNamespace(device_count=lambda: n))   # noqa: E731
+    one = bench.two_device_check(Sim, cuda(1), 0)
+    assert one["checked"] is False and "1 device" in one["reason"]
+    two = bench.two_device_check(Sim, cuda(2), 1)
+    assert two == {**two, "checked": True, "devices": [1, 0], "distinct": True, "bit_exact": True}
+    Sim.wrong = True
+    assert bench.two_device_check(Sim, cuda(2), 0)["bit_exact"] is False
+
+
 def test_rank_census_single_process():
     """World size 1 needs no process group: the census reports itself."""
     sys.path.insert(0, ROOT)
