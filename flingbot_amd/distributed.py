@@ -62,6 +62,45 @@ def barrier():
         dist.barrier()
 
 
+class SharedTaskCounter:
+    """The reference's task queue is GLOBAL: one TaskLoader actor hands the next task to whichever environment asks first
+    (utils.py setup_envs: `get_task_fn = lambda: ray.get(task_loader.get_next_task.remote())`), so a worker that draws long
+    episodes simply takes fewer of them.  Across ranks the same thing is one atomic counter on the process group's own
+    rendezvous store (c10d TCPStore `add`: no extra socket, no collective): claim(k) returns up to k task indices nobody else
+    has, [] when the set is used up.  World size 1 (no process group): a local counter.  `key` must be the same on every rank
+    and fresh per task set."""
+
+    def __init__(self, n_tasks, key="tasks"):
+        self.n, self.local = int(n_tasks), 0
+        self.store = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.store = dist.PrefixStore("flingsim/" + str(key), dist.distributed_c10d._get_default_store())
+        self.claimed = []
+
+    def claim(self, k=1):
+        k = int(k)
+        if k <= 0:
+            return []
+        if self.store is not None:
+            end = int(self.store.add("next", k))
+        else:
+            self.local += k
+            end = self.local
+        got = [i for i in range(end - k, end) if i < self.n]
+        self.claimed += got
+        return got
+
+
+def sum_over_ranks(array, device=None):
+    """SUM all-reduce of a float64 array (every rank contributes its own episodes' entries, zeros elsewhere)."""
+    t = torch.as_tensor(array, dtype=torch.float64).clone()
+    if device is not None:
+        t = t.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
 def _hash63(text):
     import hashlib
     return int.from_bytes(hashlib.sha1(str(text).encode()).digest()[:8], "big") >> 1

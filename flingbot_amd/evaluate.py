@@ -56,7 +56,7 @@ def run_episodes(policy, env, tasks, max_steps=None, fold=True):
     }
 
 
-def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=None, pipeline=True, prebuild=True):
+def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=None, pipeline=True, prebuild=True, claim=None, claim_first=None):
     """The evaluation loop the way the reference actually runs it: every environment steps on its own, the policy acts for
     whichever environments are ready (utils.step_env, utils.py:394-418: `ray.wait` on the step futures), and an environment
     whose episode ends pulls the NEXT task by itself (SimEnv.step -> on_episode_end -> reset -> get_task_fn, tasks.py
@@ -76,6 +76,12 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
     services on the context's service lane) so that the device does not wait while the host serves requests; False: the
     blocking scheduler.  cap_min / cap: bounds of a chunk (defaults 2 / 4 pipelined, 4 / 32 blocking).
     prebuild: the host half of every task's set_scene is built ahead of its turn on a worker thread (tasks.ScenePrebuilder).
+    claim: None = this call runs every task of `tasks`.  A callable claim(k) -> up to k indices into `tasks` nobody else has
+    taken ([] when the set is used up) makes the queue a SHARED one -- distributed.SharedTaskCounter: several ranks pull from one
+    task set the way the reference's environments pull from one TaskLoader actor, a rank with long episodes simply takes fewer --
+    and this call runs the tasks it gets; the statistics then cover those (`task_indices`, ascending).  claim_first: how many tasks
+    to take up front (default: one per slot; a sharded run passes its fair share, so that the first rank to arrive does not empty
+    the set); afterwards a sixteenth of the slots at a time.
     Returns run_episodes' dictionary (arrays ordered by task index) plus `scheduler` (launch statistics of the run);
     `simulation_steps` excludes the step inside every set_scene, as the lock-step path's count does."""
     from collections import deque
@@ -89,7 +95,7 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
     sim = env.sim
     slots = list(range(min(sim.n_envs, len(tasks))))
     env.open_slots(slots)
-    queue = deque(enumerate(tasks))
+    queue = deque(range(len(tasks))) if claim is None else deque()
     records = {}
 
     batch_invariant = all(getattr(net, "_hip", None) is not None for net in policy.value_nets.values())
@@ -99,12 +105,25 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
                       "size): one forward per episode, so that results do not depend on which slots are ready together")
 
     from .tasks import ScenePrebuilder
-    scenes = ScenePrebuilder(tasks, ahead=max(8, len(slots) // 4)) if prebuild else None
+    scenes = ScenePrebuilder(tasks, ahead=max(8, len(slots) // 4), order=None if claim is None else []) if prebuild else None
+
+    def refill(k):
+        got = [int(i) for i in claim(k)]
+        queue.extend(got)
+        if scenes is not None:
+            scenes.expect(got)
+
+    if claim is not None:      # one task per slot to start with; afterwards in small chunks, so that the last tasks of the set
+        refill(len(slots) if claim_first is None else max(0, min(len(slots), int(claim_first))))   # do not pile up on one rank
 
     def slot_program(slot):
-        while queue:
-            ti, task = queue.popleft()
-            records[ti] = yield from env.episode_program(slot, task, max_actions=max_steps,
+        while True:
+            if not queue and claim is not None:
+                refill(max(1, len(slots) // 16))
+            if not queue:
+                return
+            ti = queue.popleft()
+            records[ti] = yield from env.episode_program(slot, tasks[ti], max_actions=max_steps,
                                                          prebuilt=scenes.get(ti) if scenes is not None else None)
 
     def observe(reqs):
@@ -141,26 +160,30 @@ def run_tasks(policy, env, tasks, fold=True, cap_min=None, cap=None, max_steps=N
     finally:
         if scenes is not None:
             scenes.close()
-    n = len(tasks)
-    flat = np.array([float(t["flatten_area"]) for t in tasks])
-    lengths = np.array([len(records[i]["actions"]) for i in range(n)], int)
+    done = sorted(records)                   # every task of `tasks`, or the ones this call claimed
+    n = len(done)
+    flat = np.array([float(tasks[i]["flatten_area"]) for i in done])
+    lengths = np.array([len(records[i]["actions"]) for i in done], int)
     steps = int(lengths.max()) if n else 0
-    trace = np.stack([[records[i]["coverage"][min(k, lengths[i])] for i in range(n)] for k in range(steps + 1)]) / flat
+    trace = np.stack([[records[i]["coverage"][min(k, lengths[j])] for j, i in enumerate(done)] for k in range(steps + 1)]) / flat \
+        if n else np.zeros((1, 0))
     counts = {a: 0 for a in env.actions}
-    for i in range(n):
+    for i in done:
         for a in records[i]["actions"]:
             if a is not None:
                 counts[a] += 1
     init, final = trace[0], trace[-1]
+    nanmean = lambda v: float(np.mean(v)) if len(v) else float("nan")   # noqa: E731  (a rank that claimed nothing)
     return {
+        "task_indices": np.array(done, int),
         "init_coverage": init, "final_coverage": final, "best_coverage": trace.max(axis=0),
         "episode_delta_coverage": final - init, "episode_length": lengths,
         "delta_coverage_steps": np.diff(trace, axis=0), "coverage_steps": trace, "action_primitive_counts": counts,
         "simulation_steps": int(env.prim.sim_steps - env.unpaid_steps), "scheduler": dict(getattr(env.prim, "sched_stats", {})),
-        "mean": {"init_coverage": float(init.mean()), "final_coverage": float(final.mean()),
-                 "best_coverage": float(trace.max(axis=0).mean()), "episode_delta_coverage": float((final - init).mean()),
-                 "episode_length": float(lengths.mean())},
-        "records": [records[i] for i in range(n)],   # per episode: what SimEnv logs per step (taskio.save_replay stores it)
+        "mean": {"init_coverage": nanmean(init), "final_coverage": nanmean(final),
+                 "best_coverage": nanmean(trace.max(axis=0)), "episode_delta_coverage": nanmean(final - init),
+                 "episode_length": nanmean(lengths)},
+        "records": [records[i] for i in done],   # per episode: what SimEnv logs per step (taskio.save_replay stores it)
     }
 
 
@@ -211,6 +234,34 @@ def merge_rank_statistics(stats, per_rank, device=None):
     return out
 
 
+def merge_shared_statistics(stats, n_tasks, device=None):
+    """The sharded run with ONE task queue for all ranks (run_tasks(claim=SharedTaskCounter.claim)): every rank writes the
+    coverages of the tasks it ran at their task indices into vectors of the set's length, zeros elsewhere, and one SUM
+    all-reduce gives every rank the whole set; a third vector counts who ran what -- every task exactly once, or the run is
+    refused -- and tells how many tasks each rank ended up with."""
+    from . import distributed as fdist
+
+    rank, _, world = fdist.init_from_env()
+    idx = np.asarray(stats["task_indices"], int)
+    buf = np.zeros((3 + world, n_tasks))
+    buf[0, idx], buf[1, idx], buf[2, idx] = stats["init_coverage"], stats["final_coverage"], 1.0
+    buf[3 + rank, idx] = 1.0
+    tot = fdist.sum_over_ranks(np.concatenate([buf.ravel(), [float(stats["simulation_steps"])]]), device=device)
+    steps, buf = tot[-1], tot[:-1].reshape(3 + world, n_tasks)
+    if not np.array_equal(buf[2], np.ones(n_tasks)):
+        raise RuntimeError(f"shared task queue: tasks run {sorted(set(buf[2].astype(int)))} times (expected exactly once each)")
+    init, final = buf[0], buf[1]
+    out = {"gpus": world, "episodes": int(n_tasks), "init_coverage": float(init.mean()), "final_coverage": float(final.mean()),
+           "episode_delta_coverage": float((final - init).mean()), "simulation_steps": int(steps),
+           "schedule": "one shared task queue (atomic counter on the process group's store)",
+           "tasks_per_rank": [int(v) for v in buf[3:].sum(axis=1)],
+           "note": "coverages and steps over all ranks; best_coverage / episode_length / action counts are rank 0's"}
+    bad = int((~np.isfinite(init)).sum() + (~np.isfinite(final)).sum())
+    if bad:
+        out["non_finite_coverages"] = bad
+    return out
+
+
 def main(argv=None):
     """python -m flingbot_amd.evaluate --tasks set.npz [--weights flingbot.pth] [--slots 96] [--episode-length 10] [--gpus N]
 
@@ -233,6 +284,9 @@ def main(argv=None):
                          ".npz (taskio.save_replay; rank r of a multi-GPU run writes REPLAY.rank<r>.npz)")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--static-blocks", action="store_true",
+                    help="several ranks: cut the task set into one contiguous block per rank (rounds 1-5) instead of letting every rank "
+                         "pull from one shared queue like the reference's environments pull from one TaskLoader")
     a = ap.parse_args(argv)
     if a.device is not None and (a.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
         ap.error("--device names ONE HIP device: with --gpus N (or under torch.distributed.run) every rank takes LOCAL_RANK")
@@ -248,7 +302,8 @@ def main(argv=None):
     device = local_rank if a.device is None else a.device
     tasks = taskio.TaskLoader(a.tasks, repeat=False).all_tasks()
     per_rank = (len(tasks) + world - 1) // world
-    mine = tasks[rank * per_rank:(rank + 1) * per_rank]
+    shared = world > 1 and not a.static_blocks
+    mine = tasks if shared else tasks[rank * per_rank:(rank + 1) * per_rank]
     dev = f"cuda:{device}"
     torch.cuda.set_device(device)
     ctx = fsim.FlingSim(n_envs=max(1, min(a.slots, len(mine))), device=device, solver=0)
@@ -274,7 +329,15 @@ def main(argv=None):
     if a.weights:
         ckpt = torch.load(a.weights, map_location=dev)
         policy.load_state_dict(ckpt.get("net", ckpt))          # utils.py:116-118 stores the module under 'net'
-    if mine:
+    if shared:
+        # one queue for all ranks (distributed.SharedTaskCounter: an atomic counter on the process group's store): whoever has a
+        # free slot takes the next task, exactly what utils.setup_envs' shared TaskLoader actor does for the reference's workers
+        counter = fdist.SharedTaskCounter(len(tasks), key=os.path.basename(a.tasks))
+        stats = run_tasks(policy, env, tasks, claim=counter.claim, claim_first=per_rank)
+        if a.dump and len(stats["task_indices"]):
+            path = a.dump[:-4] + f".rank{rank}.npz" if a.dump.endswith(".npz") else a.dump + f".rank{rank}"
+            taskio.save_replay(path, stats["records"], [tasks[i] for i in stats["task_indices"]], episode_ids=stats["task_indices"])
+    elif mine:
         stats = run_tasks(policy, env, mine)
         if a.dump:
             path = a.dump if world == 1 else a.dump[:-4] + f".rank{rank}.npz" if a.dump.endswith(".npz") else a.dump + f".rank{rank}"
@@ -289,7 +352,7 @@ def main(argv=None):
     out = {"tasks": len(tasks), **stats["mean"], "action_primitive_counts": stats["action_primitive_counts"],
            "simulation_steps": stats["simulation_steps"]}
     if world > 1:
-        out.update(merge_rank_statistics(stats, per_rank, device=dev))
+        out.update(merge_shared_statistics(stats, len(tasks), device=dev) if shared else merge_rank_statistics(stats, per_rank, device=dev))
         out.update({k: census[k] for k in ("ranks_seen", "distinct_devices", "backend", "collective_library")})
         fdist.barrier()
     if rank == 0:

@@ -149,14 +149,15 @@ REPLAY_SCALARS = ("preaction_coverage", "postaction_coverage", "rewards", "is_te
                   "task_difficulty", "max_coverage", "init_coverage", "cloth_mass")
 
 
-def save_replay(path, records, tasks, first_episode=0):
+def save_replay(path, records, tasks, first_episode=0, episode_ids=None):
     """What SimEnv.on_episode_end -> Memory.dump (simEnv.py:783-805, learning/Memory.py:106-165) leaves of an EVALUATION
     episode: one entry per action, keyed like the reference's HDF5 groups -- '%09d_step%02d', the episode's last one with
     '_last' -- holding the scalars SimEnv.step / log_step_stats record (simEnv.py:433-452,477-503) and utils.collect_stats
     reads (utils.py:186-330): coverage before / after the action, reward, termination, the primitive, the task's get_stats().
     Not stored: observations, action masks and value maps -- the training set of run_sim.py's optimizer, out of scope here
     (DESIGN.md 8).  records: evaluate.run_tasks(...)['records']; tasks: the tasks they ran on (Task objects or generator
-    dictionaries); one flat .npz, `keys` in the order the reference's file would list its groups."""
+    dictionaries); one flat .npz, `keys` in the order the reference's file would list its groups.  Episode numbers are
+    first_episode + position, or episode_ids[position] (a rank of a run with one shared task queue: the tasks' own indices)."""
     keys, data = [], {"format": np.array(REPLAY_FORMAT)}
     for i, (rec, task) in enumerate(zip(records, tasks)):
         n = len(rec["actions"])
@@ -164,7 +165,8 @@ def save_replay(path, records, tasks, first_episode=0):
             "task_name": str(i), "cloth_mass": task["cloth_mass"], "max_coverage": task["flatten_area"],
             "task_difficulty": task["task_difficulty"], "init_coverage": task["initial_coverage"]}
         for k in range(n):
-            key = f"{first_episode + i:09d}_step{k:02d}" + ("_last" if k == n - 1 else "")
+            ep = first_episode + i if episode_ids is None else int(episode_ids[i])
+            key = f"{ep:09d}_step{k:02d}" + ("_last" if k == n - 1 else "")
             keys.append(key)
             row = {"preaction_coverage": rec["preaction_coverage"][k], "postaction_coverage": rec["coverage"][k + 1],
                    "rewards": rec["rewards"][k], "is_terminal": float(k == n - 1),

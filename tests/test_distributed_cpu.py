@@ -538,9 +538,10 @@ if os.environ.get("FS_EVAL_STUB") and os.environ.get("WORLD_SIZE"):
     open(os.path.join(os.environ["FS_OUT"], f"pid{RANK}"), "w").write(str(os.getpid()))
     torch.cuda.is_available = lambda: False
     torch.cuda.set_device = lambda d: None
-    _init, _gather = fdist.init_from_env, fdist.gather_rewards
+    _init, _gather, _sum = fdist.init_from_env, fdist.gather_rewards, fdist.sum_over_ranks
     fdist.init_from_env = lambda backend=None: _init("gloo")
     fdist.gather_rewards = lambda r, device=None: _gather(r, None)
+    fdist.sum_over_ranks = lambda a, device=None: _sum(a, None)
 
     class Ctx:
         def __init__(self, n_envs=1, device=0, solver=0, **kw):
@@ -556,7 +557,7 @@ if os.environ.get("FS_EVAL_STUB") and os.environ.get("WORLD_SIZE"):
     class Policy:
         def __init__(self, **kw):
             pass
-    def run_tasks(policy, env, tasks):
+    def run_tasks(policy, env, tasks, claim=None, claim_first=None):
         if str(RANK) == os.environ.get("FS_FAIL_RANK"):
             time.sleep(1.0)                    # the other ranks are inside the gather by now
             raise RuntimeError(f"injected failure on rank {RANK}")
@@ -564,11 +565,24 @@ if os.environ.get("FS_EVAL_STUB") and os.environ.get("WORLD_SIZE"):
             import signal
             time.sleep(1.0)
             os.kill(os.getpid(), signal.SIGKILL)
-        init = np.array([float(t["initial_coverage"]) / float(t["flatten_area"]) for t in tasks], np.float32)
+        if claim is None:
+            idx = list(range(len(tasks)))
+        else:   # the shared queue: one task per slot (at most the fair share) up front, then one at a time; rank 0 is 4x as fast
+            idx = list(claim(min(env.sim.n_envs, claim_first if claim_first is not None else env.sim.n_envs)))
+            while True:
+                time.sleep(0.01 if RANK == 0 else 0.04)
+                more = claim(1)
+                if not more:
+                    break
+                idx += more
+            idx.sort()
+        sel = [tasks[i] for i in idx]
+        init = np.array([float(t["initial_coverage"]) / float(t["flatten_area"]) for t in sel], np.float32)
         final = init + np.float32(0.125)
-        return {"init_coverage": init, "final_coverage": final, "simulation_steps": 10 * len(tasks),
-                "action_primitive_counts": {"fling": 3 * len(tasks)},
-                "mean": {"init_coverage": float(init.mean()), "final_coverage": float(final.mean()), "best_coverage": float(final.mean()),
+        mean = lambda v: float(v.mean()) if len(v) else float("nan")
+        return {"init_coverage": init, "final_coverage": final, "simulation_steps": 10 * len(sel), "task_indices": np.array(idx, int),
+                "action_primitive_counts": {"fling": 3 * len(sel)}, "records": [],
+                "mean": {"init_coverage": mean(init), "final_coverage": mean(final), "best_coverage": mean(final),
                          "episode_delta_coverage": 0.125, "episode_length": 3.0}}
     fsim.FlingSim, fenv.BatchedFlingEnv, nets.MaximumValuePolicy, evaluate.run_tasks = Ctx, Env, Policy, run_tasks
 """
@@ -586,7 +600,7 @@ def _write_task_set(path, n):
     assert taskio.save_tasks(path, tasks) == n
 
 
-def _run_evaluate(tmp_path, extra_env, n_tasks=13, gpus=8):
+def _run_evaluate(tmp_path, extra_env, n_tasks=13, gpus=8, extra_args=()):
     (tmp_path / "site").mkdir(exist_ok=True)
     (tmp_path / "site" / "sitecustomize.py").write_text(EVAL_SITECUSTOMIZE)
     tasks = str(tmp_path / "set.npz")
@@ -595,7 +609,7 @@ def _run_evaluate(tmp_path, extra_env, n_tasks=13, gpus=8):
     env.update(PYTHONPATH=os.pathsep.join([str(tmp_path / "site"), ROOT, env.get("PYTHONPATH", "")]), FS_ROOT=ROOT,
                FS_OUT=str(tmp_path), FS_EVAL_STUB="1", **extra_env)
     t0 = time.time()
-    out = subprocess.run([sys.executable, "-m", "flingbot_amd.evaluate", "--tasks", tasks, "--gpus", str(gpus), "--slots", "4"],
+    out = subprocess.run([sys.executable, "-m", "flingbot_amd.evaluate", "--tasks", tasks, "--gpus", str(gpus), "--slots", "4", *extra_args],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     pids = [int(open(tmp_path / f"pid{r}").read()) for r in range(gpus) if (tmp_path / f"pid{r}").exists()]
     return out, pids, time.time() - t0
@@ -615,11 +629,34 @@ def _alive(pid):
         return False
 
 
-def test_evaluate_command_eight_ranks_end_to_end_uneven_blocks(tmp_path):
-    """13 tasks over 8 ranks: blocks of 2, rank 6 gets one, rank 7 none -- and the summary still covers exactly the 13."""
+def test_evaluate_command_shared_task_queue_across_ranks(tmp_path):
+    """`evaluate --gpus 4` the way the reference runs its workers: ONE task queue (utils.setup_envs' TaskLoader actor; here an
+    atomic counter on the process group's store), every rank takes a task whenever it has a free slot.  40 tasks, 4 ranks of 4
+    slots, rank 0 four times as fast as the others: every task runs exactly once, the summary covers all 40, rank 0 ends up
+    with clearly more than its fair share of 10 -- and with 13 tasks over 8 ranks nobody is left waiting for a rank's block."""
     import json
 
-    out, pids, _ = _run_evaluate(tmp_path, {})
+    out, pids, _ = _run_evaluate(tmp_path, {}, n_tasks=40, gpus=4)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    init = np.array([0.01 * (i + 1) / 0.5 for i in range(40)], np.float32)
+    assert rec["gpus"] == 4 and rec["episodes"] == 40 and rec["simulation_steps"] == 400 and "shared task queue" in rec["schedule"]
+    assert sum(rec["tasks_per_rank"]) == 40 and rec["tasks_per_rank"][0] >= 14 and min(rec["tasks_per_rank"]) >= 4, rec["tasks_per_rank"]
+    assert rec["init_coverage"] == pytest.approx(float(init.mean()), rel=1e-6)
+    assert rec["final_coverage"] == pytest.approx(float((init + np.float32(0.125)).mean()), rel=1e-6)
+    assert not any(_alive(p) for p in pids)
+    out, pids, _ = _run_evaluate(tmp_path, {}, n_tasks=13, gpus=8)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["episodes"] == 13 and sum(rec["tasks_per_rank"]) == 13 and rec["simulation_steps"] == 130
+    assert rec["ranks_seen"] == 8 and rec["distinct_devices"] == 8
+
+
+def test_evaluate_command_eight_ranks_end_to_end_uneven_blocks(tmp_path):
+    """--static-blocks, 13 tasks over 8 ranks: blocks of 2, rank 6 gets one, rank 7 none -- and the summary still covers exactly the 13."""
+    import json
+
+    out, pids, _ = _run_evaluate(tmp_path, {}, extra_args=("--static-blocks",))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and len(pids) == 8                 # rank 0 prints, once

@@ -148,6 +148,23 @@ def test_async_task_loop_equals_lockstep_loop(gpu_required, actions):
         ctx.close()
     ref = results[0]
     assert ref["coverage_steps"].shape[0] >= 2 and sum(ref["action_primitive_counts"].values()) > 0
+    # the SHARED task queue of a multi-rank run (distributed.SharedTaskCounter; here two "ranks" one after the other on one counter):
+    # the first stops claiming after three tasks, the second takes what is left -- every task exactly once, and every task's
+    # coverage trace is the lock-step run's, whichever call ran it
+    from flingbot_amd import distributed as fdist
+    counter, taken = fdist.SharedTaskCounter(n), []
+    limited = lambda k: counter.claim(min(k, max(0, 3 - len(counter.claimed))))   # noqa: E731
+    for claim in (limited, counter.claim):
+        ctx = fsim.FlingSim(n_envs=2, solver=0)
+        env = BatchedFlingEnv(ctx, action_primitives=actions, image_dim=128, episode_length=3)
+        part = run_tasks(_policy(env), env, tasks, claim=claim, claim_first=2)
+        ctx.close()
+        taken.append(part["task_indices"].tolist())
+        for col, ti in enumerate(part["task_indices"]):
+            steps = int(part["episode_length"][col])
+            assert steps == int(ref["episode_length"][ti])
+            assert np.array_equal(part["coverage_steps"][:steps + 1, col], ref["coverage_steps"][:steps + 1, ti]), ti
+    assert len(taken[0]) == 3 and sorted(taken[0] + taken[1]) == list(range(n))
     for other in results[1:]:
         assert np.array_equal(ref["coverage_steps"], other["coverage_steps"])
         assert np.array_equal(ref["episode_length"], other["episode_length"])
