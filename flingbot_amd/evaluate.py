@@ -267,8 +267,9 @@ def main(argv=None):
 
     run_sim.py's evaluation (run_sim.py:37-109 with --eval: fling policy, 12 rotations x 8 scales, obs_dim 64) on a task
     set converted by scripts/convert_tasks_hdf5.py; prints the reference's summary statistics as one JSON line.
-    --gpus N > 1 (or a launch under torch.distributed.run): one process per GPU, the task set cut into contiguous blocks
-    (run_episodes_sharded), per-episode coverages gathered over RCCL; rank 0 prints the statistics of ALL episodes."""
+    --gpus N > 1 (or a launch under torch.distributed.run): one process per GPU, all ranks pulling from ONE task queue
+    (distributed.SharedTaskCounter; --static-blocks: one contiguous block per rank), per-episode coverages merged over RCCL;
+    rank 0 prints the statistics of ALL episodes."""
     import argparse
     import json
     import os
