@@ -58,6 +58,7 @@ struct Mapping {
     std::string key;
     int fd = -1;
     Table *tab = nullptr;
+    bool registered = false;  // this process asked to be listed (fs_tenants_register) and has not left since
 };
 Mapping g_map[4];  // a process rarely drives more than one device through the module; four is plenty
 std::mutex g_map_mutex;  // (ctypes callers may come from several threads; the table itself is guarded by flock)
@@ -206,6 +207,7 @@ extern "C" int fs_tenants_register(const char *device_key) {
     } else {
         mine->start = proc_start_time(me);
     }
+    m->registered = true;
     flock(m->fd, LOCK_UN);
     return n;
 }
@@ -215,6 +217,7 @@ extern "C" int fs_tenants_unregister(const char *device_key) {
     if (!m) return FS_ERR_STATE;
     const int me = (int)getpid();
     flock(m->fd, LOCK_EX);
+    m->registered = false;
     for (Slot &s : m->tab->slot)
         if (s.pid == me) {
             s.pid = 0;
@@ -231,6 +234,14 @@ extern "C" int fs_tenants_count(const char *device_key, int prune) {
         int n = 0;
         for (const Slot &s : m->tab->slot) n += s.pid > 0 ? 1 : 0;
         return n;
+    }
+    if (prune > 0 && m->registered) {
+        // self-heal: a tenant whose own entry has gone (a neighbour that could not see this pid -- another pid namespace on a
+        // shared /dev/shm -- pruned it, or somebody reset the file) lists itself again before it counts
+        const int me = (int)getpid();
+        bool listed = false;
+        for (const Slot &s : m->tab->slot) listed = listed || s.pid == me;
+        if (!listed) (void)fs_tenants_register(device_key);
     }
     return count_live(m, prune != 0);
 }
