@@ -6,7 +6,8 @@ container (/root/reference is read-only and never travels to the GPU box; only t
 Sources:  environment/flex_utils.py get_current_covered_area (stubs for pyflex, cv2),
           oracle/_ref/camera_ref  (compiled from the reference's PyFlex/core/maths.h by oracle/Makefile),
           oracle/_ref/sphere_ref  (compiled from the reference's PyFlex/core/mesh.cpp, same Makefile),
-          learning/nets.py (stubs for cv2, ray), environment/utils.py (stubs for cv2, trimesh, ...).
+          learning/nets.py (stubs for cv2, ray), environment/utils.py (stubs for cv2, trimesh, ...),
+          utils.py collect_stats run over an in-memory stand-in of the replay buffer's HDF5 groups (`replay`: replay_golden.npz).
 """
 import json
 import os
