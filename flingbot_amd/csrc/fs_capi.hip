@@ -808,28 +808,28 @@ extern "C" int fs_get_edges(fs_ctx *ctx, int env, int *out, int n_ints) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !out) return FS_ERR_ARG;
     CHECK_LEN(n_ints, 2 * e->host.m);
-    memcpy(out, e->host.springs.data(), size_t(8) * e->host.m);
+    if (e->host.m > 0) memcpy(out, e->host.springs.data(), size_t(8) * e->host.m);  // (a 1 x 1 cloth has none: no null source)
     return FS_OK;
 }
 extern "C" int fs_get_faces(fs_ctx *ctx, int env, int *out, int n_ints) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !out) return FS_ERR_ARG;
     CHECK_LEN(n_ints, 3 * e->host.t);
-    memcpy(out, e->host.tris.data(), size_t(12) * e->host.t);
+    if (e->host.t > 0) memcpy(out, e->host.tris.data(), size_t(12) * e->host.t);  // (a 1 x 1 cloth has none: no null source)
     return FS_OK;
 }
 extern "C" int fs_get_spring_lengths(fs_ctx *ctx, int env, float *out, int n_floats) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !out) return FS_ERR_ARG;
     CHECK_LEN(n_floats, e->host.m);
-    memcpy(out, e->host.spring_len.data(), size_t(4) * e->host.m);
+    if (e->host.m > 0) memcpy(out, e->host.spring_len.data(), size_t(4) * e->host.m);  // (a 1 x 1 cloth has none: no null source)
     return FS_OK;
 }
 extern "C" int fs_get_spring_stiffness(fs_ctx *ctx, int env, float *out, int n_floats) {
     FsEnv *e = get_env(ctx, env);
     if (!e || !out) return FS_ERR_ARG;
     CHECK_LEN(n_floats, e->host.m);
-    memcpy(out, e->host.spring_k.data(), size_t(4) * e->host.m);
+    if (e->host.m > 0) memcpy(out, e->host.spring_k.data(), size_t(4) * e->host.m);  // (a 1 x 1 cloth has none: no null source)
     return FS_OK;
 }
 extern "C" int fs_get_params(fs_ctx *ctx, int env, float *o, int n_floats) {

@@ -84,7 +84,7 @@ extern "C" int fs_host_scene_copy(const fs_host_scene *h, int what, void *out, i
         default: fs_set_error("unknown scene array id"); return FS_ERR_ARG;
     }
     if ((size_t)n_elems < count) { fs_set_error("buffer too small"); return FS_ERR_ARG; }
-    memcpy(out, src, count * 4);
+    if (count) memcpy(out, src, count * 4);   // (an empty array -- the springs of a 1 x 1 cloth -- has no data pointer to copy from)
     return FS_OK;
 }
 

@@ -25,8 +25,8 @@ def _cpu_has_fma():
 
 def oracle_lib_path():
     """liboracle_fma.so (fmaf inlined as the hardware instruction) when this CPU has FMA, else the libm-fmaf build.
-    Both give the same bits."""
-    return os.path.join(_HERE, "liboracle_fma.so" if _cpu_has_fma() else "liboracle.so")
+    Both give the same bits.  FLINGSIM_ORACLE_LIB overrides (scripts/host_sanitizers.sh: an ASan / UBSan build of the same source)."""
+    return os.environ.get("FLINGSIM_ORACLE_LIB") or os.path.join(_HERE, "liboracle_fma.so" if _cpu_has_fma() else "liboracle.so")
 
 
 # bounding builds of the same step (oracle/Makefile): plain IEEE arithmetic, and each arithmetic choice alone.  Tests use
