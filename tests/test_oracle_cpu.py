@@ -1164,3 +1164,73 @@ def test_prebuilt_scenes_host_side():
     finally:
         pre.close()
     assert not pre.futures
+    # a queue that learns its tasks as it goes (evaluate.run_tasks with a shared counter across ranks): nothing is built until the
+    # queue says what it expects, then in THAT order, and a task it never announced is built on the spot
+    pre = ftasks.ScenePrebuilder(tasks, ahead=2, order=[])
+    try:
+        assert not pre.futures
+        pre.expect([4, 1])
+        assert set(pre.futures) == {4, 1}
+        pre.expect([0])
+        assert set(pre.futures) == {4, 1}                     # `ahead` = 2 scenes beyond the ones handed out
+        for i in (4, 1, 3, 0):
+            scene = pre.get(i)
+            cnt = [C.c_int(0) for _ in range(4)]
+            assert lib.fs_host_scene_counts(scene.take(), *[C.byref(c) for c in cnt]) == 0
+            assert cnt[0].value == tasks[i]["cloth_size"][0] * tasks[i]["cloth_size"][1]
+            scene.free()
+    finally:
+        pre.close()
+    assert not pre.futures
+
+
+def test_run_tasks_shared_claim_logic_on_the_oracle():
+    """evaluate.run_tasks with claim= (the shared task queue of a multi-rank evaluation, distributed.SharedTaskCounter) without a
+    GPU: the scheduler runs on the oracle-backed stand-in, the environment's episode program is a two-request stub.  Two calls
+    share one counter -- the first stops claiming after four tasks -- and together they run every task exactly once; the up-front
+    claim respects claim_first, later claims come a sixteenth of the slots (here: one) at a time; a call that gets nothing returns
+    empty statistics instead of failing."""
+    from fling_helpers import OracleBatch, load_fling_golden
+    from flingbot_amd import distributed as fdist, evaluate
+    from flingbot_amd.primitives import FlingPrimitives
+
+    g = load_fling_golden()
+    n_tasks, slots = 9, 2
+    tasks = [{"flatten_area": 0.5 + 0.01 * i, "mesh_verts": np.zeros(0)} for i in range(n_tasks)]
+    counter, asked = fdist.SharedTaskCounter(n_tasks), []
+
+    class Env:
+        actions, device = ["fling"], None
+        unpaid_steps = 0
+
+        def __init__(self):
+            self.sim = OracleBatch(slots, g["scene_params"], g["init_pos"])
+            self.sim.n_envs = slots
+            self.prim = FlingPrimitives(self.sim, range(slots))
+
+        def open_slots(self, s):
+            pass
+
+        def episode_program(self, slot, task, max_actions=None, prebuilt=None):
+            yield ("step", 1 + int(round(100 * (task["flatten_area"] - 0.5))) % 3)
+            cov = yield ("coverage",)
+            return {"coverage": [0.1, float(task["flatten_area"]) / 2], "actions": ["fling"], "rewards": [0.0], "preaction_coverage": [0.1]}
+
+    class Policy:
+        value_nets = {}
+
+    def limited(k):
+        k = min(k, max(0, 4 - len(counter.claimed)))
+        asked.append(k)
+        return counter.claim(k)
+
+    parts = []
+    for claim in (limited, counter.claim, counter.claim):
+        env = Env()
+        env.sim.coverage = lambda: np.zeros(slots)
+        parts.append(evaluate.run_tasks(Policy(), env, tasks, fold=False, pipeline=False, prebuild=False, claim=claim, claim_first=2))
+    assert asked[0] == 2 and set(asked[1:]) <= {0, 1}                       # fair share up front, then one at a time
+    got = [p["task_indices"].tolist() for p in parts]
+    assert got[0] == [0, 1, 2, 3] and got[1] == [4, 5, 6, 7, 8] and got[2] == []
+    assert np.allclose(parts[1]["final_coverage"], 0.5) and parts[1]["action_primitive_counts"] == {"fling": 5}
+    assert parts[2]["records"] == [] and np.isnan(parts[2]["mean"]["final_coverage"]) and parts[2]["coverage_steps"].shape[1] == 0
