@@ -36,13 +36,13 @@ def worker(mode, steps, start_at):
     import scenarios as sc
 
     pyflex.init(True, False, 720, 720)
-    dim = 32 if mode == "c1" else 64
+    dim = 32 if mode == "c1" else (96 if mode == "picker96" else 64)   # picker96: a cloth the fused kernel cannot take (not in measure())
     e_f, e_i = np.zeros(0, np.float32), np.zeros(0, np.int32)
     pyflex.set_scene(scene_idx=0, scene_params=sc.survey_params(dim), vertices=e_f, stretch_edges=e_i, bend_edges=e_i,
                      shear_edges=e_i, faces=e_i, thread_idx=0)
     pyflex.step()
     pyflex.set_positions(sc.set_to_flatten_positions(dim, dim).flatten())
-    if mode == "picker":
+    if mode in ("picker", "picker96"):
         for c in ((0.04, 0.1, 0.0), (-0.04, 0.1, 0.0)):
             pyflex.add_sphere(0.02, np.array(c), np.array([1., 0., 0., 0.]))
     pyflex.step()
