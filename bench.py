@@ -801,7 +801,7 @@ def run_rank(args):
                                f"{args.preroll + W2}); no checker or other host work runs during them",
                      "ms_per_step": el2 / K2 * 1e3, "gpu_ms_per_step": k2_ms / K2,
                      "solver": "stream (AUTO)" if form2 in (fsim.FS_FORM_STREAM_EAGER, fsim.FS_FORM_STREAM_CODED, fsim.FS_FORM_STREAM_ELL,
-                                                            fsim.FS_FORM_STREAM_GRID, fsim.FS_FORM_STREAM_GRIDL) else "fused (AUTO)",
+                                                            fsim.FS_FORM_STREAM_GRID, fsim.FS_FORM_STREAM_GRIDL, fsim.FS_FORM_STREAM_GRIDL_TP) else "fused (AUTO)",
                      "kernel_form": int(form2), "concurrent_launch_chains": int(ctx2.last_stream_groups()),
                      "calls": "one fs_step call per frame (as pyflex.step() is called); frames batched into one call run ~5 % faster",
                      "roofline_frac_equivalent": BYTES_PER_STEP * E2 / (k2_ms / K2 * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -92,6 +92,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     for (int id : ids) launch_particles += (size_t)ctx->envs[id].host.n;
     bool find_stencil = true;  // every episode a grid cloth whose SelfCollideFilter test is the 8-neighbour stencil (find mode 4)
     for (int id : ids) find_stencil = find_stencil && ctx->envs[id].dev.find_mode == 4;
+    const bool gridl_halvable_all = gridl_posk;   // (every episode tether-free, before the launch-size rule makes gridl_posk mean "the POSK form")
     static const int posk_env = [] { const char *v = getenv("FLINGSIM_GRIDL_POSK"); return v ? atoi(v) : 0; }();  // developer: 1 always, -1 never
     gridl_posk = gridl_posk && (posk_env > 0 || (posk_env == 0 && launch_particles <= (size_t)4 * 1024 * 64));  // one round of 4 waves per SIMD at most (see fs_k_iterate_gridl)
     hipStream_t st = ctx->stream;
@@ -170,6 +171,13 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     auto iter_kernel = eager ? fs_k_iterate_eager<false> : (coded ? fs_k_iterate<true> : fs_k_iterate<false>);
     if (grid_form) iter_kernel = fs_k_iterate_grid;
     if (gridl_form) iter_kernel = gridl_posk ? fs_k_iterate_gridl<true> : fs_k_iterate_gridl<false>;
+    // large launches of tether-free cloths: the throughput instantiation (fs_stream_kernels.h TP; FLINGSIM_GRIDL_TP=0 keeps the general form)
+    const char *tp_str = getenv("FLINGSIM_GRIDL_TP");   // (read per call: the tests switch it inside one process)
+    const int tp_env = tp_str ? atoi(tp_str) : 1;
+    if (gridl_form && !gridl_posk && gridl_halvable_all && tp_env > 0) {
+        iter_kernel = fs_k_iterate_gridl_tp;
+        ctx->last_form = FS_FORM_STREAM_GRIDL_TP;
+    }
     const int flip_end = iters & 1;
     // the frame's launch sequence, issued for every chain in turn (interleaved from this thread: one host thread per chain was
     // measured too and is no faster -- the host is not the limit at two or three chains)

@@ -778,6 +778,101 @@ __global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl(const FsEnvDev *en
 #endif
 }
 
+// THROUGHPUT form of the grid-L iteration (round 6, EXPERIMENTS R6.4; launches above 262 144 particles of tether-free cloths).
+// Such a launch is VALU-bound (0.19 VALU-active per wave-cycle of a ceiling of 0.2), not one wave's critical path, so the
+// trade-offs of fs_iterate_particle_gridl turn around: (1) the springs are gathered and evaluated in two halves of six -- half
+// the live registers, more waves per SIMD to hide the second round trip; (2) equal masses and positive stiffnesses
+// (wave-uniform check per half) leave a spring nothing to decide but `length > 0`: no out-of-grid test (a slot that leaves the
+// grid gathers the particle itself: length 0, inactive by itself), the mass ratio folded into g64_kh = k / 2 -- fs_spring_fast;
+// a wavefront with a pinned particle among a half's neighbours takes fs_spring_bfm for that half.  An active spring performs
+// the same operations in the same order in either form, the accumulation order is the canonical slot order: same bits.
+__device__ __forceinline__ void fs_iterate_particle_gridl_tp(const FsEnvDev &E, const FsSlotSweeps &shape_set, int i, int sub, int flip) {
+    const FsParams &p = E.p;
+    const FsVec4 *src = flip ? E.xb : E.xa;
+    FsVec4 *dst = flip ? E.xa : E.xb;
+    constexpr int cdx[FS_G64_SLOTS] = FS_G64_DX_LIST, cdz[FS_G64_SLOTS] = FS_G64_DZ_LIST;
+    const unsigned un = (unsigned)E.n, ui = (unsigned)i;
+    FsVec4 xi = fs_ld4o(src, ui);
+    if (!(xi.w > 0.0f)) {
+        fs_st4o(dst, ui, xi);
+        return;
+    }
+    const int dimx = E.gp_dimx, dimz = E.gp_dimz;
+    const int iz = (int)__umulhi(ui, E.gp_magic), ix = i - iz * dimx;
+    FsAcc a = {0.0f, 0.0f, 0.0f, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        FsVec4 xj[6];
+        float L[6];
+        unsigned inb = 0u;
+        bool same = true;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int q = 6 * h + r;
+            const bool in = (unsigned)(ix + cdx[q]) < (unsigned)dimx && (unsigned)(iz + cdz[q]) < (unsigned)dimz;
+            inb |= (unsigned)in << r;
+            xj[r] = fs_ld4o(src, in ? (unsigned)(i + cdz[q] * dimx + cdx[q]) : ui);
+            L[r] = fs_ldo(E.g64_L, (unsigned)q * un + ui);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) same = same & (xj[r].w == xi.w);
+        if (__builtin_amdgcn_ballot_w64(!same) == 0ull) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) fs_spring_fast(a, xi.x, xi.y, xi.z, xj[r], L[r], E.g64_kh[6 * h + r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                fs_spring_bfm<true>(a, xi.x, xi.y, xi.z, xi.w, xj[r], L[r], E.gp_k[6 * h + r], (inb >> r) & 1u);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the second half's gathers stay behind the first half's arithmetic
+    }
+    const FsVec4 x0i = fs_ld4o(E.x0, ui);
+    const int ncw = fs_ldo(E.ncount, ui);
+    const int nc = ncw & FS_NCOUNT_MASK;
+    const unsigned shape_mask = (unsigned)ncw >> FS_SHAPE_MASK_SHIFT;
+    const float ri0 = xi.x - x0i.x, ri1 = xi.y - x0i.y, ri2 = xi.z - x0i.z;
+    const float restd = p.solidRestDistance, restd2 = restd * restd;
+    int cj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = k < nc ? fs_ldo(E.nlist, (unsigned)k * un + ui) : -1;
+        cj[k] = (c >= 0 && c < E.n) ? c : -1;
+    }
+    for (int q0 = 0; q0 < nc; q0 += 4) {
+        int cjn[4] = {-1, -1, -1, -1};
+        if (q0 + 4 < nc) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cjn[k] = q0 + 4 + k < nc ? fs_ldo(E.nlist, (unsigned)(q0 + 4 + k) * un + ui) : -1;
+        }
+        FsVec4 cx[4], c0[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned j = cj[k] < 0 ? ui : (unsigned)cj[k];
+            cx[k] = fs_ld4o(src, j);
+            c0[k] = fs_ld4o(E.x0, j);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cj[k] >= 0)
+                fs_particle_contact(a, xi.x, xi.y, xi.z, xi.w, ri0, ri1, ri2, cx[k], cx[k].x - c0[k].x, cx[k].y - c0[k].y,
+                                    cx[k].z - c0[k].z, restd, restd2, p.particleFriction);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cj[k] = cjn[k];
+    }
+    fs_swept_shape_contacts(a, xi.x, xi.y, xi.z, ri0, ri1, ri2, p, shape_set, sub, shape_mask);
+    fs_apply(a, p.relaxationFactor, xi.x, xi.y, xi.z);
+    fs_st4o(dst, ui, xi);
+}
+__global__ __launch_bounds__(FS_TILE) void fs_k_iterate_gridl_tp(const FsEnvDev *envs, const FsSlotSweeps *shapes, const int *ids,
+                                                                 int sub, int flip, int gx, int ne) {
+    int bx, by;
+    if (!fs_stream_tile(gx, ne, bx, by)) return;
+    const FsEnvDev &E = envs[by];
+    if (E.slot_env < 0) return;  // retired slot
+    const int i = bx * FS_TILE + threadIdx.x;
+    if (i < E.n) fs_iterate_particle_gridl_tp(E, shapes[by], i, sub, flip);
+}
+
 // (A CONTACT-SORTED form was built and measured in round 2 as well: springs in id order, then accumulator, particle and first
 // candidate ids through LDS, the workgroup's 256 particles ordered by candidate-count class (ballots + a 4 x 4 table), thread t
 // finishing the t-th particle of that order, so that the lanes of a wave carry equal numbers of contacts -- on oracle states of

@@ -16,7 +16,7 @@ FS_SOLVER_FUSED_GENERIC, FS_SOLVER_STREAM_ELL, FS_SOLVER_FUSED_CODED, FS_SOLVER_
 FS_SOLVER_STREAM_SPLIT, FS_SOLVER_STREAM_MERGED, FS_SOLVER_COTENANT = 7, 8, 9
 # fs_last_kernel_form (white box): which kernel form the last solver launch ran
 (FS_FORM_FUSED_12, FS_FORM_FUSED_16, FS_FORM_FUSED_GENERIC, FS_FORM_STREAM_EAGER, FS_FORM_STREAM_CODED, FS_FORM_STREAM_ELL,
- FS_FORM_STREAM_GRID, FS_FORM_FUSED_GRID64, FS_FORM_STREAM_GRIDL) = range(1, 10)
+ FS_FORM_STREAM_GRID, FS_FORM_FUSED_GRID64, FS_FORM_STREAM_GRIDL, FS_FORM_STREAM_GRIDL_TP) = range(1, 11)
 
 _lib = None
 

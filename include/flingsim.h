@@ -166,6 +166,9 @@ int fs_get_last_shape_candidates(fs_ctx *ctx, int env, unsigned *masks);
 #define FS_FORM_STREAM_GRID 7    /* fs_k_iterate_grid: neighbour ids from the grid coordinates (large launches) */
 #define FS_FORM_STREAM_GRIDL 9   /* fs_k_iterate_gridl: canonical grid cloths, rest lengths from the per-particle table */
 #define FS_FORM_FUSED_GRID64 8   /* fs_k_fused_grid64: 64-wide grid cloths, packed two-particle springs, no adjacency */
+#define FS_FORM_STREAM_GRIDL_TP 10 /* fs_k_iterate_gridl_tp: the grid-L iteration's throughput form -- launches above 262 144 particles of
+                                      tether-free cloths (the evaluation loop at its real sizes): springs in two halves of six,
+                                      equal-mass fast path */
 int fs_last_kernel_form(const fs_ctx *ctx);
 /* white box: how the most recent streaming launch did its substep boundaries (finalize + predict + bucket sort): 0 = four
    kernels (launches of fewer than 16 episodes, cloths above 16384 particles), 1 = fs_k_boundary (one launch per boundary) */

@@ -22,6 +22,7 @@ on distinct-seed episodes, and sampled episodes are compared with the CPU oracle
     fs_k_iterate_eager    8 x 64x64 episodes, FS_SOLVER_STREAM_CODED
     fs_k_iterate_grid     112 x 64x64 distinct episodes, FS_SOLVER_STREAM_CODED
 """
+import os
 import threading
 
 import numpy as np
@@ -298,8 +299,9 @@ def test_streaming_concurrent_chains_bit_exact(gpu_required, n_envs, groups):
     from flingbot_amd import sim as fsim
 
     sample = sorted({0, 7, 8, 15, 16, n_envs // 2, n_envs - 1} & set(range(n_envs)))
-    _bench_batch(n_envs, fsim.FS_SOLVER_STREAM, 30, sample, fsim.FS_FORM_STREAM_GRIDL, groups=groups,
-                 expect_groups=groups if groups else 2)
+    # (130 x 4096 particles is above the 262 144 from which tether-free grid cloths take the throughput form of the iteration)
+    form = fsim.FS_FORM_STREAM_GRIDL_TP if n_envs * 4096 > 262144 else fsim.FS_FORM_STREAM_GRIDL
+    _bench_batch(n_envs, fsim.FS_SOLVER_STREAM, 30, sample, form, groups=groups, expect_groups=groups if groups else 2)
 
 
 def test_streaming_small_and_large_launch_forms_bit_exact(gpu_required):
@@ -402,3 +404,81 @@ def test_cotenant_solver_mode_chooses_per_launch(gpu_required):
     ctx.step(1)                                    # a mixed list: falls back to AUTO as a whole, never an error
     assert ctx.last_kernel_form() not in fused
     ctx.close()
+
+
+def test_gridl_throughput_form_bit_exact_with_pins_spheres_and_mixed_sizes(gpu_required):
+    """fs_k_iterate_gridl_tp (round 6): the iteration kernel of streaming launches above 262 144 particles of tether-free grid
+    cloths -- the evaluation loop at the reference's task sizes.  Springs are gathered and evaluated in two halves of six; a half
+    whose neighbours all have the particle's own mass takes the equal-mass form (no out-of-grid test: a slot that leaves the grid
+    gathers the particle itself and has length 0), a wavefront that sees a pinned particle takes the general form for that half.
+    60 cloths of three sizes (342 k particles) crumpled into heaps; some with a PINNED particle (invMass 0, also one on the cloth's
+    border and one in its first row), some with two MOVING kinematic spheres; two fs_step calls and a launch of a subset that
+    is itself above the threshold.  Sampled episodes: the oracle's bits; and FLINGSIM_GRIDL_TP=0 (the general kernel) gives the
+    same bits for every episode."""
+    from flingbot_amd import sim as fsim
+
+    dims = [(64, 64), (72, 80), (96, 70)]
+    n_envs, steps = 60, 6
+
+    def setup(sim, k):
+        dx, dz = dims[k % 3]
+        sim.set_scene(cloth_params(dx, dz, pos=(0.0, -0.12, 0.0)))
+        rng = np.random.RandomState(50 + k)
+        pos = sim.get_positions().reshape(-1, 4).copy()
+        pos[:, :3] += (rng.randn(pos.shape[0], 3) * 0.004).astype(np.float32)
+        pos[:2000, :3] = (rng.rand(2000, 3) * [0.1, 0.04, 0.1] + [0.0, 0.02, 0.0]).astype(np.float32)
+        if k % 4 == 1:                       # pinned particles: interior, border column, first row
+            for pin in (dx * (dz // 2) + dx // 2, dx * 3, 5):
+                pos[pin, 3] = 0.0
+                pos[pin, 1] += 0.05
+        sim.set_positions(pos.ravel())
+        if k % 4 == 2:
+            for c in ((0.03, 0.04, 0.03), (0.08, 0.05, 0.06)):
+                sim.add_sphere(0.02, c, [1, 0, 0, 0])
+
+    def move_spheres(get, put):
+        st = np.array(get(), np.float32).reshape(-1, 14)
+        st[:, 3:6] = st[:, 0:3]
+        st[:, 0] += np.float32(0.002)
+        put(st.ravel())
+
+    sample = [0, 1, 2, 5, 9, 14, 37, 58, 59]
+    from oracle import OracleSim
+    orcs = {k: OracleSim() for k in sample}
+
+    def run_oracle(k):
+        setup(orcs[k], k)
+        for f in range(steps):
+            if k % 4 == 2:
+                move_spheres(orcs[k].get_shape_states, orcs[k].set_shape_states)
+            orcs[k].step()
+    threads = [threading.Thread(target=run_oracle, args=(k,)) for k in sample]
+    [t.start() for t in threads]
+    subset = [k for k in range(n_envs) if k % 7 != 3]
+    states = {}
+    for tp in ("1", "0"):
+        os.environ["FLINGSIM_GRIDL_TP"] = tp          # read by the library at every launch sequence
+        try:
+            ctx = fsim.FlingSim(n_envs=n_envs, solver=fsim.FS_SOLVER_AUTO)
+            for k in range(n_envs):
+                setup(ctx.env(k), k)
+            for f in range(steps):
+                for k in range(2, n_envs, 4):
+                    move_spheres(lambda k=k: ctx.get_shape_states(k), lambda s, k=k: ctx.set_shape_states(k, s))
+                if f != 3:
+                    ctx.step(1)
+                    want = fsim.FS_FORM_STREAM_GRIDL_TP if tp == "1" else fsim.FS_FORM_STREAM_GRIDL
+                    assert ctx.last_kernel_form() == want, (tp, ctx.last_kernel_form())
+                else:
+                    ctx.step_list(subset, 1)
+                    ctx.step_list([k for k in range(n_envs) if k % 7 == 3], 1)
+            if tp == "1":
+                [t.join() for t in threads]
+                for k in sample:
+                    _assert_bits(ctx, k, orcs[k], f"throughput form, episode {k} ({dims[k % 3]})")
+            states[tp] = [np.array(ctx.get_positions(k)).view(np.uint32).copy() for k in range(n_envs)]
+            ctx.close()
+        finally:
+            os.environ.pop("FLINGSIM_GRIDL_TP", None)
+    for k in range(n_envs):
+        assert np.array_equal(states["1"][k], states["0"][k]), k
