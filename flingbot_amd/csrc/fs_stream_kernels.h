@@ -812,7 +812,7 @@ __device__ __forceinline__ void fs_iterate_particle_gridl_tp(const FsEnvDev &E, 
             const bool in = (unsigned)(ix + cdx[q]) < (unsigned)dimx && (unsigned)(iz + cdz[q]) < (unsigned)dimz;
             inb |= (unsigned)in << r;
             xj[r] = fs_ld4o(src, in ? (unsigned)(i + cdz[q] * dimx + cdx[q]) : ui);
-            L[r] = fs_ldo(E.g64_L, (unsigned)q * un + ui);
+            L[r] = fs_ldo(E.g64_L + (size_t)q * un, ui);   // (the slot's row as a scalar base: one shared vector offset for all twelve)
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) same = same & (xj[r].w == xi.w);
