@@ -270,22 +270,23 @@ def eval_limiter_from_profile():
     for tag in profile_tags("eval_shapes.txt"):
         try:
             txt = open(os.path.join(ROOT, "profiles", f"{tag}_eval_shapes.txt")).read()
-            block = txt.split("# PMC pass, case A", 1)[1].split("# PMC pass, case B", 1)[0]
+            block = txt.rsplit("# PMC pass, case A", 1)[1].split("# PMC pass, case B", 1)[0]   # the newest pass of the file
             ker = {}
             for m in re.finditer(r"^(?:void )?(fs_k_\w+).*?\s+launches\s+(\d+)\s+waves/launch\s+(\d+)\s+VALU/wave\s+(\d+)\s+"
                                  r"valu_active/wave_cycles ([0-9.]+)", block, re.M):
                 ker[m.group(1)] = {"waves_per_launch": int(m.group(3)), "valu_per_wave": int(m.group(4)),
                                    "valu_active_per_wave_cycle": float(m.group(5))}
-            if "fs_k_iterate_gridl" not in ker:
+            name, waves = ("fs_k_iterate_gridl_tp", 6) if "fs_k_iterate_gridl_tp" in ker else ("fs_k_iterate_gridl", 5)
+            if name not in ker:
                 continue
-            it = ker["fs_k_iterate_gridl"]
+            it = ker[name]
             return {"bound": "valu-issue", "source": f"profiles/{tag}_eval_shapes.txt (case A: 132 stored tasks, crumpled, plain fs_step)",
-                    "kernels": ker, "iterate_valu_busy_fraction": it["valu_active_per_wave_cycle"] / 0.2,
-                    "note": "fs_k_iterate_gridl (79 % of the loop's kernel time) runs 5 waves per SIMD, so VALU-active per wave-cycle "
-                            "tops out at 0.2: at this launch size the kernel is VALU-bound on instructions that are ~40 % contact "
-                            "evaluation -- not the one-wave critical path of the 64-episode launch (DESIGN.md 6 has the frame's "
-                            "accounting: uniform benchmark 2.05 ms, + 0.5 ground contact and size mix, + 1.1 particle contacts, "
-                            "+ 0.5 the loop itself)"}
+                    "kernels": ker, "iterate_kernel": name, "iterate_waves_per_simd": waves,
+                    "iterate_valu_busy_fraction": it["valu_active_per_wave_cycle"] * waves,
+                    "note": f"{name} (~79 % of the loop's kernel time) runs {waves} waves per SIMD, so VALU-active per wave-cycle tops out "
+                            f"at 1/{waves}: at this launch size the kernel is VALU-bound on instructions of which ~40 % are contact "
+                            "evaluations -- not the one-wave critical path of the 64-episode launch (DESIGN.md 6 has the frame's "
+                            "accounting: uniform benchmark, + ground contact and size mix, + particle contacts, + the loop itself)"}
         except Exception:
             continue
     return None

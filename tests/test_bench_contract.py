@@ -97,5 +97,5 @@ def test_eval_loop_limiter_reads_the_committed_counters():
     lim = bench.eval_limiter_from_profile()
     assert lim and lim["bound"] == "valu-issue" and lim["source"].startswith("profiles/r")
     k = lim["kernels"]
-    assert {"fs_k_iterate_gridl", "fs_k_find_neighbors", "fs_k_boundary"} <= set(k)
-    assert 300 < k["fs_k_iterate_gridl"]["valu_per_wave"] < 1500 and 0.5 < lim["iterate_valu_busy_fraction"] <= 1.05
+    assert {lim["iterate_kernel"], "fs_k_find_neighbors", "fs_k_boundary"} <= set(k)
+    assert 300 < k[lim["iterate_kernel"]]["valu_per_wave"] < 1500 and 0.5 < lim["iterate_valu_busy_fraction"] <= 1.05
