@@ -630,7 +630,10 @@ int fs_step_ids(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const int
         // root): streaming 1.46 / 1.73 / 1.95 / 2.15 / 2.31 / 2.61 / 3.62 ms per step at 96 / 128 / 144 / 160 / 176 / 192 / 256
         // episodes against a flat 2.04-2.16 ms of the grid-64 fused kernel (~158 episodes) and 2.46-2.63 ms of the
         // dictionary-coded fused kernel (~190)
-        if (particles < (size_t)(grid64 ? 160 : 192) * 4096) solver = FS_SOLVER_STREAM;
+        // round 6, with the throughput form of the grid-L iteration (fs_k_iterate_gridl_tp) in the streaming back-end: streaming 1.70 /
+        // 1.88 / 1.99 / 2.14 / 2.34 / 2.51 / 2.65 ms per step at 128 / 144 / 160 / 176 / 192 / 208 / 224 episodes against 2.10-2.16 ms
+        // (grid-64) and 2.51-2.64 ms (dictionary-coded): the crossovers moved from ~158 / ~190 to ~176 / ~224 episodes
+        if (particles < (size_t)(grid64 ? 176 : 224) * 4096) solver = FS_SOLVER_STREAM;
     } else if (solver == FS_SOLVER_FUSED) {
         for (int id : ids)
             if (!fs_fused_supported(ctx, ctx->envs[id])) {

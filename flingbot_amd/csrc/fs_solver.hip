@@ -174,7 +174,7 @@ int fs_step_stream(fs_ctx *ctx, const std::vector<int> &ids, int n_steps, const 
     // large launches of tether-free cloths: the throughput instantiation (fs_stream_kernels.h TP; FLINGSIM_GRIDL_TP=0 keeps the general form)
     const char *tp_str = getenv("FLINGSIM_GRIDL_TP");   // (read per call: the tests switch it inside one process)
     const int tp_env = tp_str ? atoi(tp_str) : 1;
-    if (gridl_form && !gridl_posk && gridl_halvable_all && tp_env > 0) {
+    if (gridl_form && gridl_halvable_all && ((!gridl_posk && tp_env > 0) || tp_env > 1)) {   // (FLINGSIM_GRIDL_TP=2, developer: at every launch size)
         iter_kernel = fs_k_iterate_gridl_tp;
         ctx->last_form = FS_FORM_STREAM_GRIDL_TP;
     }
